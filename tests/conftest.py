@@ -1,0 +1,20 @@
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "ref: needs oracle/_ref (the real reference, build container only)")
+
+
+def pytest_collection_modifyitems(config, items):
+    from _oracle import have_ref
+    skip_ref = pytest.mark.skip(reason="oracle/_ref not built here (/root/reference absent)")
+    for item in items:
+        if "ref" in item.keywords and not have_ref("strict"):
+            item.add_marker(skip_ref)

@@ -1,0 +1,87 @@
+"""CPU, build container only (marker `ref`): the oracle against the REAL reference compiled by
+oracle/Makefile from /root/reference (C source-order flags).  Randomised beyond the golden scripts."""
+import numpy as np
+import pytest
+
+from _oracle import (OracleResampler, RefResampler, noise, BH, INTERP, LOWPASS, PRECISE, load_oracle, load_ref)
+from _artest import run_artest, PRESETS
+from test_oracle_golden import artest_backend
+
+pytestmark = pytest.mark.ref
+
+
+def random_script(rng, taps, ratio, calls=14):
+    s = []
+    for _ in range(calls):
+        kind = rng.integers(0, 10)
+        n = int(rng.integers(0, 6 * taps)) if kind < 8 else int(rng.integers(14 * taps, 18 * taps))
+        cap = int(rng.integers(1, 8 * taps)) if kind != 3 else int(rng.integers(1, 16))
+        s.append((n, cap, ratio * (1 + rng.uniform(-2e-4, 2e-4)) if kind == 5 else ratio, False))
+    s.append((0, 4 * taps, ratio, True))
+    s.append((5, 40, ratio, False))
+    return s
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_configs_bit_exact(seed):
+    rng = np.random.default_rng(seed)
+    taps = int(rng.choice([4, 8, 16, 48, 64, 156, 380]))
+    filters = int(rng.choice([1, 2, 7, 32, 160, 380, 1024]))
+    ch = int(rng.integers(1, 5))
+    ratio = float(rng.choice([48000 / 44100, 44100 / 96000, 0.5, 2.0, 1.0, 1 / 3.0, 3.7]))
+    flags = int(rng.choice([BH | INTERP, BH, INTERP, 0, BH | INTERP | PRECISE, BH | PRECISE]))
+    lowpass = float(rng.choice([0.0, 0.0, 0.45, 0.9]))
+    adv = float(rng.choice([0.0, taps / 2, taps / 2 + 0.37])) if flags & INTERP else float(rng.choice([0.0, taps / 2]))
+    script = random_script(rng, taps, ratio)
+    x, _ = noise((sum(n for n, *_ in script) + 8) * ch, state=0x1234567 + seed)
+    x = x.reshape(-1, ch)
+    outs = []
+    for cls in (OracleResampler, RefResampler):
+        r = cls(ch, taps, filters, lowpass, flags)
+        r.advance(adv)
+        pos, ys, tr = 0, [], []
+        for (n, cap, rat, flush) in script:
+            if flush:
+                # skip configurations that would take the reference into its out-of-bounds flush
+                if r.state()[1] > 15 * taps + taps // 2:
+                    r.process(x[pos:pos + taps], 8 * taps, rat)
+                    pos += taps
+                u, g, y = r.process(None, cap, rat, flush=True)
+            else:
+                u, g, y = r.process(x[pos:pos + n], cap, rat)
+                pos += u
+            ys.append(y)
+            tr.append((u, g) + r.state())
+        outs.append((np.concatenate(ys), tr))
+    assert outs[0][1] == outs[1][1]
+    assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
+
+
+def test_threads_and_dry_runs_match_reference():
+    Lo, Lr = load_oracle(), load_ref()
+    for ratio in (48000 / 44100, 44100 / 96000):
+        o = OracleResampler(4, 64, 64, 0.0, BH | INTERP)
+        r = RefResampler(4, 64, 64, 0.0, BH | INTERP | 0x8)      # RESAMPLE_MULTITHREADED
+        x, _ = noise(4 * 5000)
+        x = x.reshape(-1, 4)
+        for k in range(4):
+            for n in (1, 17, 400):
+                assert Lo.ora_resample_required_input(o.p, n, ratio) == Lr.resampleGetRequiredSamples(r.p, n, ratio)
+                assert Lo.ora_resample_expected_output(o.p, n, ratio) == Lr.resampleGetExpectedOutput(r.p, n, ratio)
+            assert Lo.ora_resample_expected_output(o.p, -1, ratio) == Lr.resampleGetExpectedOutput(r.p, -1, ratio)
+            uo, go, yo = o.process(x[k * 1000:(k + 1) * 1000], 3000, ratio, threads=4)
+            ur, gr, yr = r.process(x[k * 1000:(k + 1) * 1000], 3000, ratio)
+            assert (uo, go) == (ur, gr) and np.array_equal(yo.view(np.uint32), yr.view(np.uint32))
+            assert o.position() == r.position()
+
+
+def test_reference_flush_out_of_bounds_is_confined_to_the_tail():
+    """`artest -4 -e -l -c8 -n2 -s96000 -d44100`: the reference's flush reads before buffers[c][0]
+    (resampler.c:667-672 keeps `taps` samples, windows reach taps/2 further back).  Everything
+    before the flush tail is bit-identical; the tail differs by < 1e-9."""
+    mk = lambda cls: run_artest(lambda: artest_backend(cls, 4, 8, 96000, 44100, exact=True, lowpass=True), 8, 988,
+                                96000, 44100, 2, ratio_arg=0.0, collect=True)["y"]
+    a, b = mk(OracleResampler), mk(RefResampler)
+    tail = int(988 / 2 * 44100 / 96000) + 2
+    assert np.array_equal(a[:-tail].view(np.uint32), b[:-tail].view(np.uint32))
+    assert np.abs(a[-tail:] - b[-tail:]).max() < 1e-9
