@@ -1,0 +1,60 @@
+"""Build libartamd.so (C host layer + gfx950 HIP kernels) in-tree.
+
+    python -m audio_resampler_amd.build        # or: from audio_resampler_amd.build import build; build()
+
+hipcc cross-compiles gfx950 without a GPU.  -ffp-contract=off is load-bearing: the reference's
+position arithmetic, fp64 lerp, biquad and decimator are un-fused; the only FMAs are explicit.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INC = os.path.join(os.path.dirname(HERE), "include")
+OUT = os.path.join(HERE, "libartamd.so")
+
+C_SOURCES = ["resampler_host.c", "pcm_host.c"]
+HIP_SOURCES = ["device_rt.hip", "sinc_fir.hip", "pcm_kernels.hip"]
+HEADERS = [os.path.join(CSRC, "art_internal.h")] + [os.path.join(INC, h) for h in ("art_hip.h", "resampler.h", "biquad.h", "decimator.h")]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(HERE, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    for src in C_SOURCES:
+        s, o = os.path.join(CSRC, src), os.path.join(objdir, src + ".o")
+        objs.append(o)
+        if force or _stale(o, [s] + HEADERS):
+            cmd = ["gcc", "-std=c99", "-O2", "-ffp-contract=off", "-fPIC", "-Wall", "-I", INC, "-I", CSRC, "-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+    for src in HIP_SOURCES:
+        s, o = os.path.join(CSRC, src), os.path.join(objdir, src + ".o")
+        objs.append(o)
+        if force or _stale(o, [s] + HEADERS):
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
+                   "-I", INC, "-I", CSRC, "-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+    if force or _stale(OUT, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-lm", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

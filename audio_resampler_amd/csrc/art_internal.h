@@ -1,0 +1,85 @@
+/* art_internal.h — private C ABI between the C host layer (resampler_host.c, pcm_host.c) and the
+ * HIP translation units (device_rt.hip, sinc_fir.hip, pcm_kernels.hip).  Plain C types only. */
+#ifndef ART_INTERNAL_H
+#define ART_INTERNAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "art_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ART_MAX_SEGS 64          /* ring-epoch segments per kernel launch (passed by value) */
+
+/* numeric modes of the FIR */
+enum { ART_MODE_FAST = 0,        /* f32 FMA accumulation, any order (default) */
+       ART_MODE_PRECISE = 1,     /* f64 accumulation (EXTEND_CONVOLUTION_MATH) */
+       ART_MODE_STRICT = 2 };    /* reference C source order, un-fused (RESAMPLE_STRICT_ORDER) */
+
+enum { ART_KERNEL_AUTO = 0, ART_KERNEL_GENERAL = 1, ART_KERNEL_MFMA = 2 };
+
+typedef struct {
+    int count;
+    int lin_floor;                       /* linear indices below this read as silence */
+    unsigned int first [ART_MAX_SEGS];   /* first output (call-relative) of each segment, ascending */
+    int lin_base [ART_MAX_SEGS];         /* ring index -> linear index (history ++ input) */
+    double base [ART_MAX_SEGS];          /* outputOffset of the ring epoch */
+} ArtSegTable;
+
+typedef struct {
+    const float *bank;                   /* device, (F+1) x T */
+    const float *hist;                   /* device, H frames x C, interleaved */
+    const float *in;                     /* device, new input frames */
+    long in_pitch;                       /* 0: interleaved [frame][C]; else planar, channel c at in + c*in_pitch */
+    float *out;
+    long out_pitch;                      /* 0: interleaved; else planar */
+    int in_frames;                       /* frames valid at `in` (reads beyond return 0) */
+    int C, T, F, H;
+    int interpolate, lowpass;            /* SUBSAMPLE_INTERPOLATE / INCLUDE_LOWPASS in effect */
+    int mode;                            /* ART_MODE_* */
+    double ratio;
+    unsigned int n_begin, n_end;         /* call-relative output frames to produce */
+    /* periodic-phase structure for the MFMA kernel (0 = none): out frame n+period_out sits exactly
+     * period_in input frames after out frame n */
+    int period_out, period_in;
+} ArtFirArgs;
+
+/* ---- device_rt.hip ---- */
+int   arthip_device_count (void);
+void *arthip_malloc (size_t bytes);
+void  arthip_free (void *p);
+int   arthip_h2d (void *dst, const void *src, size_t bytes, void *stream);
+int   arthip_d2h (void *dst, const void *src, size_t bytes, void *stream);
+int   arthip_d2d (void *dst, const void *src, size_t bytes, void *stream);
+int   arthip_zero (void *dst, size_t bytes, void *stream);
+int   arthip_sync (void *stream);
+const char *arthip_last_error (void);
+
+/* ---- sinc_fir.hip ---- */
+/* returns the kernel actually used (ART_KERNEL_*), <0 on launch failure */
+int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, void *stream);
+/* new_hist[H][C] = last H frames of (hist ++ in[0..appended)); in may be NULL => zeros appended */
+int arthip_roll_history (float *new_hist, const float *hist, const float *in, long in_pitch, int appended, int H, int C, void *stream);
+int arthip_interleave (float *dst, const float *src_planar, long pitch, int frames, int C, void *stream);
+int arthip_deinterleave (float *dst_planar, long pitch, const float *src, int frames, int C, void *stream);
+
+/* ---- pcm_kernels.hip ---- */
+typedef struct {
+    int C, bits, bytes, dither_type, dither_on, shaping_on;
+    float scale;
+    float *feedback;                     /* device [C] */
+    uint32_t *gens;                      /* device [C] */
+    Biquad *shapers;                     /* device [C] */
+    unsigned long long *clipped;         /* device counter */
+} ArtDecArgs;
+int arthip_decimate (const ArtDecArgs *a, const float *d_in, int frames, unsigned char *d_out, void *stream);
+int arthip_decimate_planar (const ArtDecArgs *a, const float *d_in, long in_pitch, int frames, unsigned char *d_out, long out_pitch, void *stream);
+int arthip_biquad_chain (Biquad *d_sections, int C, int S, float *d_buf, int frames, int stride, void *stream);
+int arthip_ingest (const unsigned char *d_in, float gain_factor, int bits, int bytes, int stride, float *d_out, int n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

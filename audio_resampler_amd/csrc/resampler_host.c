@@ -1,0 +1,641 @@
+/* resampler_host.c — host (C) side of the MI355X sinc resampler.
+ *
+ * What runs here, on the CPU, is only what is inherently scalar and O(1)..O(log n) per call:
+ *   - filter-bank design in fp64 (once per context)           reference resampler.c:1090-1133, :149-168
+ *   - fixed-ratio resolution (gcd / auto low-pass)            reference resampler.c:310-356
+ *   - the position state machine, replayed in CLOSED FORM     reference resampler.c:487-537 (loop form)
+ *   - getters / dry runs                                       reference resampler.c:365-397, :853-968
+ * Every output sample is computed on the GPU (sinc_fir.hip).  There is no CPU evaluation path:
+ * without a device the init functions fail loudly.
+ */
+#define _USE_MATH_DEFINES
+#include <limits.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "art_internal.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+#define HIST_FRAMES(T) ((T) + (T) / 2)      /* frames of history kept in HBM between calls */
+
+struct artamd_resampler {
+    void *stream;
+    float *d_bank;
+    float *d_hist [2];                      /* ping-pong history, HIST x C interleaved */
+    int cur;
+    float *d_in;  size_t in_cap;            /* staging for host-pointer calls (bytes) */
+    float *d_out; size_t out_cap;
+    float *d_tmp; size_t tmp_cap;           /* planar <-> interleaved scratch */
+    ArtamdSegment *segs; int seg_cap;
+    int floor_active;                       /* ring index 0 is a hard history floor (after a flush-time rewind) */
+    int kernel_pref, last_kernel;
+    /* cached rational structure of the current ratio */
+    double period_ratio; int period_out, period_in;
+};
+
+/* ------------------------------------------------------------------------------------------
+ * Filter bank
+ * ---------------------------------------------------------------------------------------- */
+
+/* One polyphase row: windowed sinc centred (T/2 - 1 + phase) taps in, DC-normalised, rounded to
+ * float from the centre outwards with the rounding error carried along. */
+static void design_row (float *row, double *work, int T, double phase, double lowpass, int use_bh)
+{
+    const int mid = T / 2;
+    double dc = 0.0;
+
+    for (int k = 0; k < T; ++k) {
+        double radians = fabs ((mid - 1) + phase - k) * M_PI;
+        double wphase = radians / mid;
+        double tap = 1.0;
+
+        if (radians != 0.0) {
+            tap = sin (radians * lowpass) / (radians * lowpass);
+            tap *= use_bh ? 0.35875 + 0.48829 * cos (wphase) + 0.14128 * cos (2 * wphase) + 0.01168 * cos (3 * wphase)
+                          : 0.5 * (1.0 + cos (wphase));
+        }
+
+        dc += work [k] = tap;
+    }
+
+    const double unity = 1.0 / dc;
+    double residue = 0.0;
+
+    /* visiting order mid, mid-1, mid+1, mid-2, ..., 0 */
+    for (int step = 0, k = mid; step < T; ++step, k = (k >= mid) ? T - k - 1 : T - k) {
+        work [k] *= unity;
+        row [k] = (float)(work [k] - residue);
+        residue += row [k] - work [k];
+    }
+}
+
+void artamdBuildFilterBank (int T, int F, double lowpass, int flags, artsample_t *bank)
+{
+    double *work = malloc (sizeof (double) * (size_t) T);
+
+    memset (bank, 0, sizeof (float) * (size_t)(F + 1) * T);
+
+    for (int f = 0; f < F; ++f)
+        design_row (bank + (size_t) f * T, work, T, (double) f / F, lowpass, flags & BLACKMAN_HARRIS);
+
+    for (int k = 0; k < T; ++k)                         /* row F: row 0 one tap later */
+        bank [(size_t) F * T + (k + 1) % T] = bank [k];
+
+    bank [T - 1] = 0.0f;                                /* clear the two window outliers */
+    bank [(size_t) F * T] = 0.0f;
+    free (work);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Position state machine in closed form
+ *
+ * The reference alternates "consume one input frame" / "emit one output frame" in a scalar loop
+ * (resampler.c:494-529).  Output j (counted from the start of the call) sits at ring position
+ * base + j/ratio and can be emitted once inputIndex > position + T/2.  Because fl(base + fl(j/ratio))
+ * is monotone in j, the number of outputs reachable with a given inputIndex is found by bisection,
+ * and the ring rewinds (every 15T consumed frames) split the call into segments with their own
+ * `base`.  The arithmetic that decides emit-vs-consume is the reference's own comparison, so the
+ * counts and the carried position are bit-identical to the loop.
+ * ---------------------------------------------------------------------------------------- */
+
+int artamdPlanCall (ArtamdPosition *p, int nIn, int cap, double ratio, ResampleResult *result,
+                    ArtamdSegment *segs, int max_segs, int *lin_floor_out)
+{
+    const int T = p->numTaps, half = T / 2, ring = 16 * T, drop = 15 * T;
+    double base = p->outputOffset;
+    int wp = p->inputIndex, flags = p->flags;
+    int nseg = 0;
+
+    if (flags & RESAMPLE_FIXED_RATIO) ratio = p->fixedRatio;
+    if (flags & RESAMPLER_FLUSHED) nIn = 0;
+
+    int lin_base = HIST_FRAMES (T) - wp;
+    int lin_floor = p->floorActive ? lin_base : INT_MIN;
+
+    if (nIn < 0) {                                      /* flush: half a window of silence is appended */
+        if (ring - wp < half) {                         /* resampler.c:667-672; see DESIGN.md "reference bugs" */
+            base -= drop; wp -= drop; lin_base += drop;
+            p->floorActive = 1;
+            lin_floor = lin_base;
+        }
+        flags |= RESAMPLER_FLUSHED;
+        wp += half;
+        nIn = 0;
+    }
+
+    unsigned int made = 0, used = 0;
+    const unsigned int ucap = cap > 0 ? (unsigned int) cap : 0;
+    long left = nIn;
+
+#define PUSH_SEGMENT() do { if (nseg < max_segs) { segs [nseg].first_output = made; segs [nseg].lin_base = lin_base; \
+                                                   segs [nseg].base_offset = base; } nseg++; } while (0)
+    PUSH_SEGMENT ();
+
+    if (!(ratio > 0.0))                                 /* the reference never terminates sensibly here */
+        cap = 0;
+
+    while (made < ucap && cap > 0) {
+        long reach = (long) wp + left;
+        int top = reach < ring ? (int) reach : ring;    /* highest inputIndex reachable in this ring epoch */
+        double limit = (double)(top - half);
+        unsigned int lo = made, hi = ucap;
+
+        while (lo < hi) {                               /* first j with position(j) >= limit */
+            unsigned int mid = lo + (hi - lo) / 2;
+            if (base + (double) mid / ratio < limit) lo = mid + 1; else hi = mid;
+        }
+
+        if (lo > made) {                                /* inputs consumed on the way to output lo-1 */
+            long need = (long) floor (base + (double)(lo - 1) / ratio) + half + 1;
+            if (need > wp) { used += (unsigned int)(need - wp); left -= need - wp; wp = (int) need; }
+            made = lo;
+        }
+
+        if (made == ucap) break;
+
+        used += (unsigned int)(top - wp); left -= top - wp; wp = top;
+
+        if (left <= 0) break;                           /* output `made` needs input we do not have */
+
+        base -= drop; wp -= drop; lin_base += drop;     /* ring full: rewind, then take the frame that forced it */
+        wp++; used++; left--;
+        PUSH_SEGMENT ();
+    }
+#undef PUSH_SEGMENT
+
+    base += made ? (double) made / ratio : 0.0;
+
+    if (flags & RESAMPLER_SNAP_OFFSET)
+        base = floor (base) + floor ((base - floor (base)) * p->numFilters + 0.5) / p->numFilters;
+
+    p->outputOffset = base; p->inputIndex = wp; p->flags = flags;
+    result->input_used = used; result->output_generated = made;
+    if (lin_floor_out) *lin_floor_out = lin_floor;
+    return nseg;
+}
+
+/* smallest p/q (q <= 4096) whose double quotient equals `ratio` bit for bit; 0 if none */
+static void find_period (double ratio, int *p_out, int *q_out)
+{
+    *p_out = *q_out = 0;
+    if (!(ratio > 1.0 / 4096 && ratio < 4096)) return;
+
+    double x = ratio;
+    long h0 = 0, h1 = 1, k0 = 1, k1 = 0;               /* continued-fraction convergents h/k */
+
+    for (int it = 0; it < 32; ++it) {
+        double a = floor (x);
+        long h2 = (long) a * h1 + h0, k2 = (long) a * k1 + k0;
+        if (k2 > 4096 || h2 > 4096 * 4096L) return;
+        if ((double) h2 / (double) k2 == ratio) { if (h2 <= 4096) { *p_out = (int) h2; *q_out = (int) k2; } return; }
+        h0 = h1; h1 = h2; k0 = k1; k1 = k2;
+        double frac = x - a;
+        if (frac < 1e-12) return;
+        x = 1.0 / frac;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Contexts
+ * ---------------------------------------------------------------------------------------- */
+
+static void *grow (void *dev, size_t *cap, size_t need)
+{
+    if (need <= *cap) return dev;
+    arthip_free (dev);
+    size_t want = need + need / 2 + 4096;
+    dev = arthip_malloc (want);
+    *cap = dev ? want : 0;
+    return dev;
+}
+
+Resample *resampleInit (int numChannels, int numTaps, int numFilters, double lowpassRatio, int flags)
+{
+    if (lowpassRatio > 0.0 && lowpassRatio < 1.0)
+        flags |= INCLUDE_LOWPASS;
+    else {
+        flags &= ~INCLUDE_LOWPASS;
+        lowpassRatio = 1.0;
+    }
+
+    if ((numTaps & 3) || numTaps <= 0 || numTaps > 1024) {
+        fprintf (stderr, "must 4-1024 filter taps, and a multiple of 4!\n");
+        return NULL;
+    }
+
+    if (numFilters < 1 || numFilters > 1024) {
+        fprintf (stderr, "must be 1-1024 filters!\n");
+        return NULL;
+    }
+
+    if (numChannels < 1) {
+        fprintf (stderr, "must have at least one channel!\n");
+        return NULL;
+    }
+
+    if (arthip_device_count () < 1) {
+        fprintf (stderr, "artamd: no usable HIP device (this library has no CPU path): %s\n", arthip_last_error ());
+        return NULL;
+    }
+
+    { const char *env = getenv ("ARTAMD_STRICT"); if (env && *env && *env != '0') flags |= RESAMPLE_STRICT_ORDER; }
+
+    Resample *cxt = calloc (1, sizeof (Resample));
+    struct artamd_resampler *hip = calloc (1, sizeof (*hip));
+    const size_t bank_count = (size_t)(numFilters + 1) * numTaps;
+    const size_t hist_bytes = sizeof (float) * (size_t) HIST_FRAMES (numTaps) * numChannels;
+
+    cxt->hip = hip;
+    cxt->numChannels = numChannels;
+    cxt->numSamples = numTaps * 16;
+    cxt->numFilters = numFilters;
+    cxt->numTaps = numTaps;
+    cxt->flags = flags;
+    cxt->lowpassRatio = lowpassRatio;
+    cxt->outputOffset = numTaps / 2;
+    cxt->inputIndex = numTaps;
+
+    /* host copy of the bank, exposed through the reference's `filters` row-pointer table */
+    float *bank = malloc (sizeof (float) * bank_count);
+    artamdBuildFilterBank (numTaps, numFilters, lowpassRatio, flags, bank);
+    cxt->filters = malloc (sizeof (float *) * (size_t)(numFilters + 1));
+    for (int f = 0; f <= numFilters; ++f)
+        cxt->filters [f] = bank + (size_t) f * numTaps;
+
+    hip->d_bank = arthip_malloc (sizeof (float) * bank_count);
+    hip->d_hist [0] = arthip_malloc (hist_bytes);
+    hip->d_hist [1] = arthip_malloc (hist_bytes);
+    hip->seg_cap = 64;
+    hip->segs = malloc (sizeof (ArtamdSegment) * hip->seg_cap);
+
+    if (!hip->d_bank || !hip->d_hist [0] || !hip->d_hist [1] ||
+        arthip_h2d (hip->d_bank, bank, sizeof (float) * bank_count, NULL) ||
+        arthip_zero (hip->d_hist [0], hist_bytes, NULL) || arthip_zero (hip->d_hist [1], hist_bytes, NULL) ||
+        arthip_sync (NULL)) {
+        fprintf (stderr, "artamd: device allocation failed: %s\n", arthip_last_error ());
+        resampleFree (cxt);
+        return NULL;
+    }
+
+    if (flags & EXTRAPOLATE_ENDPOINTS)
+        cxt->flags |= EXTRAPOLATE_PREFILL;
+
+    return cxt;
+}
+
+static unsigned long gcd_of (unsigned long a, unsigned long b)
+{
+    while (b) { unsigned long r = a % b; a = b; b = r; }
+    return a;
+}
+
+Resample *resampleFixedRatioInit (int numChannels, int numTaps, int maxFilters, double sourceRate, double destinRate, int lowpassFreq, int flags)
+{
+    double lowpass = lowpassFreq / (destinRate / 2.0);
+    const double ratio = destinRate / sourceRate;
+
+    if (lowpassFreq > destinRate / 2.0) {
+        fprintf (stderr, "lowpass frequency must be lower than destination Nyquist!\n");
+        return NULL;
+    }
+
+    /* integer rates whose reduced numerator fits the filter budget need no interpolation at all */
+    if (sourceRate == floor (sourceRate) && destinRate == floor (destinRate) && !(flags & NO_FILTER_REDUCTION)) {
+        unsigned long phases = (unsigned long) destinRate / gcd_of ((unsigned long) sourceRate, (unsigned long) destinRate);
+
+        if (phases <= (unsigned long) maxFilters) {
+            flags &= ~SUBSAMPLE_INTERPOLATE;
+            maxFilters = (int) phases;
+
+            if (maxFilters & (maxFilters - 1))          /* phases not a power of two: re-quantise per call */
+                flags |= RESAMPLER_SNAP_OFFSET;
+        }
+    }
+
+    if (!lowpassFreq && (flags & INCLUDE_LOWPASS) && destinRate < sourceRate) {
+        lowpass = 1.0 - (7.5 / numTaps / ratio);
+        if (lowpass < 0.8) lowpass = 0.8;
+        if (lowpass < ratio) lowpass = ratio;
+    }
+
+    Resample *cxt = resampleInit (numChannels, numTaps, maxFilters, lowpass * ratio, flags | RESAMPLE_FIXED_RATIO);
+
+    if (cxt)
+        cxt->fixedRatio = destinRate / sourceRate;
+
+    return cxt;
+}
+
+void resampleFree (Resample *cxt)
+{
+    if (!cxt) return;
+
+    struct artamd_resampler *hip = cxt->hip;
+
+    if (hip) {
+        arthip_sync (hip->stream);
+        arthip_free (hip->d_bank); arthip_free (hip->d_hist [0]); arthip_free (hip->d_hist [1]);
+        arthip_free (hip->d_in); arthip_free (hip->d_out); arthip_free (hip->d_tmp);
+        free (hip->segs);
+        free (hip);
+    }
+
+    if (cxt->filters) { free (cxt->filters [0]); free (cxt->filters); }
+    free (cxt);
+}
+
+void resampleReset (Resample *cxt)
+{
+    struct artamd_resampler *hip = cxt->hip;
+    const size_t hist_bytes = sizeof (float) * (size_t) HIST_FRAMES (cxt->numTaps) * cxt->numChannels;
+
+    arthip_zero (hip->d_hist [0], hist_bytes, hip->stream);
+    arthip_zero (hip->d_hist [1], hist_bytes, hip->stream);
+    hip->floor_active = 0;
+    cxt->outputOffset = cxt->numTaps / 2;
+    cxt->inputIndex = cxt->numTaps;
+
+    if (cxt->flags & EXTRAPOLATE_ENDPOINTS)
+        cxt->flags |= EXTRAPOLATE_PREFILL;
+
+    cxt->flags &= ~RESAMPLER_FLUSHED;
+}
+
+double resampleGetLowpassRatio (Resample *cxt) { return cxt->lowpassRatio; }
+int resampleGetNumFilters (Resample *cxt) { return cxt->numFilters; }
+int resampleInterpolationUsed (Resample *cxt) { return cxt->flags & SUBSAMPLE_INTERPOLATE; }
+
+double resampleGetPosition (Resample *cxt)
+{
+    return cxt->outputOffset + (cxt->numTaps / 2.0) - cxt->inputIndex;
+}
+
+void resampleAdvancePosition (Resample *cxt, double delta)
+{
+    if (delta < 0.0)
+        fprintf (stderr, "resampleAdvancePosition() can only advance forward!\n");
+    else if (!(cxt->flags & SUBSAMPLE_INTERPOLATE) && floor (delta) != delta)
+        fprintf (stderr, "resampleAdvancePosition() cannot advance partial samples without interpolation!\n");
+    else
+        cxt->outputOffset += delta;
+}
+
+/* Dry runs.  These step the position by repeated addition of 1/ratio (reference resampler.c:874, :912)
+ * — deliberately NOT the division form the real run uses — so they are replayed as loops. */
+unsigned int resampleGetRequiredSamples (Resample *cxt, int numOutputFrames, double ratio)
+{
+    const int half = cxt->numTaps / 2, drop = cxt->numSamples - cxt->numTaps;
+    int wp = cxt->inputIndex;
+    double pos = cxt->outputOffset;
+    unsigned int used = 0;
+
+    if (cxt->flags & RESAMPLE_FIXED_RATIO) ratio = cxt->fixedRatio;
+    if (!(ratio > 0.0)) return 0;
+
+    while (numOutputFrames > 0)
+        if (pos >= wp - half) {
+            if (wp == cxt->numSamples) { pos -= drop; wp -= drop; }
+            wp++; used++;
+        }
+        else { pos += 1.0 / ratio; numOutputFrames--; }
+
+    return used;
+}
+
+unsigned int resampleGetExpectedOutput (Resample *cxt, int numInputFrames, double ratio)
+{
+    const int half = cxt->numTaps / 2, drop = cxt->numSamples - cxt->numTaps;
+    int wp = cxt->inputIndex;
+    double pos = cxt->outputOffset;
+    unsigned int made = 0;
+
+    if (cxt->flags & RESAMPLE_FIXED_RATIO) ratio = cxt->fixedRatio;
+    if (!(ratio > 0.0)) return 0;
+
+    if (cxt->flags & RESAMPLER_FLUSHED) numInputFrames = 0;
+    else if (numInputFrames < 0) wp += half;
+
+    for (;;)
+        if (pos >= wp - half) {
+            if (numInputFrames <= 0) break;
+            if (wp == cxt->numSamples) { pos -= drop; wp -= drop; }
+            wp++; numInputFrames--;
+        }
+        else { pos += 1.0 / ratio; made++; }
+
+    return made;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Processing
+ * ---------------------------------------------------------------------------------------- */
+
+void resampleHipSetStream (Resample *cxt, void *stream) { cxt->hip->stream = stream; }
+void resampleHipSynchronize (Resample *cxt) { arthip_sync (cxt->hip->stream); }
+void resampleHipSetKernel (Resample *cxt, int which) { cxt->hip->kernel_pref = which; }
+int  resampleHipLastKernel (Resample *cxt) { return cxt->hip->last_kernel; }
+
+/* Plan one call, enqueue the FIR launches and the history roll.  `d_in` holds the call's input on
+ * the device (interleaved, or planar with `in_pitch`); `d_out` receives the output likewise. */
+static ResampleResult enqueue_call (Resample *cxt, const float *d_in, long in_pitch, int nIn,
+                                    float *d_out, long out_pitch, int cap, double ratio)
+{
+    struct artamd_resampler *hip = cxt->hip;
+    const int T = cxt->numTaps, C = cxt->numChannels, H = HIST_FRAMES (T);
+    ResampleResult res = { 0, 0 };
+    ArtamdPosition pos, trial;
+    int lin_floor, nseg;
+
+    pos.numTaps = T; pos.numFilters = cxt->numFilters; pos.flags = cxt->flags; pos.inputIndex = cxt->inputIndex;
+    pos.floorActive = hip->floor_active; pos.outputOffset = cxt->outputOffset; pos.fixedRatio = cxt->fixedRatio;
+
+    const int is_flush = nIn < 0 && !(cxt->flags & RESAMPLER_FLUSHED);
+    const double eff_ratio = (cxt->flags & RESAMPLE_FIXED_RATIO) ? cxt->fixedRatio : ratio;
+
+    for (;;) {
+        trial = pos;
+        nseg = artamdPlanCall (&trial, nIn, cap, ratio, &res, hip->segs, hip->seg_cap, &lin_floor);
+        if (nseg <= hip->seg_cap) break;
+        hip->seg_cap = nseg + 16;
+        hip->segs = realloc (hip->segs, sizeof (ArtamdSegment) * hip->seg_cap);
+    }
+
+    if (eff_ratio != hip->period_ratio) {
+        hip->period_ratio = eff_ratio;
+        find_period (eff_ratio, &hip->period_out, &hip->period_in);
+    }
+
+    const int appended = is_flush ? T / 2 : (int) res.input_used;
+
+    if (res.output_generated) {
+        ArtFirArgs a;
+        memset (&a, 0, sizeof (a));
+        a.bank = hip->d_bank; a.hist = hip->d_hist [hip->cur];
+        a.in = is_flush ? NULL : d_in; a.in_pitch = in_pitch; a.in_frames = is_flush ? 0 : (int) res.input_used;
+        a.out = d_out; a.out_pitch = out_pitch;
+        a.C = C; a.T = T; a.F = cxt->numFilters; a.H = H;
+        a.interpolate = (cxt->flags & SUBSAMPLE_INTERPOLATE) != 0;
+        a.lowpass = (cxt->flags & INCLUDE_LOWPASS) != 0;
+        a.mode = (cxt->flags & RESAMPLE_STRICT_ORDER) ? ART_MODE_STRICT :
+                 (cxt->flags & EXTEND_CONVOLUTION_MATH) ? ART_MODE_PRECISE : ART_MODE_FAST;
+        if ((cxt->flags & RESAMPLE_STRICT_ORDER) && (cxt->flags & EXTEND_CONVOLUTION_MATH)) a.mode |= 4;
+        a.ratio = eff_ratio;
+        a.period_out = hip->period_out; a.period_in = hip->period_in;
+
+        for (int s0 = 0; s0 < nseg; s0 += ART_MAX_SEGS) {
+            const int s1 = s0 + ART_MAX_SEGS < nseg ? s0 + ART_MAX_SEGS : nseg;
+            ArtSegTable tab;
+
+            tab.count = s1 - s0; tab.lin_floor = lin_floor;
+            for (int s = s0; s < s1; ++s) {
+                tab.first [s - s0] = hip->segs [s].first_output;
+                tab.lin_base [s - s0] = hip->segs [s].lin_base;
+                tab.base [s - s0] = hip->segs [s].base_offset;
+            }
+            a.n_begin = hip->segs [s0].first_output;
+            a.n_end = s1 < nseg ? hip->segs [s1].first_output : res.output_generated;
+            if (a.n_end > a.n_begin) {
+                int k = arthip_fir (&a, &tab, hip->kernel_pref, hip->stream);
+                if (k < 0) { fprintf (stderr, "artamd: FIR launch failed: %s\n", arthip_last_error ()); res.input_used = res.output_generated = 0; return res; }
+                hip->last_kernel = k;
+            }
+        }
+    }
+
+    if (appended > 0) {
+        arthip_roll_history (hip->d_hist [hip->cur ^ 1], hip->d_hist [hip->cur], is_flush ? NULL : d_in, in_pitch, appended, H, C, hip->stream);
+        hip->cur ^= 1;
+    }
+
+    cxt->outputOffset = trial.outputOffset; cxt->inputIndex = trial.inputIndex;
+    cxt->flags = (cxt->flags & ~(RESAMPLER_FLUSHED | EXTRAPOLATE_PREFILL)) | (trial.flags & RESAMPLER_FLUSHED) |
+                 ((res.output_generated == 0) ? (cxt->flags & EXTRAPOLATE_PREFILL) : 0);
+    hip->floor_active = trial.floorActive;
+    return res;
+}
+
+ResampleResult resampleProcessInterleavedDevice (Resample *cxt, const artsample_t *d_input, int numInputFrames,
+                                                 artsample_t *d_output, int numOutputFrames, double ratio)
+{
+    return enqueue_call (cxt, d_input, 0, numInputFrames, d_output, 0, numOutputFrames, ratio);
+}
+
+ResampleResult resampleProcessPlanarDevice (Resample *cxt, const artsample_t *d_input, long inputPitch, int numInputFrames,
+                                            artsample_t *d_output, long outputPitch, int numOutputFrames, double ratio)
+{
+    return enqueue_call (cxt, d_input, inputPitch, numInputFrames, d_output, outputPitch, numOutputFrames, ratio);
+}
+
+ResampleResult resampleProcessAndFlushInterleavedDevice (Resample *cxt, const artsample_t *d_input, int numInputFrames,
+                                                         artsample_t *d_output, int numOutputFrames, double ratio)
+{
+    ResampleResult res = resampleProcessInterleavedDevice (cxt, d_input, numInputFrames, d_output, numOutputFrames, ratio);
+
+    if ((numInputFrames -= res.input_used) != 0 || (numOutputFrames -= res.output_generated) == 0)
+        return res;
+
+    ResampleResult tail = resampleProcessInterleavedDevice (cxt, NULL, -1, d_output + (size_t) res.output_generated * cxt->numChannels,
+                                                            numOutputFrames, ratio);
+    res.output_generated += tail.output_generated;
+    return res;
+}
+
+/* host-pointer call: how many input frames can this call consume at most / produce at most is known
+ * only after planning, so plan on a scratch copy first to size the transfers */
+static ResampleResult host_call (Resample *cxt, const float *input, const float *const *planes, int nIn,
+                                 float *output, float *const *out_planes, int cap, double ratio)
+{
+    struct artamd_resampler *hip = cxt->hip;
+    const int C = cxt->numChannels;
+    ResampleResult res = { 0, 0 }, peek;
+    ArtamdPosition pos;
+    int dummy_floor;
+
+    pos.numTaps = cxt->numTaps; pos.numFilters = cxt->numFilters; pos.flags = cxt->flags; pos.inputIndex = cxt->inputIndex;
+    pos.floorActive = hip->floor_active; pos.outputOffset = cxt->outputOffset; pos.fixedRatio = cxt->fixedRatio;
+    artamdPlanCall (&pos, nIn, cap, ratio, &peek, NULL, 0, &dummy_floor);
+
+    const size_t in_samples = (size_t) peek.input_used * C, out_samples = (size_t) peek.output_generated * C;
+
+    hip->d_in = grow (hip->d_in, &hip->in_cap, sizeof (float) * in_samples);
+    hip->d_out = grow (hip->d_out, &hip->out_cap, sizeof (float) * out_samples);
+    if ((in_samples && !hip->d_in) || (out_samples && !hip->d_out)) {
+        fprintf (stderr, "artamd: device allocation failed: %s\n", arthip_last_error ());
+        return res;
+    }
+
+    if (planes || out_planes) {
+        size_t big = in_samples > out_samples ? in_samples : out_samples;
+        hip->d_tmp = grow (hip->d_tmp, &hip->tmp_cap, sizeof (float) * big);
+    }
+
+    if (in_samples) {
+        if (planes) {
+            for (int c = 0; c < C; ++c)
+                arthip_h2d (hip->d_tmp + (size_t) c * peek.input_used, planes [c], sizeof (float) * peek.input_used, hip->stream);
+            arthip_interleave (hip->d_in, hip->d_tmp, peek.input_used, (int) peek.input_used, C, hip->stream);
+        }
+        else
+            arthip_h2d (hip->d_in, input, sizeof (float) * in_samples, hip->stream);
+    }
+
+    res = enqueue_call (cxt, hip->d_in, 0, nIn, hip->d_out, 0, cap, ratio);
+
+    if (res.output_generated) {
+        if (out_planes) {
+            arthip_deinterleave (hip->d_tmp, res.output_generated, hip->d_out, (int) res.output_generated, C, hip->stream);
+            for (int c = 0; c < C; ++c)
+                arthip_d2h (out_planes [c], hip->d_tmp + (size_t) c * res.output_generated, sizeof (float) * res.output_generated, hip->stream);
+        }
+        else
+            arthip_d2h (output, hip->d_out, sizeof (float) * (size_t) res.output_generated * C, hip->stream);
+    }
+
+    arthip_sync (hip->stream);
+    return res;
+}
+
+ResampleResult resampleProcessInterleaved (Resample *cxt, const artsample_t *input, int numInputFrames, artsample_t *output, int numOutputFrames, double ratio)
+{
+    return host_call (cxt, input, NULL, numInputFrames, output, NULL, numOutputFrames, ratio);
+}
+
+ResampleResult resampleProcess (Resample *cxt, const artsample_t *const *input, int numInputFrames, artsample_t *const *output, int numOutputFrames, double ratio)
+{
+    return host_call (cxt, NULL, input, numInputFrames, NULL, output, numOutputFrames, ratio);
+}
+
+ResampleResult resampleProcessAndFlushInterleaved (Resample *cxt, const artsample_t *input, int numInputFrames, artsample_t *output, int numOutputFrames, double ratio)
+{
+    ResampleResult res = resampleProcessInterleaved (cxt, input, numInputFrames, output, numOutputFrames, ratio);
+
+    /* unconsumed input or no room left: the caller made a mistake, report what happened */
+    if ((numInputFrames -= res.input_used) != 0 || (numOutputFrames -= res.output_generated) == 0)
+        return res;
+
+    ResampleResult tail = resampleProcessInterleaved (cxt, NULL, -1, output + (size_t) res.output_generated * cxt->numChannels, numOutputFrames, ratio);
+    res.output_generated += tail.output_generated;
+    return res;
+}
+
+ResampleResult resampleProcessAndFlush (Resample *cxt, const artsample_t *const *input, int numInputFrames, artsample_t *const *output, int numOutputFrames, double ratio)
+{
+    ResampleResult res = resampleProcess (cxt, input, numInputFrames, output, numOutputFrames, ratio);
+
+    if ((numInputFrames -= res.input_used) != 0 || (numOutputFrames -= res.output_generated) == 0)
+        return res;
+
+    float **shifted = malloc (sizeof (float *) * (size_t) cxt->numChannels);
+    for (int c = 0; c < cxt->numChannels; ++c)
+        shifted [c] = output [c] + res.output_generated;
+
+    ResampleResult tail = resampleProcess (cxt, NULL, -1, shifted, numOutputFrames, ratio);
+    res.output_generated += tail.output_generated;
+    free (shifted);
+    return res;
+}

@@ -1,0 +1,85 @@
+/* art_hip.h — MI355X extensions to the reference C API (additive; nothing here exists in the
+ * reference).  Device-pointer entry points take HIP device pointers, enqueue their work on the
+ * context's stream and return without synchronising: the frame counts in the result are computed
+ * on the host by replaying the reference's scalar position state machine
+ * (reference resampler.c:487-537) in closed form, so they are available immediately.
+ *
+ * One process drives one GPU: contexts bind to the HIP device that is current when they are
+ * created (so `torch.cuda.set_device(LOCAL_RANK)` before resampleInit shards channels across the
+ * GPUs of a node).
+ */
+#ifndef ARTAMD_ART_HIP_H
+#define ARTAMD_ART_HIP_H
+
+#include "resampler.h"
+#include "biquad.h"
+#include "decimator.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- runtime ---- */
+int artamdDeviceCount (void);                       /* 0 when no usable gfx950 device / HIP runtime */
+const char *artamdVersion (void);
+
+/* ---- resampler ---- */
+void resampleHipSetStream (Resample *cxt, void *hipStream);   /* default: the null stream */
+void resampleHipSynchronize (Resample *cxt);
+/* kernel selection for ablation/tests: 0 = automatic, 1 = general wave-per-output kernel,
+ * 2 = MFMA periodic-phase kernel where applicable (falls back to 1 elsewhere) */
+void resampleHipSetKernel (Resample *cxt, int which);
+int  resampleHipLastKernel (Resample *cxt);          /* which kernel produced the bulk of the last call */
+
+ResampleResult resampleProcessInterleavedDevice (Resample *cxt, const artsample_t *d_input, int numInputFrames,
+                                                 artsample_t *d_output, int numOutputFrames, double ratio);
+ResampleResult resampleProcessAndFlushInterleavedDevice (Resample *cxt, const artsample_t *d_input, int numInputFrames,
+                                                         artsample_t *d_output, int numOutputFrames, double ratio);
+/* planar device buffers: channel c at d_input + c*inputPitch (in samples), likewise output */
+ResampleResult resampleProcessPlanarDevice (Resample *cxt, const artsample_t *d_input, long inputPitch, int numInputFrames,
+                                            artsample_t *d_output, long outputPitch, int numOutputFrames, double ratio);
+
+/* ---- host-only building blocks (no GPU needed; used by the CPU test-suite) ---- */
+/* (numFilters+1) x numTaps bank exactly as resampleInit builds it (reference resampler.c:149-168, 1090-1133) */
+void artamdBuildFilterBank (int numTaps, int numFilters, double lowpassRatio, int flags, artsample_t *bank);
+
+typedef struct {
+    unsigned int first_output;      /* outputs [first_output, next.first_output) belong to this segment */
+    int lin_base;                   /* ring index + lin_base = index into (history ++ new input) */
+    double base_offset;             /* outputOffset valid for this ring epoch */
+} ArtamdSegment;
+
+typedef struct {
+    int numTaps, numFilters, flags, inputIndex, floorActive;
+    double outputOffset, fixedRatio;
+} ArtamdPosition;
+
+/* Replay one process call on explicit position state: fills the result, advances *pos and writes up
+ * to maxSegments ring-epoch segments.  Returns the number of segments the call needs (may exceed
+ * maxSegments; then only the first maxSegments were written).  *linFloor receives the linear index
+ * below which history reads as silence (INT_MIN when unrestricted). */
+int artamdPlanCall (ArtamdPosition *pos, int numInputFrames, int numOutputFrames, double ratio,
+                    ResampleResult *result, ArtamdSegment *segments, int maxSegments, int *linFloor);
+
+/* ---- biquad: device-resident bank of per-channel section chains ---- */
+typedef struct artamd_biquad_bank BiquadBank;
+/* sections[c*numSections + s] is section s of channel c (state and coefficients are copied) */
+BiquadBank *biquadBankCreate (const Biquad *sections, int numChannels, int numSections);
+void biquadBankSetStream (BiquadBank *bank, void *hipStream);
+/* in-place over interleaved device frames [numFrames][numChannels]; asynchronous */
+void biquadBankApplyInterleavedDevice (BiquadBank *bank, artsample_t *d_buffer, int numFrames);
+void biquadBankRead (BiquadBank *bank, Biquad *sections);      /* synchronises; copies state back */
+void biquadBankFree (BiquadBank *bank);
+
+/* ---- decimator, device pointers ---- */
+void decimateHipSetStream (Decimate *cxt, void *hipStream);
+/* asynchronous; clipped-sample count accumulates on the device, read with decimateHipClipped() */
+void decimateProcessInterleavedLEDevice (Decimate *cxt, const artsample_t *d_input, int numInputFrames, unsigned char *d_output);
+long decimateHipClipped (Decimate *cxt);             /* synchronises; total clipped since init */
+void floatIntegersLEDevice (const unsigned char *d_input, double inputGain, int inputBits, int inputBytes, int inputStride,
+                            artsample_t *d_output, int numSamples, void *hipStream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,45 @@
+/* biquad.h — 1st..4th-order direct-form-I IIR sections, C API.
+ *
+ * Drop-in boundary for the reference's biquad.h (reference biquad.h:27-47): BiquadCoefficients
+ * (36 bytes) and Biquad (80 bytes) are caller-allocated PODs whose layout is ABI
+ * (ART allocates them itself, art.c:726-729, 869-870).
+ *
+ * biquad_lowpass/_highpass/_init are host-side design code.  biquad_apply_buffer and
+ * biquad_apply_sample run the recurrence in a gfx950 kernel (one lane per section chain,
+ * un-fused float ops in the reference's order => bit-identical to the reference built with
+ * -ffp-contract=off).  Batched, device-resident forms are in art_hip.h.
+ */
+#ifndef ARTAMD_BIQUAD_H
+#define ARTAMD_BIQUAD_H
+
+#include <stdint.h>
+
+#ifndef ARTSAMPLE_T_DEFINED
+#define ARTSAMPLE_T_DEFINED
+typedef float artsample_t;
+#endif
+
+typedef struct {
+    artsample_t a0, a1, a2, a3, a4, b1, b2, b3, b4;
+} BiquadCoefficients;
+
+typedef struct {
+    artsample_t a[5], b[5];               /* coefficients (gain folded into a[]) */
+    artsample_t x[4], y[4];               /* circular input / output history */
+    int order, index;
+} Biquad;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+void biquad_init (Biquad *f, const BiquadCoefficients *coeffs, double gain);
+void biquad_lowpass (BiquadCoefficients *filter, double frequency);
+void biquad_highpass (BiquadCoefficients *filter, double frequency);
+void biquad_apply_buffer (Biquad *f, artsample_t *buffer, int num_samples, int stride);
+artsample_t biquad_apply_sample (Biquad *f, artsample_t input);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

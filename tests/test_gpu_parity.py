@@ -1,0 +1,298 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the golden vectors made from the real
+reference and against the oracle on the same seeded inputs.
+
+Contract (DESIGN.md "parity"):
+  * frame counts and the carried position after every call: exact, always;
+  * RESAMPLE_STRICT_ORDER: every output bit equals the reference built with -O2 -ffp-contract=off;
+  * EXTEND_CONVOLUTION_MATH: equals the reference's double-accumulate mode except where the fp64
+    summation order flips the final float rounding (<= 1 float ulp, < 0.1 % of samples);
+  * default (fast) mode: |y - y_precise| <= 2^-23 * max(1, |y|)  (one float32 ulp at full scale),
+    and RMS error no worse than the reference's own shipping build;
+  * biquad, decimator, ingest: bit-exact.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _golden as G
+import audio_resampler_amd as A
+from _artest import run_artest, PRESETS
+from _hip import HipResampler, tolerance_ok
+from _oracle import (OracleResampler, load_oracle, noise, checksum_words, checksum_bytes, f32p, u8p,
+                     BH, INTERP, LOWPASS, PRECISE, DITHER_HP, SHAPE_ATH)
+from test_oracle_golden import artest_backend, ARTEST_CASES, decimate_input
+
+pytestmark = pytest.mark.gpu
+
+STRICT = A.RESAMPLE_STRICT_ORDER
+
+
+def test_native_library_is_the_in_tree_build():
+    import os
+    assert os.path.samefile(os.path.dirname(A.api.LIB_PATH), os.path.dirname(A.__file__))
+    assert A.lib().artamdDeviceCount() >= 1
+
+
+@pytest.mark.parametrize("name", G.NAMES)
+def test_strict_mode_is_bit_exact_vs_reference(name):
+    y, trace = G.replay(G.make(HipResampler, name, STRICT), name)
+    full, head, tail, csum = G.expected(name, "strict")
+    assert np.array_equal(trace[:, :4], G.load("resample")[name + "/trace"][:, :4])
+    assert np.array_equal(y[:256].view(np.uint32), head.view(np.uint32))
+    assert np.array_equal(y[-256:].view(np.uint32), tail.view(np.uint32))
+    assert checksum_words(y) == csum
+    if full is not None:
+        assert np.array_equal(y.view(np.uint32), full.view(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["P_mono_48x48", "B_fixed_160x380", "C_small_147x156_lp", "lp_frac", "E_asrc_380_nolerp"])
+def test_strict_precise_mode_is_bit_exact_vs_reference(name):
+    y, _ = G.replay(G.make(HipResampler, name, STRICT | PRECISE), name)
+    assert checksum_words(y) == G.expected(name, "precise")[3]
+
+
+@pytest.mark.parametrize("name", G.NAMES)
+def test_fast_mode_within_one_ulp_fullscale_of_precise(name):
+    y, trace = G.replay(G.make(HipResampler, name), name)
+    truth, _ = G.replay(G.make(OracleResampler, name, PRECISE), name)
+    assert np.array_equal(trace[:, :4], G.load("resample")[name + "/trace"][:, :4])
+    assert y.shape == truth.shape
+    ok, worst, rms = tolerance_ok(y, truth)
+    assert ok, (worst, rms)
+    # no worse than the reference's own float build (same inputs, strict source order)
+    ref_float, _ = G.replay(G.make(OracleResampler, name), name)
+    _, _, rms_ref = tolerance_ok(ref_float, truth)
+    assert rms <= rms_ref * 1.25 + 1e-12, (rms, rms_ref)
+
+
+@pytest.mark.parametrize("name", G.NAMES)
+def test_precise_mode_matches_double_accumulate_reference(name):
+    y, _ = G.replay(G.make(HipResampler, name, PRECISE), name)
+    truth, _ = G.replay(G.make(OracleResampler, name, PRECISE), name)
+    diff = y.view(np.int32).astype(np.int64) - truth.view(np.int32).astype(np.int64)
+    same_sign = np.signbit(y) == np.signbit(truth)
+    assert np.all(np.abs(diff[same_sign]) <= 1)
+    assert np.all(np.abs(y[~same_sign] - truth[~same_sign]) < 1e-30)
+    assert np.mean(diff != 0) < 1e-3
+
+
+@pytest.mark.parametrize("args,preset,chans,src,dst,opt,outbits", ARTEST_CASES)
+def test_reference_artest_known_answers_in_strict_mode(args, preset, chans, src, dst, opt, outbits):
+    """The reference's whole test program, restated, driving the HIP library: same checksums as the
+    reference's own artest (strict build) — resampler, flush and (with -o) the decimator."""
+    want = G.kat()["strict"][args]
+    opt = dict(opt)
+    block = opt.pop("block", 4096)
+    seconds = opt.pop("seconds", 2)
+    ub_tail = opt.pop("ub_tail", False)
+    dec = None
+    if outbits:
+        d = A.Decimator(chans, outbits, 2, 1.0, dst, DITHER_HP | SHAPE_ATH)
+        dec = d.process
+    res = run_artest(lambda: artest_backend(HipResampler, preset, chans, src, dst, extra=STRICT, **opt), chans,
+                     PRESETS[preset][0], src, dst, seconds, block=block, ratio_arg=0.0 if opt.get("exact") else None, decimator=dec)
+    assert res["out_frames"] == want["output"]["count"]
+    if ub_tail:
+        return
+    assert res["out_checksum"] == want["output"]["checksum"]
+    if outbits:
+        assert res["dec_checksum"] == want["decimate"]["checksum"]
+        assert res["clips"] == want["decimate"]["clips"]
+
+
+def test_headline_config_fast_mode_full_artest_run_vs_oracle():
+    """8 ch, 44.1k->48k, preset -4 (988x988 interpolating), 1 s, 4096-frame blocks + flush: every sample
+    within tolerance of the double-accumulate oracle; frame count equals the reference's."""
+    mk = lambda cls, **kw: run_artest(lambda: artest_backend(cls, 4, 8, 44100, 48000, **kw), 8, 988, 44100, 48000, 1, collect=True)
+    got = mk(HipResampler)
+    truth = mk(OracleResampler, precise=True)
+    assert got["out_frames"] == truth["out_frames"]
+    ok, worst, rms = tolerance_ok(got["y"], truth["y"])
+    assert ok, (worst, rms)
+    assert rms < 2.5e-8
+
+
+def test_planar_and_device_entry_points_equal_interleaved():
+    torch = pytest.importorskip("torch")
+    ch, T = 3, 64
+    x, _ = noise(ch * 5000)
+    x = x.reshape(-1, ch)
+    ratio = 48000 / 44100
+    a, b, c, d = (HipResampler(ch, T, 32, 0.7, BH | INTERP) for _ in range(4))
+    for r in (a, b, c, d):
+        r.advance(T / 2)
+    outs = []
+    for k in range(4):
+        seg = x[k * 1200:(k + 1) * 1200]
+        ua, ga, ya = a.process(seg, 2000, ratio, and_flush=(k == 3))
+        ub, gb, yb = b.process_planar([seg[:, i] for i in range(ch)], 2000, ratio, and_flush=(k == 3))
+        assert (ua, ga) == (ub, gb)
+        assert np.array_equal(ya.view(np.uint32), np.stack(yb, axis=1).view(np.uint32))
+        din = torch.from_numpy(seg.copy()).cuda()
+        dout = torch.zeros(2000, ch, device="cuda")
+        c.set_stream(torch.cuda.current_stream().cuda_stream)
+        uc, gc = c.process_device(din, 1200, dout, 2000, ratio, and_flush=(k == 3))
+        torch.cuda.synchronize()
+        assert (uc, gc) == (ua, ga)
+        assert np.array_equal(dout[:gc].cpu().numpy().view(np.uint32), ya.view(np.uint32))
+        if k < 3:
+            dpl = torch.from_numpy(np.ascontiguousarray(seg.T)).cuda()
+            dpo = torch.zeros(ch, 2048, device="cuda")
+            ud, gd = d.process_planar_device(dpl, 1200, 1200, dpo, 2048, 2000, ratio)
+            torch.cuda.synchronize()
+            assert (ud, gd) == (ua, ga)
+            assert np.array_equal(dpo[:, :gd].cpu().numpy().T.view(np.uint32), ya.view(np.uint32))
+        outs.append(ya)
+
+
+def test_fixed_ratio_output_is_block_size_invariant():
+    """size-independent property: with a reduced fixed-ratio bank the output stream does not
+    depend on how the input is cut into calls."""
+    ch, T = 2, 380
+    x, _ = noise(ch * 40000)
+    x = x.reshape(-1, ch)
+    streams = []
+    for block in (256, 1000, 4096, 40000):
+        r = HipResampler(ch, T, 380, flags=BH | INTERP | LOWPASS, fixed=(44100.0, 48000.0, 0), extra=STRICT)
+        r.advance(T / 2)
+        ys = []
+        for p in range(0, 40000, block):
+            u, g, y = r.process(x[p:p + block], int(block * 1.1) + T, 0.0)
+            assert u == min(block, 40000 - p)
+            ys.append(y)
+        streams.append(np.concatenate(ys))
+    n = min(len(s) for s in streams)
+    for s in streams[1:]:
+        assert np.array_equal(s[:n].view(np.uint32), streams[0][:n].view(np.uint32))
+
+
+def test_reset_and_getters():
+    L = A.lib()
+    r = HipResampler(2, 156, 320, flags=BH | INTERP | LOWPASS, fixed=(96000.0, 44100.0, 0))
+    o = OracleResampler(2, 156, 320, flags=BH | INTERP | LOWPASS, fixed=(96000.0, 44100.0, 0))
+    assert L.resampleGetNumFilters(r.p) == o.c.filters == 147
+    assert L.resampleInterpolationUsed(r.p) == 0
+    assert L.resampleGetLowpassRatio(r.p) == o.c.lowpass_ratio
+    x, _ = noise(2 * 3000)
+    x = x.reshape(-1, 2)
+    Lo = load_oracle()
+    for _ in range(2):
+        r.advance(78.0)
+        o.advance(78.0)
+        for n in (10, 333):
+            assert L.resampleGetRequiredSamples(r.p, n, 0.0) == Lo.ora_resample_required_input(o.p, n, 0.0)
+            assert L.resampleGetExpectedOutput(r.p, n, 0.0) == Lo.ora_resample_expected_output(o.p, n, 0.0)
+        u, g, y = r.process(x, 3000, 0.0)
+        uo, go, yo = o.process(x, 3000, 0.0)
+        assert (u, g) == (uo, go) and r.position() == o.position()
+        assert tolerance_ok(y, yo)[0]
+        r.reset()
+        o.reset()
+        assert r.state()[:2] == o.state()[:2]
+
+
+# ------------------------------------------------------------------------------------------------
+# biquad / decimator / ingest: bit-exact
+# ------------------------------------------------------------------------------------------------
+
+def test_biquad_host_api_and_device_bank_bit_exact():
+    torch = pytest.importorskip("torch")
+    L = A.lib()
+    z = G.load("biquad")
+    for key in [k for k in z.files if k.startswith("design/")]:
+        row = z[key]
+        c = A.BiquadCoefficients()
+        (L.biquad_lowpass if "/lp" in key else L.biquad_highpass)(C.byref(c), float(row[0]))
+        got = np.array([getattr(c, n) for n, _ in A.BiquadCoefficients._fields_], np.float32)
+        assert np.array_equal(got.view(np.uint32), row[1:].astype(np.float32).view(np.uint32)), key
+    ch, frames = 8, 3000
+    x, _ = noise(frames * ch)
+    c = A.BiquadCoefficients()
+    L.biquad_lowpass(C.byref(c), 44100 * 0.45 / 96000)
+    # (a) the reference's calling pattern: one strided call per channel per section (art.c:1011-1017)
+    buf = x.reshape(frames, ch).copy()
+    filt = [[A.Biquad(), A.Biquad()] for _ in range(ch)]
+    for pair in filt:
+        for b in pair:
+            L.biquad_init(C.byref(b), C.byref(c), 1.0)
+    for blk in range(3):
+        view = buf[blk * 1000:(blk + 1) * 1000]
+        for k in range(ch):
+            for b in filt[k]:
+                L.biquad_apply_buffer(C.byref(b), C.cast(view.ctypes.data + 4 * k, f32p), 1000, ch)
+    assert np.array_equal(buf.view(np.uint32), z["cascade/y"].view(np.uint32))
+    # (b) device-resident bank: all channels x both sections in one launch per block
+    secs = (A.Biquad * (ch * 2))()
+    for i in range(ch * 2):
+        L.biquad_init(C.byref(secs[i]), C.byref(c), 1.0)
+    bank = A.BiquadBank(secs, ch, 2)
+    d = torch.from_numpy(x.reshape(frames, ch).copy()).cuda()
+    for blk in range(3):
+        bank.apply_device(d[blk * 1000:(blk + 1) * 1000], 1000)
+    torch.cuda.synchronize()
+    assert np.array_equal(d.cpu().numpy().view(np.uint32), z["cascade/y"].view(np.uint32))
+    state = bank.read()
+    for k in range(ch):
+        for s in range(2):
+            assert bytes(state[k * 2 + s]) == bytes(filt[k][s])
+    # (c) orders 1..4, buffer and per-sample association
+    for order in (1, 2, 3, 4):
+        co = A.BiquadCoefficients(*[float(v) for v in z[f"order{order}/coeffs"]])
+        x1, _ = noise(600)
+        bb, bs = A.Biquad(), A.Biquad()
+        L.biquad_init(C.byref(bb), C.byref(co), 0.8)
+        L.biquad_init(C.byref(bs), C.byref(co), 0.8)
+        assert bb.order == order
+        yb = x1.copy()
+        L.biquad_apply_buffer(C.byref(bb), yb.ctypes.data_as(f32p), 600, 1)
+        assert np.array_equal(yb.view(np.uint32), z[f"order{order}/buffer"].view(np.uint32))
+        ys = np.array([L.biquad_apply_sample(C.byref(bs), float(v)) for v in x1[:64]], np.float32)
+        assert np.array_equal(ys.view(np.uint32), z[f"order{order}/sample"][:64].view(np.uint32))
+
+
+def test_decimator_all_combos_bit_exact():
+    z = G.load("decimate")
+    ch, frames, x = decimate_input()
+    x2 = x.reshape(frames, ch)
+    for (bits, nbytes, dither, shape, rate, want_sum, want_clips) in z["table"]:
+        bits, nbytes, dither, shape, rate = int(bits), int(nbytes), int(dither), int(shape), int(rate)
+        d = A.Decimator(ch, bits, nbytes, 1.0, rate, dither | shape)
+        parts, clips = [], 0
+        for blk in range(3):
+            b, c = d.process(x2[blk * 2000:(blk + 1) * 2000])
+            parts.append(b)
+            clips += c
+        buf = np.concatenate(parts)
+        assert checksum_bytes(buf) == int(want_sum), (bits, nbytes, dither, shape, rate)
+        assert clips == int(want_clips)
+        key = f"bytes/{bits}_{nbytes}_{dither}_{shape}_{rate}"
+        if key in z.files:
+            assert np.array_equal(buf, z[key])
+        d.close()
+
+
+def test_decimator_planar_device_and_ingest():
+    torch = pytest.importorskip("torch")
+    L = A.lib()
+    z = G.load("decimate")
+    ch, frames, x = decimate_input()
+    x2 = x.reshape(frames, ch)
+    d = A.Decimator(ch, 16, 2, 1.0, 48000, DITHER_HP | SHAPE_ATH)
+    outs, clips = d.process_planar([np.ascontiguousarray(x2[:, k]) for k in range(ch)])
+    assert clips == int(z["planar/clips"])
+    assert np.array_equal(np.stack(outs), z["planar/bytes"])
+    # device-pointer form == host form
+    d1 = A.Decimator(ch, 16, 2, 1.0, 48000, DITHER_HP | SHAPE_ATH)
+    d2 = A.Decimator(ch, 16, 2, 1.0, 48000, DITHER_HP | SHAPE_ATH)
+    want, wc = d1.process(x2)
+    din = torch.from_numpy(x2.copy()).cuda()
+    dout = torch.zeros(frames * ch * 2, dtype=torch.uint8, device="cuda")
+    d2.process_device(din, frames, dout)
+    assert d2.clipped() == wc
+    assert np.array_equal(dout.cpu().numpy(), want)
+    raw = z["ingest/raw"].copy()
+    for bits, nbytes in ((8, 1), (16, 2), (24, 3), (24, 4), (12, 2), (20, 3)):
+        o = np.zeros(50, np.float32)
+        L.floatIntegersLE(raw.ctypes.data_as(u8p), 0.75, bits, nbytes, 2, o.ctypes.data_as(f32p), 50)
+        assert np.array_equal(o.view(np.uint32), z[f"ingest/{bits}_{nbytes}"].view(np.uint32))

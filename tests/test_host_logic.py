@@ -1,0 +1,133 @@
+"""CPU (no GPU): the product library's host logic — it loads, exports every symbol the public headers
+declare, fails loudly without a device, designs the same filter bank as the reference, and its
+closed-form position planner reproduces the reference's scalar state machine exactly."""
+import ctypes as C
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+import _golden as G
+import audio_resampler_amd as A
+from audio_resampler_amd.api import ArtamdPosition, ArtamdSegment, ResampleResult, f32p
+from _oracle import OracleResampler, BH, INTERP, LOWPASS, FIXED, FLUSHED, SNAP
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = A.lib()
+    declared = set()
+    for h in ("resampler.h", "biquad.h", "decimator.h", "art_hip.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared |= set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;", text))
+    declared -= {"defined"}
+    assert declared, "no prototypes parsed"
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/ but not exported"
+    assert declared == set(A.EXPORTED_SYMBOLS), declared ^ set(A.EXPORTED_SYMBOLS)
+
+
+def test_struct_layouts_are_abi():
+    assert C.sizeof(A.Biquad) == 80 and C.sizeof(A.BiquadCoefficients) == 36      # reference biquad.h:27-35
+    assert C.sizeof(A.ResampleResult) == 8
+    assert A.Resample.numChannels.offset == 0 and A.Resample.outputOffset.offset == 32 and A.Resample.filters.offset == 72
+    assert A.Decimate.numChannels.offset == 0 and A.Decimate.outputBytes.offset == 8 and A.Decimate.outputGain.offset == 24
+
+
+@pytest.mark.skipif(A.lib().artamdDeviceCount() > 0, reason="a GPU is present")
+def test_no_gpu_means_loud_failure_not_fallback(capfd):
+    L = A.lib()
+    assert not L.resampleInit(2, 48, 48, 0.0, 3)
+    assert not L.decimateInit(2, 16, 2, 1.0, 48000, 0)
+    err = capfd.readouterr().err
+    assert "no CPU path" in err
+
+
+@pytest.mark.parametrize("name", G.NAMES)
+def test_filter_bank_matches_reference(name):
+    z = G.load("bank")
+    rz = G.load("resample")
+    F, T, flags = [int(v) for v in rz[name + "/meta"]]
+    lowpass = float(rz[name + "/meta_f"][0])
+    bank = np.zeros((F + 1, T), np.float32)
+    A.lib().artamdBuildFilterBank(T, F, lowpass, flags, bank.ctypes.data_as(f32p))
+    assert hashlib.sha256(bank.tobytes()).digest() == bytes(z[name + "/sha256"])
+    assert np.array_equal(bank[z[name + "/rows"]].view(np.uint32), z[name + "/data"].view(np.uint32))
+
+
+def plan(pos, n_in, cap, ratio, max_segs=4096):
+    res = ResampleResult()
+    segs = (ArtamdSegment * max_segs)()
+    floor = C.c_int()
+    n = A.lib().artamdPlanCall(C.byref(pos), n_in, cap, ratio, C.byref(res), segs, max_segs, C.byref(floor))
+    return res.input_used, res.output_generated, [(s.first_output, s.lin_base, s.base_offset) for s in segs[:n]], floor.value
+
+
+@pytest.mark.parametrize("name", G.NAMES)
+def test_planner_reproduces_golden_traces(name):
+    rz = G.load("resample")
+    F, T, flags = [int(v) for v in rz[name + "/meta"]]
+    pos = ArtamdPosition(T, F, flags & ~0x80, T, 0, float(T // 2), float(rz[name + "/meta_f"][1]))
+    adv = G.CTOR[name]["adv"]
+    if adv is not None:
+        pos.outputOffset += adv
+    for (n, cap, ratio, flush), want in zip(G.script_of(name), rz[name + "/trace"]):
+        used, made, segs, _ = plan(pos, -1 if flush else n, cap, ratio)
+        got = (used, made, np.float64(pos.outputOffset).view(np.uint64).item(), pos.inputIndex)
+        assert got == tuple(int(v) for v in want[:4])
+        assert segs[0][0] == 0 and all(a[0] <= b[0] for a, b in zip(segs, segs[1:]))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_planner_equals_oracle_loop_randomised(seed):
+    """closed-form planner vs the oracle's literal consume/emit loop (which is pinned to the reference)"""
+    rng = np.random.default_rng(1000 + seed)
+    T = int(rng.choice([4, 8, 16, 48, 156, 380, 988]))
+    F = int(rng.choice([1, 3, 48, 147, 160, 988]))
+    ratio = float(rng.choice([48000 / 44100, 44100 / 96000, 0.5, 2.0, 1.0, 1 / 3.0, 3.7, 0.01, 97.3, 1.0000001]))
+    interp = bool(rng.integers(0, 2))
+    fixed = bool(rng.integers(0, 2))
+    if fixed:
+        o = OracleResampler(1, T, max(F, 2), flags=BH | (INTERP if interp else 0) | LOWPASS, fixed=(44100.0, 48000.0, 0))
+    else:
+        o = OracleResampler(1, T, F, 0.0, BH | (INTERP if interp else 0))
+    c = o.c
+    adv = float(rng.choice([0.0, T / 2, T / 2 + (0.37 if c.flags & INTERP else 0.0), 5 * T]))
+    o.advance(adv)
+    pos = ArtamdPosition(T, c.filters, c.flags, c.write_pos, 0, c.read_pos, c.fixed_ratio)
+    x = np.zeros((1, 1), np.float32)
+    for call in range(30):
+        kind = int(rng.integers(0, 12))
+        n = int(rng.integers(0, 40 * T)) if kind < 9 else int(rng.integers(0, 4))
+        cap = int(rng.integers(0, 50 * T)) if kind != 4 else int(rng.integers(0, 5))
+        r = ratio * (1 + rng.uniform(-3e-4, 3e-4)) if kind == 6 else ratio
+        flush = kind == 11 and call > 20
+        if flush and o.c.write_pos > 15 * T + T // 2:
+            continue                          # the reference's own flush is out of bounds there
+        xin = np.zeros((max(n, 1), 1), np.float32)
+        if flush:
+            u, g, _ = o.process(None, cap, r, flush=True)
+            used, made, segs, floor = plan(pos, -1, cap, r)
+        else:
+            u, g, _ = o.process(xin[:n], cap, r)
+            used, made, segs, floor = plan(pos, n, cap, r)
+        assert (used, made) == (u, g), (call, n, cap, r)
+        st = o.state()
+        assert np.float64(pos.outputOffset).view(np.uint64).item() == st[0] and pos.inputIndex == st[1]
+        assert (pos.flags & (FLUSHED | SNAP | FIXED)) == (st[2] & (FLUSHED | SNAP | FIXED))
+
+
+def test_planner_segments_cover_ring_rewinds():
+    T = 48
+    pos = ArtamdPosition(T, 48, 3, T, 0, float(T), 0.0)
+    used, made, segs, floor = plan(pos, 100 * T, 200 * T, 48000 / 44100)
+    assert used == 100 * T and len(segs) == 1 + (100 * T + T - 1 - 16 * T) // (15 * T) + 1 or len(segs) >= 6
+    H = T + T // 2
+    assert segs[0][1] == H - T
+    for a, b in zip(segs, segs[1:]):
+        assert b[1] - a[1] == 15 * T and a[2] - b[2] == 15 * T
+    assert floor == -2 ** 31
