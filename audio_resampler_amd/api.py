@@ -101,6 +101,8 @@ EXPORTED_SYMBOLS = {
     "resampleHipSynchronize": (None, [RP]),
     "resampleHipSetKernel": (None, [RP, C.c_int]),
     "resampleHipLastKernel": (C.c_int, [RP]),
+    "resampleHipSetTiming": (None, [RP, C.c_int]),
+    "resampleHipReadTiming": (C.c_double, [RP, C.POINTER(C.c_int)]),
     "resampleProcessInterleavedDevice": (ResampleResult, [RP, ptr, C.c_int, ptr, C.c_int, C.c_double]),
     "resampleProcessAndFlushInterleavedDevice": (ResampleResult, [RP, ptr, C.c_int, ptr, C.c_int, C.c_double]),
     "resampleProcessPlanarDevice": (ResampleResult, [RP, ptr, C.c_long, C.c_int, ptr, C.c_long, C.c_int, C.c_double]),
@@ -203,6 +205,15 @@ class Resampler:
 
     def synchronize(self):
         self.L.resampleHipSynchronize(self.p)
+
+    def set_timing(self, on=True):
+        self.L.resampleHipSetTiming(self.p, int(on))
+
+    def read_timing(self):
+        """(total FIR-kernel milliseconds, launches) since timing was enabled / last read"""
+        n = C.c_int()
+        ms = self.L.resampleHipReadTiming(self.p, C.byref(n))
+        return ms, n.value
 
     # -- host-pointer API (numpy) --
     def process(self, x, out_cap, ratio, flush=False, and_flush=False, threads=1):

@@ -56,6 +56,10 @@ int   arthip_d2d (void *dst, const void *src, size_t bytes, void *stream);
 int   arthip_zero (void *dst, size_t bytes, void *stream);
 int   arthip_sync (void *stream);
 const char *arthip_last_error (void);
+void *arthip_event_create (void);
+void  arthip_event_destroy (void *ev);
+int   arthip_event_record (void *ev, void *stream);
+float arthip_event_elapsed_ms (void *start, void *stop);   /* synchronises on `stop` */
 
 /* ---- sinc_fir.hip ---- */
 /* returns the kernel actually used (ART_KERNEL_*), <0 on launch failure */

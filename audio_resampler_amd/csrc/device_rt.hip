@@ -45,4 +45,15 @@ int arthip_d2d (void *d, const void *s, size_t n, void *st) { return n ? fail (h
 int arthip_zero (void *d, size_t n, void *st) { return n ? fail (hipMemsetAsync (d, 0, n, (hipStream_t) st), "memset") : 0; }
 int arthip_sync (void *st) { return fail (hipStreamSynchronize ((hipStream_t) st), "sync"); }
 
+void *arthip_event_create (void) { hipEvent_t e = nullptr; return fail (hipEventCreate (&e), "hipEventCreate") ? nullptr : (void *) e; }
+void arthip_event_destroy (void *e) { if (e) (void) hipEventDestroy ((hipEvent_t) e); }
+int arthip_event_record (void *e, void *st) { return fail (hipEventRecord ((hipEvent_t) e, (hipStream_t) st), "hipEventRecord"); }
+float arthip_event_elapsed_ms (void *a, void *b)
+{
+    float ms = 0.0f;
+    if (fail (hipEventSynchronize ((hipEvent_t) b), "hipEventSynchronize")) return -1.0f;
+    if (fail (hipEventElapsedTime (&ms, (hipEvent_t) a, (hipEvent_t) b), "hipEventElapsedTime")) return -1.0f;
+    return ms;
+}
+
 }

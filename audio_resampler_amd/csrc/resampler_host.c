@@ -36,6 +36,8 @@ struct artamd_resampler {
     int kernel_pref, last_kernel;
     /* cached rational structure of the current ratio */
     double period_ratio; int period_out, period_in;
+    /* optional HIP-event timing of FIR launches */
+    int timing; void **ev; int ev_count, ev_cap;
 };
 
 /* ------------------------------------------------------------------------------------------
@@ -341,6 +343,8 @@ void resampleFree (Resample *cxt)
         arthip_sync (hip->stream);
         arthip_free (hip->d_bank); arthip_free (hip->d_hist [0]); arthip_free (hip->d_hist [1]);
         arthip_free (hip->d_in); arthip_free (hip->d_out); arthip_free (hip->d_tmp);
+        for (int i = 0; i < hip->ev_cap; ++i) arthip_event_destroy (hip->ev [i]);
+        free (hip->ev);
         free (hip->segs);
         free (hip);
     }
@@ -438,6 +442,36 @@ unsigned int resampleGetExpectedOutput (Resample *cxt, int numInputFrames, doubl
 void resampleHipSetStream (Resample *cxt, void *stream) { cxt->hip->stream = stream; }
 void resampleHipSynchronize (Resample *cxt) { arthip_sync (cxt->hip->stream); }
 void resampleHipSetKernel (Resample *cxt, int which) { cxt->hip->kernel_pref = which; }
+
+void resampleHipSetTiming (Resample *cxt, int enable)
+{
+    struct artamd_resampler *hip = cxt->hip;
+    hip->timing = enable;
+    hip->ev_count = 0;
+}
+
+double resampleHipReadTiming (Resample *cxt, int *numLaunches)
+{
+    struct artamd_resampler *hip = cxt->hip;
+    double total = 0.0;
+    arthip_sync (hip->stream);
+    for (int i = 0; i + 1 < hip->ev_count; i += 2)
+        total += arthip_event_elapsed_ms (hip->ev [i], hip->ev [i + 1]);
+    if (numLaunches) *numLaunches = hip->ev_count / 2;
+    hip->ev_count = 0;
+    return total;
+}
+
+static void *timing_event (struct artamd_resampler *hip)
+{
+    if (hip->ev_count == hip->ev_cap) {
+        int cap = hip->ev_cap ? hip->ev_cap * 2 : 64;
+        hip->ev = realloc (hip->ev, sizeof (void *) * cap);
+        for (int i = hip->ev_cap; i < cap; ++i) hip->ev [i] = arthip_event_create ();
+        hip->ev_cap = cap;
+    }
+    return hip->ev [hip->ev_count++];
+}
 int  resampleHipLastKernel (Resample *cxt) { return cxt->hip->last_kernel; }
 
 /* Plan one call, enqueue the FIR launches and the history roll.  `d_in` holds the call's input on
@@ -500,7 +534,9 @@ static ResampleResult enqueue_call (Resample *cxt, const float *d_in, long in_pi
             a.n_begin = hip->segs [s0].first_output;
             a.n_end = s1 < nseg ? hip->segs [s1].first_output : res.output_generated;
             if (a.n_end > a.n_begin) {
+                if (hip->timing) arthip_event_record (timing_event (hip), hip->stream);
                 int k = arthip_fir (&a, &tab, hip->kernel_pref, hip->stream);
+                if (hip->timing) arthip_event_record (timing_event (hip), hip->stream);
                 if (k < 0) { fprintf (stderr, "artamd: FIR launch failed: %s\n", arthip_last_error ()); res.input_used = res.output_generated = 0; return res; }
                 hip->last_kernel = k;
             }

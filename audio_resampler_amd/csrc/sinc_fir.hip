@@ -126,19 +126,26 @@ void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile)
 #pragma unroll
             for (int c = 0; c < CG; ++c) { acc0 [c] = 0; acc1 [c] = 0; }
 
-            for (int k = lane; k < a.T; k += 64) {
-                const float c0 = h0 [k];
-                const float c1 = INTERP ? h1 [k] : 0.0f;
+            // Taps are visited in mirrored pairs from the window edges towards the centre (as the
+            // reference does): partial sums stay small until the dominant central taps arrive, which
+            // keeps the float accumulation error at or below the reference's.
+            for (int p = lane; p < half; p += 64) {
 #pragma unroll
-                for (int c = 0; c < CG; ++c) {
-                    const float v = x [(size_t) k * CG + c];
-                    if (PRECISE) {
-                        acc0 [c] = acc0 [c] + (Acc) c0 * (Acc) v;
-                        if (INTERP) acc1 [c] = acc1 [c] + (Acc) c1 * (Acc) v;
-                    }
-                    else {
-                        acc0 [c] = __builtin_fmaf (c0, v, acc0 [c]);
-                        if (INTERP) acc1 [c] = __builtin_fmaf (c1, v, acc1 [c]);
+                for (int side = 0; side < 2; ++side) {
+                    const int k = side ? a.T - 1 - p : p;
+                    const float c0 = h0 [k];
+                    const float c1 = INTERP ? h1 [k] : 0.0f;
+#pragma unroll
+                    for (int c = 0; c < CG; ++c) {
+                        const float v = x [(size_t) k * CG + c];
+                        if (PRECISE) {
+                            acc0 [c] = acc0 [c] + (Acc) c0 * (Acc) v;
+                            if (INTERP) acc1 [c] = acc1 [c] + (Acc) c1 * (Acc) v;
+                        }
+                        else {
+                            acc0 [c] = __builtin_fmaf (c0, v, acc0 [c]);
+                            if (INTERP) acc1 [c] = __builtin_fmaf (c1, v, acc1 [c]);
+                        }
                     }
                 }
             }

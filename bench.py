@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X sinc resampler.
+
+Metric (BASELINE.json): output Msamples/s, 44.1 kHz -> 48 kHz, preset -4 (988 filters x 988 taps,
+Blackman-Harris, interpolating = what `artest -4 -c8 -s44100 -d48000` runs), 8 channels, float32.
+
+A "step" is ONE streaming call of the drop-in entry point on device-resident buffers:
+    resampleProcessInterleavedDevice(cxt, d_in[block x C], block, d_out, cap, ratio)
+i.e. the whole hot path (host position planning, FIR kernel, history roll) for one block of
+`--block-frames` input frames x C channels, with the input already in HBM when timing starts.
+
+Multi-GPU (`--gpus N`, launched by torch.distributed.run): channels shard across ranks — every rank
+owns an independent 8-channel slice of an 8N-channel stream (its own context, filter-bank replica and
+history in its own HBM).  No data-path collective exists or is needed; RCCL is used
+only for the timing barrier and the max-over-ranks reduction.  Weak scaling: per-GPU work is fixed.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TAPS = FILTERS = 988                      # preset -4 (reference art.c:163-166 / artest.c:166-169)
+SRC, DST = 44100, 48000
+FLOP_PER_SAMPLE = 4 * TAPS + 3            # two T-tap dot products + lerp           
+BYTES_PER_SAMPLE = 4.0 * SRC / DST + 4.0  # float32 in (1/R frames per out frame) + float32 out
+PEAK_FP32_TFLOPS = 157.3                  # MI355X f32 FMA / f32-MFMA dense peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(channels, seconds_budget=12.0):
+    """Reference CPU path on this host's cores, bounded sample of the same workload.
+    kind "reference": oracle/_ref/libartref_make.so — the real reference (its own Makefile flags) with
+    RESAMPLE_MULTITHREADED (workers.c, one thread per channel) and 65,536-frame blocks, its best setting.
+    kind "port": the oracle restatement built with the same flags, one pthread per channel."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    from audio_resampler_amd.synth import noise
+    block = 65536
+    ratio = DST / SRC
+    cap = int(math.floor((block + TAPS // 2) * ratio + 10))
+    x, _ = noise(block * channels)
+    x = np.ascontiguousarray(x.reshape(block, channels))
+    out = np.zeros((cap, channels), np.float32)
+    cores = os.cpu_count() or 1
+    threads = min(channels, cores)
+    if O.have_ref("make"):
+        L = O.load_ref("make")
+        p = L.resampleInit(channels, TAPS, FILTERS, 0.0, O.BH | O.INTERP | O.MT)
+        L.resampleAdvancePosition(p, TAPS / 2.0)
+        call = lambda: L.resampleProcessInterleaved(p, x.ctypes.data_as(O.f32p), block, out.ctypes.data_as(O.f32p), cap, ratio).generated
+        kind, free = "reference", lambda: L.resampleFree(p)
+    else:
+        L = O.load_oracle("fast")
+        p = L.ora_resample_init(channels, TAPS, FILTERS, 0.0, O.BH | O.INTERP)
+        L.ora_resample_advance(p, TAPS / 2.0)
+        call = lambda: L.ora_resample_interleaved(p, x.ctypes.data_as(O.f32p), block, out.ctypes.data_as(O.f32p), cap, ratio, threads).generated
+        kind, free = "port", lambda: L.ora_resample_free(p)
+    call()                                   # warm-up (thread pool, caches)
+    t0 = time.perf_counter()
+    frames = blocks = 0
+    while blocks < 3 or time.perf_counter() - t0 < seconds_budget:
+        frames += call()
+        blocks += 1
+        if blocks >= 200:
+            break
+    dt = time.perf_counter() - t0
+    free()
+    return {"value": round(frames * channels / dt / 1e6, 3), "unit": "Msamples/s", "cores": threads, "host_cores": cores,
+            "kind": kind, "sample": f"{blocks} blocks x {block} frames x {channels} ch ({blocks * block / SRC:.1f} s of audio), "
+                                    f"{dt:.1f} s wall; 988x988 interpolating, one thread per channel"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--channels", type=int, default=8, help="channels per GPU")
+    ap.add_argument("--block-frames", type=int, default=1 << 20, help="input frames per call")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 general, 2 MFMA")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import audio_resampler_amd as A
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    Cn, block = args.channels, args.block_frames
+    ratio = DST / SRC
+    cap = int(math.floor((block + TAPS // 2) * ratio + 10))
+
+    # this rank's channel slice of the stream: artest's noise generator, rank-decorrelated by skipping ahead
+    from audio_resampler_amd.synth import noise, SEED
+    x, _ = noise(block * Cn, state=(SEED + 2 * rank) | 1)
+    d_in = torch.from_numpy(x.reshape(block, Cn)).cuda()
+    d_out = torch.empty(cap, Cn, device="cuda", dtype=torch.float32)
+
+    rs = A.Resampler(Cn, TAPS, FILTERS, 0.0, A.BLACKMAN_HARRIS | A.SUBSAMPLE_INTERPOLATE)
+    rs.advance(TAPS / 2.0)
+    rs.set_stream(torch.cuda.current_stream().cuda_stream)
+    if args.kernel:
+        rs.set_kernel(args.kernel)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        used, made = rs.process_device(d_in, block, d_out, cap, ratio)
+        assert used == block and made < cap
+    barrier()
+    rs.set_timing(True)
+    out_frames = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        used, made = rs.process_device(d_in, block, d_out, cap, ratio)
+        out_frames += made
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms, launches = rs.read_timing()
+    kernel_used = rs.last_kernel()
+
+    stats = torch.tensor([dt, float(out_frames * Cn), kernel_ms, float(launches)], device="cuda", dtype=torch.float64)
+    if dist is not None:
+        tmax = stats.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = stats.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_max, samples_total = tmax[0].item(), tsum[1].item()
+    else:
+        dt_max, samples_total = dt, float(out_frames * Cn)
+
+    if rank == 0:
+        # roofline of the dominant kernel (the FIR), from HIP events recorded around its launches on its stream
+        per_launch_samples = out_frames * Cn / max(launches, 1)
+        avg_ms = kernel_ms / max(launches, 1)
+        tflops = per_launch_samples * FLOP_PER_SAMPLE / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        gbs = per_launch_samples * BYTES_PER_SAMPLE / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        line = {
+            "metric": "Msamples/s (out) 44.1k->48k preset -4, 8ch float32",
+            "value": round(samples_total / dt_max / 1e6, 2),
+            "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt_max / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{Cn * world}-channel stream ({Cn} ch/GPU), 44100->48000 Hz, preset -4 = 988 filters x 988 taps "
+                                   f"Blackman-Harris interpolating (artest -4 -c8), float32 interleaved, {block} input frames per call, "
+                                   f"device-resident in/out, resampleProcessInterleavedDevice",
+                       "channels_per_gpu": Cn, "block_frames": block, "taps": TAPS, "filters": FILTERS,
+                       "fir_kernel": {1: "general", 2: "mfma"}.get(kernel_used, str(kernel_used)),
+                       "parallelism": f"channel-shard x{world}, no data-path collective"},
+            "roofline": {"bound": "mfma", "achieved": round(tflops, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tflops / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                         "kernel": "fir", "avg_kernel_ms": round(avg_ms, 4), "launches": launches,
+                         "flop_per_sample": FLOP_PER_SAMPLE, "bytes_per_sample": round(BYTES_PER_SAMPLE, 3),
+                         "hbm_algorithmic_GBps": round(gbs, 2), "hbm_frac": round(gbs / PEAK_HBM_GBS, 5)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(Cn)
+        print(json.dumps(line), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
