@@ -126,6 +126,14 @@ _lib = None
 def load_library(path=LIB_PATH):
     global _lib
     if _lib is None:
+        # torch bundles its own HIP runtime; whichever libamdhip64 is loaded first owns the process.
+        # Import torch first so that device memory, streams and RCCL handed in from torch and the
+        # kernels launched by libartamd.so live in ONE runtime (set ARTAMD_NO_TORCH=1 for torch-free use).
+        if not os.environ.get("ARTAMD_NO_TORCH"):
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing — build it with `python -m audio_resampler_amd.build` "
                                "(there is no CPU fallback)")

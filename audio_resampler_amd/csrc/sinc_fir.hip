@@ -59,18 +59,31 @@ __device__ __forceinline__ Pos locate (const ArtFirArgs &a, const ArtSegTable &s
     return p;
 }
 
-template <typename A> __device__ __forceinline__ A wave_sum (A v);
-template <> __device__ __forceinline__ float wave_sum<float> (float v)
+// Cross-lane reduction of NV per-lane partial sums, carried out in fp64 so that the handful of
+// large-magnitude additions near the root of the tree do not each cost half a float ulp.
+// Halving butterfly: at every level half of the values change hands, so NV values cost
+// NV-1 (+ 6 - log2 NV) shuffle-adds instead of 6*NV.  On return lane L holds the complete sum of
+// value (L >> (6 - log2 NV)) in v[0].
+template <int NV>
+__device__ __forceinline__ void wave_reduce (double (&v) [NV], int lane)
 {
+    int n = NV;
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor (v, m);
-    return v;
-}
-template <> __device__ __forceinline__ double wave_sum<double> (double v)
-{
+    for (int m = 32; m >= 1; m >>= 1) {
+        if (n > 1) {
+            const bool upper = (lane & m) != 0;
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor (v, m);
-    return v;
+            for (int j = 0; j < NV / 2; ++j)
+                if (j < n / 2) {
+                    const double keep = upper ? v [j + n / 2] : v [j];
+                    const double send = upper ? v [j] : v [j + n / 2];
+                    v [j] = keep + __shfl_xor (send, m);
+                }
+            n >>= 1;
+        }
+        else
+            v [0] = v [0] + __shfl_xor (v [0], m);
+    }
 }
 
 constexpr int GEN_THREADS = 256;
@@ -150,20 +163,38 @@ void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile)
                 }
             }
 
-            const double frac = s_frac [i];
+            // interleave rows per channel: value index 2c (+1) = row fi (fi+1) of channel c
+            constexpr int NV = INTERP ? 2 * CG : CG;
+            double part [NV];
 #pragma unroll
             for (int c = 0; c < CG; ++c) {
-                // apply_filter returns the (float or double) sum as a double; the lerp is fp64, un-fused
-                double s0 = (double) wave_sum<Acc> (acc0 [c]);
-                if (INTERP) {
-                    double s1 = (double) wave_sum<Acc> (acc1 [c]);
-                    double left = s0 * (1.0 - frac);
-                    double right = s1 * frac;
-                    result [c] = (float)(left + right);
-                }
-                else
-                    result [c] = (float) s0;
+                if (INTERP) { part [2 * c] = (double) acc0 [c]; part [2 * c + 1] = (double) acc1 [c]; }
+                else part [c] = (double) acc0 [c];
             }
+            wave_reduce<NV> (part, lane);
+
+            constexpr int GROUP = 64 / NV;                       // lanes holding the same reduced value
+            const double mine = part [0];
+            const double frac = s_frac [i];
+            float y;
+            if (INTERP) {
+                // the lane group of row fi fetches row fi+1 from the neighbouring group; fp64 lerp, un-fused
+                const double s1 = __shfl_xor (mine, GROUP);
+                const double left = mine * (1.0 - frac);
+                const double right = s1 * frac;
+                y = (float)(left + right);
+            }
+            else
+                y = (float) mine;
+
+            const int owner = INTERP ? (lane / GROUP) >> 1 : lane / GROUP;
+            const bool writer = (lane % GROUP) == 0 && (!INTERP || ((lane / GROUP) & 1) == 0);
+            if (writer && ch0 + owner < a.C) {
+                const size_t n = n0 + i;
+                if (a.out_pitch) a.out [(size_t)(ch0 + owner) * a.out_pitch + n] = y;
+                else a.out [n * a.C + ch0 + owner] = y;
+            }
+            continue;
         }
 
 #pragma unroll
