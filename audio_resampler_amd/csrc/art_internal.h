@@ -44,6 +44,9 @@ typedef struct {
     /* periodic-phase structure for the MFMA kernel (0 = none): out frame n+period_out sits exactly
      * period_in input frames after out frame n */
     int period_out, period_in;
+    /* scratch for outputs the MFMA kernel hands back to the general kernel (device memory) */
+    unsigned int *fix_list, *fix_count;
+    unsigned int fix_cap;
 } ArtFirArgs;
 
 /* ---- device_rt.hip ---- */

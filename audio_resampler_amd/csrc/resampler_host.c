@@ -38,6 +38,7 @@ struct artamd_resampler {
     double period_ratio; int period_out, period_in;
     /* optional HIP-event timing of FIR launches */
     int timing; void **ev; int ev_count, ev_cap;
+    unsigned int *d_fix; size_t fix_cap;    /* [0] = counter, [1..] = output indices handed back by the MFMA kernel */
 };
 
 /* ------------------------------------------------------------------------------------------
@@ -342,7 +343,7 @@ void resampleFree (Resample *cxt)
     if (hip) {
         arthip_sync (hip->stream);
         arthip_free (hip->d_bank); arthip_free (hip->d_hist [0]); arthip_free (hip->d_hist [1]);
-        arthip_free (hip->d_in); arthip_free (hip->d_out); arthip_free (hip->d_tmp);
+        arthip_free (hip->d_in); arthip_free (hip->d_out); arthip_free (hip->d_tmp); arthip_free (hip->d_fix);
         for (int i = 0; i < hip->ev_cap; ++i) arthip_event_destroy (hip->ev [i]);
         free (hip->ev);
         free (hip->segs);
@@ -520,6 +521,10 @@ static ResampleResult enqueue_call (Resample *cxt, const float *d_in, long in_pi
         if ((cxt->flags & RESAMPLE_STRICT_ORDER) && (cxt->flags & EXTEND_CONVOLUTION_MATH)) a.mode |= 4;
         a.ratio = eff_ratio;
         a.period_out = hip->period_out; a.period_in = hip->period_in;
+        if (a.period_out && a.mode == ART_MODE_FAST && hip->kernel_pref != ART_KERNEL_GENERAL) {
+            hip->d_fix = grow (hip->d_fix, &hip->fix_cap, sizeof (unsigned int) * ((size_t) res.output_generated + 1));
+            if (hip->d_fix) { a.fix_count = hip->d_fix; a.fix_list = hip->d_fix + 1; a.fix_cap = res.output_generated; }
+        }
 
         for (int s0 = 0; s0 < nseg; s0 += ART_MAX_SEGS) {
             const int s1 = s0 + ART_MAX_SEGS < nseg ? s0 + ART_MAX_SEGS : nseg;

@@ -13,7 +13,9 @@
 //   in    n x C  (or planar)   this call's new frames
 //   "linear index" lin addresses the concatenation hist ++ in; ring index + lin_base = lin.
 #include <hip/hip_runtime.h>
+#include <climits>
 #include <cstdio>
+#include <type_traits>
 #include "art_internal.h"
 
 namespace {
@@ -29,28 +31,35 @@ __device__ __forceinline__ float load_frame (const ArtFirArgs &a, int lin_floor,
     return a.in_pitch ? a.in [(size_t) ch * a.in_pitch + f] : a.in [(size_t) f * a.C + ch];
 }
 
+// last segment whose first output is <= n
+__device__ __forceinline__ int find_segment (const ArtSegTable &segs, unsigned int n)
+{
+    int lo = 0, hi = segs.count - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (segs.first [mid] <= n) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
 // exact replay of the reference's per-output position arithmetic (fp64, un-fused)
 template <bool INTERP>
 __device__ __forceinline__ Pos locate (const ArtFirArgs &a, const ArtSegTable &segs, unsigned int n)
 {
-    int e = 0;
-    for (int k = 1; k < segs.count; ++k)
-        if (segs.first [k] <= n) e = k;
-
+    const int e = find_segment (segs, n);
     const double step = n ? (double) n / a.ratio : 0.0;
     const double off = segs.base [e] + step;
     const double whole = floor (off);
     Pos p;
 
+    double fr = off - whole;
+    fr = fr * (double) a.F;
+
     if (INTERP) {
-        double fr = off - whole;
-        fr = fr * (double) a.F;
         p.fi = (int) floor (fr);
         p.frac = fr - (double) p.fi;
     }
     else {
-        double fr = off - whole;
-        fr = fr * (double) a.F;
         p.fi = (int) floor (fr + 0.5);
         p.frac = 0.0;
     }
@@ -92,9 +101,11 @@ constexpr int GEN_MAX_TILE = 32;
 // General kernel: one workgroup per tile of consecutive output frames; the tile's input span is
 // staged once in LDS (coalesced frame-major reads), then each wave evaluates whole output frames:
 // lanes stride the taps, every lane feeds CG channels and both interpolation rows from one LDS read.
+// `from_list`: instead of tiling [n_begin, n_end), every workgroup evaluates single output frames whose
+// indices were handed back by the MFMA kernel (a.fix_list / *a.fix_count).
 template <int CG, bool INTERP, bool PRECISE>
 __global__ __launch_bounds__ (GEN_THREADS)
-void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile)
+void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile, int from_list)
 {
     using Acc = typename std::conditional<PRECISE, double, float>::type;
     extern __shared__ __attribute__ ((aligned (16))) float xs [];
@@ -103,10 +114,14 @@ void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ch0 = blockIdx.y * CG;
-    const unsigned int n0 = a.n_begin + blockIdx.x * (unsigned int) tile;
-    const int cnt = min ((unsigned int) tile, a.n_end - n0);
     const int half = a.T / 2;
+    const unsigned int list_len = from_list ? min (*a.fix_count, a.fix_cap) : 1u;
 
+  for (unsigned int item = blockIdx.x; item < (from_list ? list_len : gridDim.x); item += gridDim.x) {
+    const unsigned int n0 = from_list ? a.fix_list [item] : a.n_begin + item * (unsigned int) tile;
+    const int cnt = from_list ? 1 : (int) min ((unsigned int) tile, a.n_end - n0);
+
+    __syncthreads ();                       // LDS reuse across list items
     if (tid < cnt) {
         Pos p = locate<INTERP> (a, segs, n0 + tid);
         s_ip [tid] = p.ip; s_fi [tid] = p.fi; s_frac [tid] = p.frac;
@@ -205,6 +220,7 @@ void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile)
                 else a.out [n * a.C + ch0 + c] = result [c];
             }
     }
+  }
 }
 
 // Strict kernel: one lane per output sample, taps visited in the reference's source order
@@ -258,6 +274,227 @@ void fir_strict_kernel (ArtFirArgs a, ArtSegTable segs, int precise)
     else a.out [(size_t) n * a.C + ch] = y;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// MFMA kernel for rational ratios (the headline path: 44.1k -> 48k is 160 outputs per 147 inputs).
+//
+// When ratio = P/Q exactly, output n+P sits exactly Q input frames after output n, at the same filter
+// phase.  Two facts turn the per-sample "two dot products + lerp" into one GEMM on the matrix cores:
+//
+//  (1) The lerp is linear, so for a fixed phase the two rows can be blended ONCE into an effective row
+//          g_i[k] = h[fi_i][k] * (1 - frac_i) + h[fi_i + 1][k] * frac_i        (fp64, rounded once to f32)
+//      shared by every period and channel — half the multiply-adds of the reference formulation.
+//  (2) 32 consecutive outputs ("slots" r0..r0+31 of the P-periodic pattern) have windows shifted by
+//      0/1 frames each, so their rows fit one zero-padded matrix over a common K = T + shift_max span:
+//
+//          Y[i, (j, c)] = sum_k A[i, k] * X[k, (j, c)],   A[i, k] = g_i[k - shift_i],  X[k, (j, c)] = x_c[w0 + j*Q + k]
+//
+//      a (32 x K) * (K x N) product, N = periods x channels, on exact-f32 v_mfma_f32_32x32x2_f32.
+//
+// A workgroup (4 waves) owns one slot tile and 128 columns, 32 per wave.  A and X chunks (32 k's) are
+// staged through LDS in [row][k] layout (+4 pad: conflict-free ds_read_b128; the 8 k's of a group are
+// split 4/4 over the two half-waves, a fixed permutation of the summation order).
+//
+// Accuracy.  An f32 accumulator that has swallowed the big central taps loses half an ulp on every
+// further add, so no f32 partial sum is carried past a chunk: after each 32-k chunk the MFMA
+// accumulator is added into an fp64 running sum and cleared, and inside the "centre band" (the chunks
+// holding the central taps of any row) after every 4 k's.  At most 3 adds follow a row's peak tap in
+// f32 — fewer full-magnitude roundings than the reference's own float loop.
+//
+// Exactness of positions.  Every output's (ip, fi, frac) is recomputed with the reference's own fp64
+// arithmetic and compared with its slot's canonical values (taken from the workgroup's first period).
+// Equal, or the same position within 1e-7 filter steps (phase values on a filter boundary can round to
+// the neighbouring (fi-1, frac ~ 1) representation; the effective rows differ by < 1e-10 relative):
+// the tile's row is used.  Anything else (ratio drift, ring-epoch seams) goes to a fix list that the
+// general kernel evaluates.
+// ---------------------------------------------------------------------------------------------------
+
+typedef float f32x16 __attribute__ ((ext_vector_type (16)));
+typedef float f32x4 __attribute__ ((ext_vector_type (4)));
+
+constexpr int MF_THREADS = 256;
+constexpr int MF_KC = 32;                 // k's per staged chunk
+constexpr int MF_LD = MF_KC + 4;          // LDS row pitch in floats (144 B: 16-B aligned, conflict-free b128)
+constexpr int MF_COLS = 128;              // columns per workgroup
+constexpr int MF_MAX_PPW = 64;            // periods per workgroup (C = 2)
+constexpr int MF_BSLOTS = (MF_KC * 32 + MF_THREADS - 1) / MF_THREADS;   // staging slots per thread at cg = 32
+
+struct MfmaGeom {
+    int P, Q;                             // outputs / inputs per period
+    int slot_tiles;                       // ceil (P / 32)
+    int ppw;                              // periods per workgroup
+    int cg;                               // channels per column group
+    int ktot;                             // K columns, multiple of MF_KC
+    int period_groups;
+    int band_lo, band_hi;                 // K columns [band_lo, band_hi) hold every row's central taps
+};
+
+template <bool INTERP>
+__global__ __launch_bounds__ (MF_THREADS, 2)
+void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
+{
+    __shared__ __attribute__ ((aligned (16))) float As [32 * MF_LD];
+    __shared__ __attribute__ ((aligned (16))) float Bs [MF_COLS * MF_LD];
+    __shared__ unsigned char s_status [32 * MF_MAX_PPW];      // 0 ok, 1 handed back, 2 masked, 3 pass-through
+    __shared__ int s_fi [32], s_shift [32], s_ip [32];
+    __shared__ double s_frac [32];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int st = blockIdx.x % g.slot_tiles, jg = blockIdx.x / g.slot_tiles;
+    const int ch_base = blockIdx.y * g.cg;
+    const int half = a.T / 2;
+    const int r0 = st * 32;
+    const int rows_valid = min (32, g.P - r0);
+    const unsigned int n_tile = a.n_begin + (unsigned int)(jg * g.ppw) * g.P + r0;     // slot 0, first period
+    if (n_tile >= a.n_end) return;
+
+    // ---- canonical (ip, fi, frac) of the 32 slots from the first period of this workgroup
+    if (tid < 32) {
+        const Pos p = locate<INTERP> (a, segs, n_tile + min (tid, rows_valid - 1));
+        s_ip [tid] = p.ip; s_fi [tid] = p.fi; s_frac [tid] = p.frac;
+    }
+    __syncthreads ();
+    const int w0 = s_ip [0] - half + 1;                      // linear index of K column 0 (first period)
+    if (tid < 32) s_shift [tid] = s_ip [tid] - s_ip [0];
+
+    // ---- exact position of every (slot, period) of the tile, checked against the canonical pattern
+    for (int e = tid; e < 32 * g.ppw; e += MF_THREADS) {
+        const int i = e & 31, jl = e >> 5;
+        const unsigned int n = n_tile + (unsigned int) jl * g.P + i;
+        unsigned char status = 2;
+        if (i < rows_valid && n < a.n_end) {
+            const Pos p = locate<INTERP> (a, segs, n);
+            const int dip = p.ip - (s_ip [i] + jl * g.Q), dfi = p.fi - s_fi [i];
+            if (dip == 0 && dfi == 0 && p.frac == s_frac [i]) status = 0;
+            else if (INTERP) {
+                const double d = (double)(dip * a.F + dfi) + (p.frac - s_frac [i]);   // signed distance in filter steps
+                status = (d >= -1e-7 && d <= 1e-7) ? 0 : 1;
+            }
+            else status = (dip == 0 && dfi == 0) ? 0 : 1;
+            if (!INTERP && status == 0 && !a.lowpass && (p.fi % a.F) == 0) status = 3;
+            if (status == 1) {
+                const unsigned int slot = atomicAdd (a.fix_count, 1u);
+                if (slot < a.fix_cap) a.fix_list [slot] = n;
+            }
+        }
+        s_status [e] = status;
+    }
+
+    double sum [16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sum [r] = 0.0;
+
+    const int nchunks = g.ktot / MF_KC;
+    const int ncols = g.ppw * g.cg;
+    const int arow = (lane & 31) * MF_LD + 4 * (lane >> 5);
+    const int brow = (wave * 32 + (lane & 31)) * MF_LD + 4 * (lane >> 5);
+
+    // this thread's (k, channel) slots within one period's chunk of 32 x cg samples (cg <= 32 => <= 4 slots)
+    int bs_kk [MF_BSLOTS], bs_c [MF_BSLOTS];
+#pragma unroll
+    for (int u = 0; u < MF_BSLOTS; ++u) {
+        const int idx = tid + u * MF_THREADS;
+        bs_kk [u] = idx < MF_KC * g.cg ? idx / g.cg : -1;
+        bs_c [u] = idx - (idx / g.cg) * g.cg;
+    }
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int k0 = chunk * MF_KC;
+
+        __syncthreads ();                                    // previous chunk fully consumed (and s_shift visible)
+        // ---- stage A: 32 rows x 32 k; each thread 4 consecutive k of one row; the lerp is folded in here
+        {
+            const int row = tid >> 3, kseg = (tid & 7) * 4;
+            const float *h0 = a.bank + (size_t) s_fi [row] * a.T;
+            const int kb = k0 + kseg - s_shift [row];
+            const double f = s_frac [row];
+            f32x4 v;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = kb + q;
+                float c = 0.0f;
+                if (k >= 0 && k < a.T) {
+                    if (INTERP) {
+                        const double left = (double) h0 [k] * (1.0 - f);
+                        const double right = (double) h0 [k + a.T] * f;
+                        c = (float)(left + right);
+                    }
+                    else c = h0 [k];
+                }
+                v [q] = c;
+            }
+            *reinterpret_cast<f32x4 *> (&As [row * MF_LD + kseg]) = v;
+        }
+        // ---- stage B: columns (period, channel).  One period's chunk is 32 frames x cg channels of
+        // contiguous memory; thread slots (kk, c) are fixed for the whole kernel (no index division here)
+#pragma unroll
+        for (int u = 0; u < MF_BSLOTS; ++u) {
+            if (bs_kk [u] < 0) continue;
+            const int kk = bs_kk [u], c = bs_c [u];
+            for (int jl = 0; jl < g.ppw; ++jl) {
+                const int lin = w0 + jl * g.Q + k0 + kk;
+                Bs [(jl * g.cg + c) * MF_LD + kk] = load_frame (a, INT_MIN, lin, ch_base + c);
+            }
+        }
+        if (ncols < MF_COLS)
+            for (int e = tid; e < (MF_COLS - ncols) * MF_KC; e += MF_THREADS)
+                Bs [(ncols + e / MF_KC) * MF_LD + (e % MF_KC)] = 0.0f;
+        __syncthreads ();
+
+        // ---- 32 k's = 4 groups of 8; lanes 0-31 take k 0-3 of a group, lanes 32-63 k 4-7
+        const bool band = k0 < g.band_hi && k0 + MF_KC > g.band_lo;
+        if (!band) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc [r] = 0.0f;
+#pragma unroll
+            for (int grp = 0; grp < MF_KC / 8; ++grp) {
+                const f32x4 av = *reinterpret_cast<const f32x4 *> (&As [arow + grp * 8]);
+                const f32x4 bv = *reinterpret_cast<const f32x4 *> (&Bs [brow + grp * 8]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [q], bv [q], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum [r] = sum [r] + (double) acc [r];
+        }
+        else {
+#pragma unroll
+            for (int grp = 0; grp < MF_KC / 8; ++grp) {
+                const f32x4 av = *reinterpret_cast<const f32x4 *> (&As [arow + grp * 8]);
+                const f32x4 bv = *reinterpret_cast<const f32x4 *> (&Bs [brow + grp * 8]);
+#pragma unroll
+                for (int q = 0; q < 4; q += 2) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc [r] = 0.0f;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [q], bv [q], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [q + 1], bv [q + 1], acc, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sum [r] = sum [r] + (double) acc [r];
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: C/D layout of 32x32: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31
+    const int col = wave * 32 + (lane & 31);
+    if (col >= ncols) return;
+    const int jl = col / g.cg, c = col - jl * g.cg;
+    if (ch_base + c >= a.C) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const unsigned char status = s_status [jl * 32 + i];
+        if (status == 0 || status == 3) {
+            const size_t n = (size_t) n_tile + (size_t) jl * g.P + i;
+            float y = (float) sum [r];
+            if (!INTERP && status == 3)
+                y = load_frame (a, INT_MIN, s_ip [i] + jl * g.Q + s_fi [i] / a.F, ch_base + c);
+            a.out [n * a.C + ch_base + c] = y;
+        }
+    }
+}
+
 __global__ void roll_history_kernel (float *dst, const float *hist, const float *in, long in_pitch, int appended, int H, int C)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -286,24 +523,24 @@ __global__ void deinterleave_kernel (float *dst, long pitch, const float *src, i
 }
 
 template <int CG>
-int launch_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st)
+int launch_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st, int from_list = 0)
 {
     // tile size: as many consecutive outputs as keep the staged span within the LDS budget
     const int lds_budget = 64 * 1024;
     const int max_span = lds_budget / (4 * CG);
     int tile = (int) floor ((max_span - a.T - 3) * a.ratio);
     if (tile > GEN_MAX_TILE) tile = GEN_MAX_TILE;
-    if (tile < 1) tile = 1;
+    if (tile < 1 || from_list) tile = 1;
     long span = a.T + (long) ceil (tile / a.ratio) + 3;
     size_t lds = (size_t) span * CG * 4;
     if (lds > 160 * 1024 - 1024) return -1;                 // absurd ratio/taps combination
     const unsigned int total = a.n_end - a.n_begin;
-    dim3 grid ((total + tile - 1) / tile, (a.C + CG - 1) / CG);
+    dim3 grid (from_list ? 512u : (total + tile - 1) / tile, (a.C + CG - 1) / CG);
     const bool precise = (a.mode & 3) == ART_MODE_PRECISE;
 
 #define GO(I, P) do { auto k = fir_general_kernel<CG, I, P>; \
         if (lds > 48 * 1024) (void) hipFuncSetAttribute ((const void *) k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
-        hipLaunchKernelGGL (k, grid, dim3 (GEN_THREADS), lds, st, a, segs, tile); } while (0)
+        hipLaunchKernelGGL (k, grid, dim3 (GEN_THREADS), lds, st, a, segs, tile, from_list); } while (0)
     if (a.interpolate) { if (precise) GO (true, true); else GO (true, false); }
     else               { if (precise) GO (false, true); else GO (false, false); }
 #undef GO
@@ -314,10 +551,17 @@ int launch_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st
 
 extern "C" {
 
+static int run_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st, int from_list)
+{
+    if (a.C > 4) return launch_general<8> (a, segs, st, from_list);
+    if (a.C > 2) return launch_general<4> (a, segs, st, from_list);
+    if (a.C == 2) return launch_general<2> (a, segs, st, from_list);
+    return launch_general<1> (a, segs, st, from_list);
+}
+
 int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, void *stream)
 {
     hipStream_t st = (hipStream_t) stream;
-    (void) kernel_pref;
 
     if (a->n_end <= a->n_begin) return ART_KERNEL_GENERAL;
 
@@ -329,12 +573,37 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
         return hipGetLastError () == hipSuccess ? ART_KERNEL_GENERAL : -1;
     }
 
-    int rc;
-    if (a->C >= 8 || a->C > 4) rc = launch_general<8> (*a, *segs, st);
-    else if (a->C > 2) rc = launch_general<4> (*a, *segs, st);
-    else if (a->C == 2) rc = launch_general<2> (*a, *segs, st);
-    else rc = launch_general<1> (*a, *segs, st);
-    if (rc) return rc;
+    // MFMA path: exact rational ratio, default numeric mode, interleaved buffers, no history floor, and at
+    // least a few periods of work (below that the tile is mostly padding and the general kernel wins)
+    const unsigned int total = a->n_end - a->n_begin;
+    const bool mfma_ok = a->mode == ART_MODE_FAST && a->period_out > 0 && a->fix_list && a->in_pitch == 0 && a->out_pitch == 0 &&
+                         segs->lin_floor == INT_MIN && kernel_pref != ART_KERNEL_GENERAL &&
+                         (total >= 4u * (unsigned int) a->period_out || kernel_pref == ART_KERNEL_MFMA) && total >= (unsigned int) a->period_out;
+
+    if (mfma_ok) {
+        MfmaGeom g;
+        g.P = a->period_out; g.Q = a->period_in;
+        g.slot_tiles = (g.P + 31) / 32;
+        g.cg = a->C < 32 ? a->C : 32;
+        g.ppw = MF_COLS / g.cg;
+        if (g.ppw > MF_MAX_PPW) g.ppw = MF_MAX_PPW;
+        const int shift_max = (int)(31.0 * g.Q / g.P) + 2;
+        g.ktot = ((a->T + shift_max + MF_KC - 1) / MF_KC) * MF_KC;
+        g.band_lo = a->T / 2 - 1 - 6;                       // central taps of the first row ...
+        g.band_hi = a->T / 2 + shift_max + 6;               // ... to those of the last
+        const unsigned int periods = (total + g.P - 1) / g.P;
+        g.period_groups = (int)((periods + g.ppw - 1) / g.ppw);
+        dim3 grid ((unsigned int)(g.slot_tiles * g.period_groups), (unsigned int)((a->C + g.cg - 1) / g.cg));
+
+        if (hipMemsetAsync (a->fix_count, 0, sizeof (unsigned int), st) != hipSuccess) return -1;
+        if (a->interpolate) hipLaunchKernelGGL (fir_mfma_kernel<true>, grid, dim3 (MF_THREADS), 0, st, *a, *segs, g);
+        else hipLaunchKernelGGL (fir_mfma_kernel<false>, grid, dim3 (MF_THREADS), 0, st, *a, *segs, g);
+        if (hipGetLastError () != hipSuccess) return -1;
+        if (run_general (*a, *segs, st, 1)) return -1;          // outputs handed back (usually none)
+        return hipGetLastError () == hipSuccess ? ART_KERNEL_MFMA : -1;
+    }
+
+    if (run_general (*a, *segs, st, 0)) return -1;
     return hipGetLastError () == hipSuccess ? ART_KERNEL_GENERAL : -1;
 }
 

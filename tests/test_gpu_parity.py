@@ -67,6 +67,37 @@ def test_fast_mode_within_one_ulp_fullscale_of_precise(name):
 
 
 @pytest.mark.parametrize("name", G.NAMES)
+def test_mfma_kernel_within_one_ulp_fullscale_of_precise(name):
+    """same contract with the MFMA periodic-phase kernel forced on wherever the ratio is rational
+    (short calls included; non-rational calls fall back to the general kernel inside the library)"""
+    r = G.make(HipResampler, name, kernel=2)
+    y, trace = G.replay(r, name)
+    truth, _ = G.replay(G.make(OracleResampler, name, PRECISE), name)
+    assert np.array_equal(trace[:, :4], G.load("resample")[name + "/trace"][:, :4])
+    ok, worst, rms = tolerance_ok(y, truth)
+    assert ok, (worst, rms)
+    ref_float, _ = G.replay(G.make(OracleResampler, name), name)
+    assert rms <= tolerance_ok(ref_float, truth)[2] * 1.25 + 1e-12
+
+
+def test_mfma_kernel_is_the_one_running_the_headline_config():
+    ch, T = 8, 988
+    x, _ = noise(ch * 40000)
+    x = x.reshape(-1, ch)
+    r = HipResampler(ch, T, T, 0.0, BH | INTERP)
+    o = OracleResampler(ch, T, T, 0.0, BH | INTERP | PRECISE)
+    for b in (r, o):
+        b.advance(T / 2)
+    for k in range(2):
+        u, g, y = r.process(x[k * 20000:(k + 1) * 20000], 23000, 48000 / 44100)
+        uo, go, yo = o.process(x[k * 20000:(k + 1) * 20000], 23000, 48000 / 44100)
+        assert (u, g) == (uo, go)
+        assert r.last_kernel() == 2
+        ok, worst, rms = tolerance_ok(y, yo)
+        assert ok and rms < 2.0e-8, (worst, rms)
+
+
+@pytest.mark.parametrize("name", G.NAMES)
 def test_precise_mode_matches_double_accumulate_reference(name):
     y, _ = G.replay(G.make(HipResampler, name, PRECISE), name)
     truth, _ = G.replay(G.make(OracleResampler, name, PRECISE), name)
@@ -119,7 +150,8 @@ def test_planar_and_device_entry_points_equal_interleaved():
     x, _ = noise(ch * 5000)
     x = x.reshape(-1, ch)
     ratio = 48000 / 44100
-    a, b, c, d = (HipResampler(ch, T, 32, 0.7, BH | INTERP) for _ in range(4))
+    # one kernel for all four so that the comparison is about the entry-point plumbing only
+    a, b, c, d = (HipResampler(ch, T, 32, 0.7, BH | INTERP, kernel=1) for _ in range(4))
     for r in (a, b, c, d):
         r.advance(T / 2)
     outs = []
