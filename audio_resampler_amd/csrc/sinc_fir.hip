@@ -14,6 +14,7 @@
 //   "linear index" lin addresses the concatenation hist ++ in; ring index + lin_base = lin.
 #include <hip/hip_runtime.h>
 #include <climits>
+#include <cstdint>
 #include <cstdio>
 #include <type_traits>
 #include "art_internal.h"
@@ -328,7 +329,28 @@ struct MfmaGeom {
     int band_lo, band_hi;                 // K columns [band_lo, band_hi) hold every row's central taps
 };
 
-template <bool INTERP>
+typedef unsigned int u32x4 __attribute__ ((ext_vector_type (4)));
+typedef unsigned int u32x2 __attribute__ ((ext_vector_type (2)));
+
+// raw buffer descriptor: the hardware range check returns 0 for any access past `bytes`, which is
+// exactly the zero padding the tile needs (beyond the valid input, before/after a filter row)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc (const void *base, unsigned int bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc (const_cast<void *> (base), 0, (int) bytes, 0x00020000);
+}
+
+template <int VEC> struct VecLoad;
+template <> struct VecLoad<1> { static __device__ __forceinline__ void load (float *dst, __amdgpu_buffer_rsrc_t r, unsigned int off) {
+    dst [0] = __uint_as_float (__builtin_amdgcn_raw_buffer_load_b32 (r, (int) off, 0, 0)); } };
+template <> struct VecLoad<2> { static __device__ __forceinline__ void load (float *dst, __amdgpu_buffer_rsrc_t r, unsigned int off) {
+    u32x2 v = __builtin_amdgcn_raw_buffer_load_b64 (r, (int) off, 0, 0);
+    dst [0] = __uint_as_float (v.x); dst [1] = __uint_as_float (v.y); } };
+template <> struct VecLoad<4> { static __device__ __forceinline__ void load (float *dst, __amdgpu_buffer_rsrc_t r, unsigned int off) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128 (r, (int) off, 0, 0);
+    dst [0] = __uint_as_float (v.x); dst [1] = __uint_as_float (v.y); dst [2] = __uint_as_float (v.z); dst [3] = __uint_as_float (v.w); } };
+
+// CG > 0: the stream has exactly CG channels (compile-time index math, vector loads);  CG == 0: any count.
+template <bool INTERP, int CG>
 __global__ __launch_bounds__ (MF_THREADS, 2)
 void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
 {
@@ -340,11 +362,12 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int st = blockIdx.x % g.slot_tiles, jg = blockIdx.x / g.slot_tiles;
-    const int ch_base = blockIdx.y * g.cg;
+    const int cg = CG ? CG : g.cg, ppw = CG ? (MF_COLS / CG > MF_MAX_PPW ? MF_MAX_PPW : MF_COLS / CG) : g.ppw;
+    const int ch_base = blockIdx.y * cg;
     const int half = a.T / 2;
     const int r0 = st * 32;
     const int rows_valid = min (32, g.P - r0);
-    const unsigned int n_tile = a.n_begin + (unsigned int)(jg * g.ppw) * g.P + r0;     // slot 0, first period
+    const unsigned int n_tile = a.n_begin + (unsigned int)(jg * ppw) * g.P + r0;       // slot 0, first period
     if (n_tile >= a.n_end) return;
 
     // ---- canonical (ip, fi, frac) of the 32 slots from the first period of this workgroup
@@ -357,7 +380,7 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
     if (tid < 32) s_shift [tid] = s_ip [tid] - s_ip [0];
 
     // ---- exact position of every (slot, period) of the tile, checked against the canonical pattern
-    for (int e = tid; e < 32 * g.ppw; e += MF_THREADS) {
+    for (int e = tid; e < 32 * ppw; e += MF_THREADS) {
         const int i = e & 31, jl = e >> 5;
         const unsigned int n = n_tile + (unsigned int) jl * g.P + i;
         unsigned char status = 2;
@@ -378,67 +401,118 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
         }
         s_status [e] = status;
     }
+    __syncthreads ();
+
+    // ---- staging plan.  All loads are raw buffer loads; everything out of range reads as 0.
+    const __amdgpu_buffer_rsrc_t rs_bank = make_rsrc (a.bank, (unsigned int)((size_t)(a.F + 1) * a.T * 4));
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc (a.in, (unsigned int)((size_t) a.in_frames * a.C * 4));
+    const __amdgpu_buffer_rsrc_t rs_hist = make_rsrc (a.hist, (unsigned int)((size_t) a.H * a.C * 4));
+    const bool touches_hist = w0 < a.H;                      // only the first period group of a call
+
+    // A: thread -> (row, 4 consecutive k)
+    const int a_row = tid >> 3, a_kseg = (tid & 7) * 4;
+    const int a_tap0 = a_kseg - s_shift [a_row];             // tap index of this thread's first k at chunk 0
+    const unsigned int a_rowoff = (unsigned int) s_fi [a_row] * (unsigned int) a.T;
+    const double a_frac = s_frac [a_row];
+
+    // B: thread -> NB vectors of VEC channels of one frame of one period
+    constexpr int VEC = CG >= 4 ? 4 : (CG == 2 ? 2 : 1);
+    constexpr int VPF = CG ? CG / VEC : 1;                   // vectors per frame
+    constexpr int VPP = MF_KC * VPF;                         // vectors per period-chunk
+    constexpr int PPW_C = CG ? (MF_COLS / CG > MF_MAX_PPW ? MF_MAX_PPW : MF_COLS / CG) : 1;
+    constexpr int NB = CG ? (PPW_C * VPP) / MF_THREADS : 1;
+
+    float ra0 [4], ra1 [4];
+    float rb [NB * VEC];
+
+    auto fetch = [&] (int chunk) {
+        const int k0 = chunk * MF_KC;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int tap = a_tap0 + k0 + q;
+            const unsigned int off = ((unsigned int) tap < (unsigned int) a.T) ? (a_rowoff + (unsigned int) tap) * 4u : 0xffffff00u;
+            VecLoad<1>::load (&ra0 [q], rs_bank, off);
+            if (INTERP) VecLoad<1>::load (&ra1 [q], rs_bank, off == 0xffffff00u ? off : off + (unsigned int) a.T * 4u);
+        }
+        if (CG) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int v = tid + u * MF_THREADS;
+                const int jl = v / VPP, rem = v % VPP, kk = rem / VPF, cv = rem % VPF;
+                const int lin = w0 + jl * g.Q + k0 + kk;
+                const unsigned int oi = (unsigned int)((lin - a.H) * CG + cv * VEC) * 4u;      // wraps (=> 0) below H
+                VecLoad<VEC>::load (&rb [u * VEC], rs_in, oi);
+                if (touches_hist) {
+                    float hv [VEC];
+                    VecLoad<VEC>::load (hv, rs_hist, (unsigned int)(lin * CG + cv * VEC) * 4u);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) rb [u * VEC + e] = __uint_as_float (__float_as_uint (rb [u * VEC + e]) | __float_as_uint (hv [e]));
+                }
+            }
+        }
+    };
+
+    auto commit = [&] (int chunk) {
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (INTERP) {
+                const double left = (double) ra0 [q] * (1.0 - a_frac);
+                const double right = (double) ra1 [q] * a_frac;
+                v [q] = (float)(left + right);
+            }
+            else v [q] = ra0 [q];
+        }
+        *reinterpret_cast<f32x4 *> (&As [a_row * MF_LD + a_kseg]) = v;
+
+        if (CG) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int vi = tid + u * MF_THREADS;
+                const int jl = vi / VPP, rem = vi % VPP, kk = rem / VPF, cv = rem % VPF;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    Bs [(jl * CG + cv * VEC + e) * MF_LD + kk] = rb [u * VEC + e];
+            }
+        }
+        else {
+            // generic channel count: plain loop, four loads in flight at a time
+            const int k0 = chunk * MF_KC, per = MF_KC * cg, total = ppw * per;
+            for (int e0 = tid; e0 < total; e0 += 4 * MF_THREADS) {
+                float tmp [4]; int dst [4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * MF_THREADS;
+                    const int jl = e / per, rem = e - jl * per, kk = rem / cg, c = rem - kk * cg;
+                    dst [u] = e < total ? (jl * cg + c) * MF_LD + kk : -1;
+                    tmp [u] = e < total ? load_frame (a, INT_MIN, w0 + jl * g.Q + k0 + kk, ch_base + c) : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (dst [u] >= 0) Bs [dst [u]] = tmp [u];
+            }
+        }
+    };
+
+    const int ncols = ppw * cg;
+    if (ncols < MF_COLS)                                     // unused columns stay zero for the whole kernel
+        for (int e = tid; e < (MF_COLS - ncols) * MF_LD; e += MF_THREADS) Bs [ncols * MF_LD + e] = 0.0f;
 
     double sum [16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) sum [r] = 0.0;
 
     const int nchunks = g.ktot / MF_KC;
-    const int ncols = g.ppw * g.cg;
     const int arow = (lane & 31) * MF_LD + 4 * (lane >> 5);
     const int brow = (wave * 32 + (lane & 31)) * MF_LD + 4 * (lane >> 5);
 
-    // this thread's (k, channel) slots within one period's chunk of 32 x cg samples (cg <= 32 => <= 4 slots)
-    int bs_kk [MF_BSLOTS], bs_c [MF_BSLOTS];
-#pragma unroll
-    for (int u = 0; u < MF_BSLOTS; ++u) {
-        const int idx = tid + u * MF_THREADS;
-        bs_kk [u] = idx < MF_KC * g.cg ? idx / g.cg : -1;
-        bs_c [u] = idx - (idx / g.cg) * g.cg;
-    }
-
+    fetch (0);
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int k0 = chunk * MF_KC;
 
-        __syncthreads ();                                    // previous chunk fully consumed (and s_shift visible)
-        // ---- stage A: 32 rows x 32 k; each thread 4 consecutive k of one row; the lerp is folded in here
-        {
-            const int row = tid >> 3, kseg = (tid & 7) * 4;
-            const float *h0 = a.bank + (size_t) s_fi [row] * a.T;
-            const int kb = k0 + kseg - s_shift [row];
-            const double f = s_frac [row];
-            f32x4 v;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int k = kb + q;
-                float c = 0.0f;
-                if (k >= 0 && k < a.T) {
-                    if (INTERP) {
-                        const double left = (double) h0 [k] * (1.0 - f);
-                        const double right = (double) h0 [k + a.T] * f;
-                        c = (float)(left + right);
-                    }
-                    else c = h0 [k];
-                }
-                v [q] = c;
-            }
-            *reinterpret_cast<f32x4 *> (&As [row * MF_LD + kseg]) = v;
-        }
-        // ---- stage B: columns (period, channel).  One period's chunk is 32 frames x cg channels of
-        // contiguous memory; thread slots (kk, c) are fixed for the whole kernel (no index division here)
-#pragma unroll
-        for (int u = 0; u < MF_BSLOTS; ++u) {
-            if (bs_kk [u] < 0) continue;
-            const int kk = bs_kk [u], c = bs_c [u];
-            for (int jl = 0; jl < g.ppw; ++jl) {
-                const int lin = w0 + jl * g.Q + k0 + kk;
-                Bs [(jl * g.cg + c) * MF_LD + kk] = load_frame (a, INT_MIN, lin, ch_base + c);
-            }
-        }
-        if (ncols < MF_COLS)
-            for (int e = tid; e < (MF_COLS - ncols) * MF_KC; e += MF_THREADS)
-                Bs [(ncols + e / MF_KC) * MF_LD + (e % MF_KC)] = 0.0f;
+        __syncthreads ();                                    // previous chunk fully consumed
+        commit (chunk);
         __syncthreads ();
+        if (chunk + 1 < nchunks) fetch (chunk + 1);          // global loads fly while the matrix cores work
 
         // ---- 32 k's = 4 groups of 8; lanes 0-31 take k 0-3 of a group, lanes 32-63 k 4-7
         const bool band = k0 < g.band_hi && k0 + MF_KC > g.band_lo;
@@ -479,7 +553,7 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
     // ---- epilogue: C/D layout of 32x32: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31
     const int col = wave * 32 + (lane & 31);
     if (col >= ncols) return;
-    const int jl = col / g.cg, c = col - jl * g.cg;
+    const int jl = col / cg, c = col - jl * cg;
     if (ch_base + c >= a.C) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -596,8 +670,16 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
         dim3 grid ((unsigned int)(g.slot_tiles * g.period_groups), (unsigned int)((a->C + g.cg - 1) / g.cg));
 
         if (hipMemsetAsync (a->fix_count, 0, sizeof (unsigned int), st) != hipSuccess) return -1;
-        if (a->interpolate) hipLaunchKernelGGL (fir_mfma_kernel<true>, grid, dim3 (MF_THREADS), 0, st, *a, *segs, g);
-        else hipLaunchKernelGGL (fir_mfma_kernel<false>, grid, dim3 (MF_THREADS), 0, st, *a, *segs, g);
+        // compile-time channel count where the whole stream is one column group and the buffers allow
+        // vector loads; otherwise the generic instantiation
+        const bool small = (size_t) a->in_frames * a->C * 4 < 0xffff0000ull && ((uintptr_t) a->in % 16) == 0 && ((uintptr_t) a->hist % 16) == 0;
+        const int cgt = (small && (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8)) ? a->C : 0;
+#define MF_GO(I, CGT) hipLaunchKernelGGL ((fir_mfma_kernel<I, CGT>), grid, dim3 (MF_THREADS), 0, st, *a, *segs, g)
+        if (a->interpolate) switch (cgt) { case 8: MF_GO (true, 8); break; case 4: MF_GO (true, 4); break; case 2: MF_GO (true, 2); break;
+                                            case 1: MF_GO (true, 1); break; default: MF_GO (true, 0); }
+        else                switch (cgt) { case 8: MF_GO (false, 8); break; case 4: MF_GO (false, 4); break; case 2: MF_GO (false, 2); break;
+                                            case 1: MF_GO (false, 1); break; default: MF_GO (false, 0); }
+#undef MF_GO
         if (hipGetLastError () != hipSuccess) return -1;
         if (run_general (*a, *segs, st, 1)) return -1;          // outputs handed back (usually none)
         return hipGetLastError () == hipSuccess ? ART_KERNEL_MFMA : -1;
