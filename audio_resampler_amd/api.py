@@ -101,6 +101,7 @@ EXPORTED_SYMBOLS = {
     "resampleHipSynchronize": (None, [RP]),
     "resampleHipSetKernel": (None, [RP, C.c_int]),
     "resampleHipLastKernel": (C.c_int, [RP]),
+    "resampleHipLastHandedBack": (C.c_uint, [RP]),
     "resampleHipSetTiming": (None, [RP, C.c_int]),
     "resampleHipReadTiming": (C.c_double, [RP, C.POINTER(C.c_int)]),
     "resampleProcessInterleavedDevice": (ResampleResult, [RP, ptr, C.c_int, ptr, C.c_int, C.c_double]),
@@ -213,6 +214,9 @@ class Resampler:
 
     def synchronize(self):
         self.L.resampleHipSynchronize(self.p)
+
+    def handed_back(self):
+        return self.L.resampleHipLastHandedBack(self.p)
 
     def set_timing(self, on=True):
         self.L.resampleHipSetTiming(self.p, int(on))

@@ -47,6 +47,8 @@ typedef struct {
     /* scratch for outputs the MFMA kernel hands back to the general kernel (device memory) */
     unsigned int *fix_list, *fix_count;
     unsigned int fix_cap;
+    /* optional HIP events recorded immediately before/after the dominant kernel's launch (host side only) */
+    void *ev_start, *ev_stop;
 } ArtFirArgs;
 
 /* ---- device_rt.hip ---- */

@@ -475,6 +475,16 @@ static void *timing_event (struct artamd_resampler *hip)
 }
 int  resampleHipLastKernel (Resample *cxt) { return cxt->hip->last_kernel; }
 
+/* outputs the MFMA kernel has handed back to the general kernel so far (synchronises) */
+unsigned int resampleHipLastHandedBack (Resample *cxt)
+{
+    unsigned int n = 0;
+    if (!cxt->hip->d_fix) return 0;
+    arthip_d2h (&n, cxt->hip->d_fix + 1, sizeof (n), cxt->hip->stream);      /* running total since context creation */
+    arthip_sync (cxt->hip->stream);
+    return n;
+}
+
 /* Plan one call, enqueue the FIR launches and the history roll.  `d_in` holds the call's input on
  * the device (interleaved, or planar with `in_pitch`); `d_out` receives the output likewise. */
 static ResampleResult enqueue_call (Resample *cxt, const float *d_in, long in_pitch, int nIn,
@@ -522,8 +532,12 @@ static ResampleResult enqueue_call (Resample *cxt, const float *d_in, long in_pi
         a.ratio = eff_ratio;
         a.period_out = hip->period_out; a.period_in = hip->period_in;
         if (a.period_out && a.mode == ART_MODE_FAST && hip->kernel_pref != ART_KERNEL_GENERAL) {
-            hip->d_fix = grow (hip->d_fix, &hip->fix_cap, sizeof (unsigned int) * ((size_t) res.output_generated + 1));
-            if (hip->d_fix) { a.fix_count = hip->d_fix; a.fix_list = hip->d_fix + 1; a.fix_cap = res.output_generated; }
+            /* [0] per-launch count, [1] running total (diagnostics), [2..] the list */
+            if (sizeof (unsigned int) * ((size_t) res.output_generated + 2) > hip->fix_cap) {
+                hip->d_fix = grow (hip->d_fix, &hip->fix_cap, sizeof (unsigned int) * ((size_t) res.output_generated + 2));
+                if (hip->d_fix) arthip_zero (hip->d_fix, 2 * sizeof (unsigned int), hip->stream);
+            }
+            if (hip->d_fix) { a.fix_count = hip->d_fix; a.fix_list = hip->d_fix + 2; a.fix_cap = res.output_generated; }
         }
 
         for (int s0 = 0; s0 < nseg; s0 += ART_MAX_SEGS) {
@@ -539,9 +553,9 @@ static ResampleResult enqueue_call (Resample *cxt, const float *d_in, long in_pi
             a.n_begin = hip->segs [s0].first_output;
             a.n_end = s1 < nseg ? hip->segs [s1].first_output : res.output_generated;
             if (a.n_end > a.n_begin) {
-                if (hip->timing) arthip_event_record (timing_event (hip), hip->stream);
+                a.ev_start = hip->timing ? timing_event (hip) : NULL;
+                a.ev_stop = hip->timing ? timing_event (hip) : NULL;
                 int k = arthip_fir (&a, &tab, hip->kernel_pref, hip->stream);
-                if (hip->timing) arthip_event_record (timing_event (hip), hip->stream);
                 if (k < 0) { fprintf (stderr, "artamd: FIR launch failed: %s\n", arthip_last_error ()); res.input_used = res.output_generated = 0; return res; }
                 hip->last_kernel = k;
             }

@@ -303,7 +303,7 @@ void fir_strict_kernel (ArtFirArgs a, ArtSegTable segs, int precise)
 //
 // Exactness of positions.  Every output's (ip, fi, frac) is recomputed with the reference's own fp64
 // arithmetic and compared with its slot's canonical values (taken from the workgroup's first period).
-// Equal, or the same position within 1e-7 filter steps (phase values on a filter boundary can round to
+// Equal, or the same position within MF_PHASE_TOL filter steps (phase values on a filter boundary can round to
 // the neighbouring (fi-1, frac ~ 1) representation; the effective rows differ by < 1e-10 relative):
 // the tile's row is used.  Anything else (ratio drift, ring-epoch seams) goes to a fix list that the
 // general kernel evaluates.
@@ -317,6 +317,10 @@ constexpr int MF_KC = 32;                 // k's per staged chunk
 constexpr int MF_LD = MF_KC + 4;          // LDS row pitch in floats (144 B: 16-B aligned, conflict-free b128)
 constexpr int MF_COLS = 128;              // columns per workgroup
 constexpr int MF_MAX_PPW = 64;            // periods per workgroup (C = 2)
+// A slot's phase may differ from its canonical value by this many filter steps and still use the tile's
+// effective row: adjacent rows differ by < 3e-3 per tap, so the row changes by < 6e-9 relative (a tenth of
+// half a float ulp).  The reference's own position arithmetic is quantised to ~1e-7 steps after 1M frames.
+constexpr double MF_PHASE_TOL = 2e-6;
 constexpr int MF_BSLOTS = (MF_KC * 32 + MF_THREADS - 1) / MF_THREADS;   // staging slots per thread at cg = 32
 
 struct MfmaGeom {
@@ -390,13 +394,14 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
             if (dip == 0 && dfi == 0 && p.frac == s_frac [i]) status = 0;
             else if (INTERP) {
                 const double d = (double)(dip * a.F + dfi) + (p.frac - s_frac [i]);   // signed distance in filter steps
-                status = (d >= -1e-7 && d <= 1e-7) ? 0 : 1;
+                status = (d >= -MF_PHASE_TOL && d <= MF_PHASE_TOL) ? 0 : 1;
             }
             else status = (dip == 0 && dfi == 0) ? 0 : 1;
             if (!INTERP && status == 0 && !a.lowpass && (p.fi % a.F) == 0) status = 3;
             if (status == 1) {
                 const unsigned int slot = atomicAdd (a.fix_count, 1u);
                 if (slot < a.fix_cap) a.fix_list [slot] = n;
+                atomicAdd (a.fix_count + 1, 1u);
             }
         }
         s_status [e] = status;
@@ -644,6 +649,7 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
         dim3 grid ((unsigned int)((total + 255) / 256));
         if (a->interpolate) hipLaunchKernelGGL (fir_strict_kernel<true>, grid, dim3 (256), 0, st, *a, *segs, (a->mode & 4) != 0);
         else hipLaunchKernelGGL (fir_strict_kernel<false>, grid, dim3 (256), 0, st, *a, *segs, (a->mode & 4) != 0);
+        if (a->ev_start) { arthip_event_record (a->ev_start, stream); arthip_event_record (a->ev_stop, stream); }
         return hipGetLastError () == hipSuccess ? ART_KERNEL_GENERAL : -1;
     }
 
@@ -670,6 +676,7 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
         dim3 grid ((unsigned int)(g.slot_tiles * g.period_groups), (unsigned int)((a->C + g.cg - 1) / g.cg));
 
         if (hipMemsetAsync (a->fix_count, 0, sizeof (unsigned int), st) != hipSuccess) return -1;
+        if (a->ev_start) arthip_event_record (a->ev_start, stream);
         // compile-time channel count where the whole stream is one column group and the buffers allow
         // vector loads; otherwise the generic instantiation
         const bool small = (size_t) a->in_frames * a->C * 4 < 0xffff0000ull && ((uintptr_t) a->in % 16) == 0 && ((uintptr_t) a->hist % 16) == 0;
@@ -680,12 +687,15 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
         else                switch (cgt) { case 8: MF_GO (false, 8); break; case 4: MF_GO (false, 4); break; case 2: MF_GO (false, 2); break;
                                             case 1: MF_GO (false, 1); break; default: MF_GO (false, 0); }
 #undef MF_GO
+        if (a->ev_stop) arthip_event_record (a->ev_stop, stream);
         if (hipGetLastError () != hipSuccess) return -1;
         if (run_general (*a, *segs, st, 1)) return -1;          // outputs handed back (usually none)
         return hipGetLastError () == hipSuccess ? ART_KERNEL_MFMA : -1;
     }
 
+    if (a->ev_start) arthip_event_record (a->ev_start, stream);
     if (run_general (*a, *segs, st, 0)) return -1;
+    if (a->ev_stop) arthip_event_record (a->ev_stop, stream);
     return hipGetLastError () == hipSuccess ? ART_KERNEL_GENERAL : -1;
 }
 

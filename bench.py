@@ -145,15 +145,10 @@ def main():
     kernel_ms, launches = rs.read_timing()
     kernel_used = rs.last_kernel()
 
-    stats = torch.tensor([dt, float(out_frames * Cn), kernel_ms, float(launches)], device="cuda", dtype=torch.float64)
-    if dist is not None:
-        tmax = stats.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = stats.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt_max, samples_total = tmax[0].item(), tsum[1].item()
-    else:
-        dt_max, samples_total = dt, float(out_frames * Cn)
+    from audio_resampler_amd.shard import agree_and_aggregate
+    agg = agree_and_aggregate(dist, "cuda", dt, out_frames, Cn, kernel_ms, launches)
+    dt_max, samples_total = agg["seconds_max"], agg["samples_total"]
+    assert agg["frames_consistent"], "ranks disagree on the number of generated frames"
 
     if rank == 0:
         # roofline of the dominant kernel (the FIR), from HIP events recorded around its launches on its stream
@@ -179,6 +174,9 @@ def main():
                          "frac": round(tflops / PEAK_FP32_TFLOPS, 4), "traffic": None,
                          "kernel": "fir", "avg_kernel_ms": round(avg_ms, 4), "launches": launches,
                          "flop_per_sample": FLOP_PER_SAMPLE, "bytes_per_sample": round(BYTES_PER_SAMPLE, 3),
+                         # the MFMA kernel folds the lerp into one effective row per phase: it EXECUTES 2*Kpad flop per
+                         # sample on the matrix cores (Kpad = 1024 columns for T = 988), half the algorithmic count
+                         "executed_mfma_TFLOPs": round(tflops * (2 * 1024) / FLOP_PER_SAMPLE, 3) if kernel_used == 2 else None,
                          "hbm_algorithmic_GBps": round(gbs, 2), "hbm_frac": round(gbs / PEAK_HBM_GBS, 5)},
         }
         if world == 1 and not args.no_cpu_baseline:

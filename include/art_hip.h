@@ -30,8 +30,9 @@ void resampleHipSynchronize (Resample *cxt);
  * 2 = MFMA periodic-phase kernel where applicable (falls back to 1 elsewhere) */
 void resampleHipSetKernel (Resample *cxt, int which);
 int  resampleHipLastKernel (Resample *cxt);          /* which kernel produced the bulk of the last call */
-/* HIP-event timing of the FIR launches only (events recorded on the context's stream around each FIR
- * launch).  Enable, run calls, then read: returns accumulated kernel milliseconds and the launch count
+unsigned int resampleHipLastHandedBack (Resample *cxt);   /* outputs the MFMA kernel has passed to the general kernel so far */
+/* HIP-event timing of the dominant FIR kernel only (events recorded on the context's stream immediately
+ * before and after that kernel's launch; the fix-up and history kernels are outside the bracket).  Enable, run calls, then read: returns accumulated kernel milliseconds and the launch count
  * since timing was (re-)enabled; the read synchronises. */
 void resampleHipSetTiming (Resample *cxt, int enable);
 double resampleHipReadTiming (Resample *cxt, int *numLaunches);
