@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libartamd.so")
+LIB_PATH = os.environ.get("ARTAMD_LIB") or os.path.join(HERE, "libartamd.so")      # ARTAMD_LIB: ablation builds only
 
 # resampler.h flags
 SUBSAMPLE_INTERPOLATE, BLACKMAN_HARRIS, INCLUDE_LOWPASS, RESAMPLE_MULTITHREADED, NO_FILTER_REDUCTION = 0x1, 0x2, 0x4, 0x8, 0x10

@@ -11,7 +11,7 @@
 extern "C" {
 #endif
 
-#define ART_MAX_SEGS 64          /* ring-epoch segments per kernel launch (passed by value) */
+#define ART_MAX_SEGS 128         /* ring-epoch segments per kernel launch (passed by value) */
 
 /* numeric modes of the FIR */
 enum { ART_MODE_FAST = 0,        /* f32 FMA accumulation, any order (default) */
@@ -47,6 +47,8 @@ typedef struct {
     /* scratch for outputs the MFMA kernel hands back to the general kernel (device memory) */
     unsigned int *fix_list, *fix_count;
     unsigned int fix_cap;
+    /* device scratch for the MFMA path: per-launch effective rows + canonical slot positions */
+    void *scratch; size_t scratch_bytes;
     /* optional HIP events recorded immediately before/after the dominant kernel's launch (host side only) */
     void *ev_start, *ev_stop;
 } ArtFirArgs;

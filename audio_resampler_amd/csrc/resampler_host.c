@@ -38,6 +38,7 @@ struct artamd_resampler {
     double period_ratio; int period_out, period_in;
     /* optional HIP-event timing of FIR launches */
     int timing; void **ev; int ev_count, ev_cap;
+    void *d_scratch; size_t scratch_cap;     /* MFMA path: effective rows + canonical positions of one launch */
     unsigned int *d_fix; size_t fix_cap;    /* [0] = counter, [1..] = output indices handed back by the MFMA kernel */
 };
 
@@ -343,7 +344,7 @@ void resampleFree (Resample *cxt)
     if (hip) {
         arthip_sync (hip->stream);
         arthip_free (hip->d_bank); arthip_free (hip->d_hist [0]); arthip_free (hip->d_hist [1]);
-        arthip_free (hip->d_in); arthip_free (hip->d_out); arthip_free (hip->d_tmp); arthip_free (hip->d_fix);
+        arthip_free (hip->d_in); arthip_free (hip->d_out); arthip_free (hip->d_tmp); arthip_free (hip->d_fix); arthip_free (hip->d_scratch);
         for (int i = 0; i < hip->ev_cap; ++i) arthip_event_destroy (hip->ev [i]);
         free (hip->ev);
         free (hip->segs);
@@ -538,6 +539,8 @@ static ResampleResult enqueue_call (Resample *cxt, const float *d_in, long in_pi
                 if (hip->d_fix) arthip_zero (hip->d_fix, 2 * sizeof (unsigned int), hip->stream);
             }
             if (hip->d_fix) { a.fix_count = hip->d_fix; a.fix_list = hip->d_fix + 2; a.fix_cap = res.output_generated; }
+            if (!hip->d_scratch) hip->d_scratch = grow (hip->d_scratch, &hip->scratch_cap, (size_t) 8 << 20);
+            a.scratch = hip->d_scratch; a.scratch_bytes = hip->d_scratch ? hip->scratch_cap : 0;
         }
 
         for (int s0 = 0; s0 < nseg; s0 += ART_MAX_SEGS) {

@@ -331,7 +331,11 @@ struct MfmaGeom {
     int ktot;                             // K columns, multiple of MF_KC
     int period_groups;
     int groups_per_xcd;                   // ceil (period_groups / 8)
-    int band_lo, band_hi;                 // K columns [band_lo, band_hi) hold every row's central taps
+    int band_lo, band_hi;
+    // per-launch tables in device scratch (written by mfma_prepare_kernel)
+    float *eff;                           // [slot_tiles*32][ktot]  blended rows, shifted to the tile's K origin, zero padded
+    int *canon_ip, *canon_fi;             // [slot_tiles*32]        canonical position of each slot (period 0 of the launch)
+    double *canon_frac;                 // K columns [band_lo, band_hi) hold every row's central taps
 };
 
 typedef unsigned int u32x4 __attribute__ ((ext_vector_type (4)));
@@ -354,18 +358,62 @@ template <> struct VecLoad<4> { static __device__ __forceinline__ void load (flo
     u32x4 v = __builtin_amdgcn_raw_buffer_load_b128 (r, (int) off, 0, 0);
     dst [0] = __uint_as_float (v.x); dst [1] = __uint_as_float (v.y); dst [2] = __uint_as_float (v.z); dst [3] = __uint_as_float (v.w); } };
 
+// One block per slot tile: canonical (ip, fi, frac) of its 32 slots from the first period of the launch,
+// and their effective rows g_i[k - shift_i] (lerp folded in, fp64, one rounding) laid out exactly as the
+// main kernel stages them: [row][ktot], zero outside the row's T taps.
+template <bool INTERP>
+__global__ __launch_bounds__ (256)
+void mfma_prepare_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
+{
+    __shared__ int s_ip [32], s_fi [32];
+    __shared__ double s_frac [32];
+    const int st = blockIdx.x, tid = threadIdx.x;
+    const int rows_valid = min (32, g.P - st * 32);
+    if (tid < 32) {
+        const Pos p = locate<INTERP> (a, segs, a.n_begin + st * 32 + min (tid, rows_valid - 1));
+        s_ip [tid] = p.ip; s_fi [tid] = p.fi; s_frac [tid] = p.frac;
+        g.canon_ip [st * 32 + tid] = p.ip; g.canon_fi [st * 32 + tid] = p.fi; g.canon_frac [st * 32 + tid] = p.frac;
+    }
+    __syncthreads ();
+    for (int e = tid; e < 32 * g.ktot; e += 256) {
+        const int row = e / g.ktot, k = e - row * g.ktot;
+        const int tap = k - (s_ip [row] - s_ip [0]);
+        float c = 0.0f;
+        if (tap >= 0 && tap < a.T) {
+            const float *h0 = a.bank + (size_t) s_fi [row] * a.T;
+            if (INTERP) {
+                const double f = s_frac [row];
+                const double left = (double) h0 [tap] * (1.0 - f);
+                const double right = (double) h0 [tap + a.T] * f;
+                c = (float)(left + right);
+            }
+            else c = h0 [tap];
+        }
+        g.eff [(size_t)(st * 32 + row) * g.ktot + k] = c;
+    }
+}
+
 // CG > 0: the stream has exactly CG channels (compile-time index math, vector loads);  CG == 0: any count.
-template <bool INTERP, int CG>
-__global__ __launch_bounds__ (MF_THREADS, 2)
+// WS (wave specialisation, needs CG > 0): the workgroup has 8 waves.  Waves 4-7 are LOADERS — they prefetch
+// chunk c+2 from global memory into registers and commit chunk c+1 (lerp folded in) to the other LDS buffer;
+// waves 0-3 are the MATRIX waves — LDS operand reads, the MFMA chain and its fp64 flush, nothing else.
+// Each SIMD hosts one wave of each kind per workgroup, so staging (VALU/VMEM/LDS-write) and matrix work
+// overlap in hardware with one barrier per chunk, instead of relying on instruction scheduling.
+template <bool INTERP, int CG, bool WS>
+__global__ __launch_bounds__ (WS ? 2 * MF_THREADS : MF_THREADS, WS ? 4 : 2)
 void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
 {
-    __shared__ __attribute__ ((aligned (16))) float As [32 * MF_LD];
-    __shared__ __attribute__ ((aligned (16))) float Bs [MF_COLS * MF_LD];
+    constexpr int THREADS = WS ? 2 * MF_THREADS : MF_THREADS;
+    constexpr int NBUF = WS ? 2 : 1;
+    __shared__ __attribute__ ((aligned (16))) float As_ [NBUF] [32 * MF_LD];
+    __shared__ __attribute__ ((aligned (16))) float Bs_ [NBUF] [MF_COLS * MF_LD];
     __shared__ unsigned char s_status [32 * MF_MAX_PPW];      // 0 ok, 1 handed back, 2 masked, 3 pass-through
     __shared__ int s_fi [32], s_shift [32], s_ip [32];
     __shared__ double s_frac [32];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool loader = WS && wave >= 4;
+    const int pt = WS ? (tid & (MF_THREADS - 1)) : tid;        // staging thread index (loaders, or everybody)
     // XCD-aware tile mapping.  Workgroup b is dispatched to XCD b % 8, each with a private 4 MiB L2.  The
     // slot tiles of one period group read the same input span and consecutive period groups overlap, so
     // XCD x takes the contiguous period groups [x*gpx, (x+1)*gpx) and all their slot tiles: its L2 then
@@ -383,17 +431,19 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
     const unsigned int n_tile = a.n_begin + (unsigned int)(jg * ppw) * g.P + r0;       // slot 0, first period
     if (n_tile >= a.n_end) return;
 
-    // ---- canonical (ip, fi, frac) of the 32 slots from the first period of this workgroup
+    // ---- canonical (ip, fi, frac) of the 32 slots: period 0 of the launch (mfma_prepare_kernel), moved to
+    // this workgroup's first period
+    const int j_first = jg * ppw;
     if (tid < 32) {
-        const Pos p = locate<INTERP> (a, segs, n_tile + min (tid, rows_valid - 1));
-        s_ip [tid] = p.ip; s_fi [tid] = p.fi; s_frac [tid] = p.frac;
+        s_ip [tid] = g.canon_ip [st * 32 + tid] + j_first * g.Q;
+        s_fi [tid] = g.canon_fi [st * 32 + tid]; s_frac [tid] = g.canon_frac [st * 32 + tid];
     }
     __syncthreads ();
     const int w0 = s_ip [0] - half + 1;                      // linear index of K column 0 (first period)
     if (tid < 32) s_shift [tid] = s_ip [tid] - s_ip [0];
 
     // ---- exact position of every (slot, period) of the tile, checked against the canonical pattern
-    for (int e = tid; e < 32 * ppw; e += MF_THREADS) {
+    for (int e = tid; e < 32 * ppw; e += THREADS) {
         const int i = e & 31, jl = e >> 5;
         const unsigned int n = n_tile + (unsigned int) jl * g.P + i;
         unsigned char status = 2;
@@ -418,16 +468,14 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
     __syncthreads ();
 
     // ---- staging plan.  All loads are raw buffer loads; everything out of range reads as 0.
-    const __amdgpu_buffer_rsrc_t rs_bank = make_rsrc (a.bank, (unsigned int)((size_t)(a.F + 1) * a.T * 4));
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc (a.in, (unsigned int)((size_t) a.in_frames * a.C * 4));
     const __amdgpu_buffer_rsrc_t rs_hist = make_rsrc (a.hist, (unsigned int)((size_t) a.H * a.C * 4));
     const bool touches_hist = w0 < a.H;                      // only the first period group of a call
 
-    // A: thread -> (row, 4 consecutive k)
-    const int a_row = tid >> 3, a_kseg = (tid & 7) * 4;
-    const int a_tap0 = a_kseg - s_shift [a_row];             // tap index of this thread's first k at chunk 0
-    const unsigned int a_rowoff = (unsigned int) s_fi [a_row] * (unsigned int) a.T;
-    const double a_frac = s_frac [a_row];
+    // A: thread -> (row, 4 consecutive k) of the prepared effective rows: one aligned dwordx4 per chunk
+    const int a_row = pt >> 3, a_kseg = (pt & 7) * 4;
+    const __amdgpu_buffer_rsrc_t rs_eff = make_rsrc (g.eff + (size_t) st * 32 * g.ktot, (unsigned int)((size_t) 32 * g.ktot * 4));
+    const unsigned int a_off0 = (unsigned int)(a_row * g.ktot + a_kseg) * 4u;
 
     // B: thread -> NB vectors of VEC channels of one frame of one period
     constexpr int VEC = CG >= 4 ? 4 : (CG == 2 ? 2 : 1);
@@ -436,22 +484,16 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
     constexpr int PPW_C = CG ? (MF_COLS / CG > MF_MAX_PPW ? MF_MAX_PPW : MF_COLS / CG) : 1;
     constexpr int NB = CG ? (PPW_C * VPP) / MF_THREADS : 1;
 
-    float ra0 [4], ra1 [4];
+    float ra [4];
     float rb [NB * VEC];
 
     auto fetch = [&] (int chunk) {
         const int k0 = chunk * MF_KC;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int tap = a_tap0 + k0 + q;
-            const unsigned int off = ((unsigned int) tap < (unsigned int) a.T) ? (a_rowoff + (unsigned int) tap) * 4u : 0xffffff00u;
-            VecLoad<1>::load (&ra0 [q], rs_bank, off);
-            if (INTERP) VecLoad<1>::load (&ra1 [q], rs_bank, off == 0xffffff00u ? off : off + (unsigned int) a.T * 4u);
-        }
+        VecLoad<4>::load (ra, rs_eff, a_off0 + (unsigned int) k0 * 4u);      // past ktot: out of range => 0
         if (CG) {
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
-                const int v = tid + u * MF_THREADS;
+                const int v = pt + u * MF_THREADS;
                 const int jl = v / VPP, rem = v % VPP, kk = rem / VPF, cv = rem % VPF;
                 const int lin = w0 + jl * g.Q + k0 + kk;
                 const unsigned int oi = (unsigned int)((lin - a.H) * CG + cv * VEC) * 4u;      // wraps (=> 0) below H
@@ -466,23 +508,16 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
         }
     };
 
-    auto commit = [&] (int chunk) {
+    auto commit = [&] (int chunk, int buf) {
+        float *As = As_ [buf], *Bs = Bs_ [buf];
         f32x4 v;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (INTERP) {
-                const double left = (double) ra0 [q] * (1.0 - a_frac);
-                const double right = (double) ra1 [q] * a_frac;
-                v [q] = (float)(left + right);
-            }
-            else v [q] = ra0 [q];
-        }
+        v [0] = ra [0]; v [1] = ra [1]; v [2] = ra [2]; v [3] = ra [3];
         *reinterpret_cast<f32x4 *> (&As [a_row * MF_LD + a_kseg]) = v;
 
         if (CG) {
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
-                const int vi = tid + u * MF_THREADS;
+                const int vi = pt + u * MF_THREADS;
                 const int jl = vi / VPP, rem = vi % VPP, kk = rem / VPF, cv = rem % VPF;
 #pragma unroll
                 for (int e = 0; e < VEC; ++e)
@@ -509,7 +544,8 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
 
     const int ncols = ppw * cg;
     if (ncols < MF_COLS)                                     // unused columns stay zero for the whole kernel
-        for (int e = tid; e < (MF_COLS - ncols) * MF_LD; e += MF_THREADS) Bs [ncols * MF_LD + e] = 0.0f;
+        for (int e = tid; e < (MF_COLS - ncols) * MF_LD; e += THREADS)
+            for (int b = 0; b < NBUF; ++b) Bs_ [b] [ncols * MF_LD + e] = 0.0f;
 
     double sum [16];
 #pragma unroll
@@ -519,16 +555,11 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
     const int arow = (lane & 31) * MF_LD + 4 * (lane >> 5);
     const int brow = (wave * 32 + (lane & 31)) * MF_LD + 4 * (lane >> 5);
 
-    fetch (0);
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
+    // one chunk of matrix work on LDS buffer `buf`: 32 k's = 4 groups of 8; lanes 0-31 take k 0-3 of a
+    // group, lanes 32-63 k 4-7
+    auto matrix_chunk = [&] (int chunk, int buf) {
+        const float *As = As_ [buf], *Bs = Bs_ [buf];
         const int k0 = chunk * MF_KC;
-
-        __syncthreads ();                                    // previous chunk fully consumed
-        commit (chunk);
-        __syncthreads ();
-        if (chunk + 1 < nchunks) fetch (chunk + 1);          // global loads fly while the matrix cores work
-
-        // ---- 32 k's = 4 groups of 8; lanes 0-31 take k 0-3 of a group, lanes 32-63 k 4-7
         const bool band = k0 < g.band_hi && k0 + MF_KC > g.band_lo;
         if (!band) {
             f32x16 acc;
@@ -539,11 +570,22 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
                 const f32x4 av = *reinterpret_cast<const f32x4 *> (&As [arow + grp * 8]);
                 const f32x4 bv = *reinterpret_cast<const f32x4 *> (&Bs [brow + grp * 8]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < 4; ++q) {
+#ifndef ABL_NOMFMA
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [q], bv [q], acc, 0, 0, 0);
+#else
+                    acc [q] += av [q] * bv [q];
+#endif
+                }
             }
+#ifndef ABL_NOFLUSH
 #pragma unroll
             for (int r = 0; r < 16; ++r) sum [r] = sum [r] + (double) acc [r];
+#else
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile ("" :: "v" (acc [r]));
+            sum [0] = sum [0] + (double) acc [0];
+#endif
         }
         else {
 #pragma unroll
@@ -561,6 +603,38 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
                     for (int r = 0; r < 16; ++r) sum [r] = sum [r] + (double) acc [r];
                 }
             }
+        }
+    };
+
+    if (WS) {
+        // two separate loops (disjoint live ranges => registers = max of the two roles, not the sum);
+        // both execute exactly nchunks + 1 barriers
+        if (loader) {
+            fetch (0); commit (0, 0); fetch (1);
+            __syncthreads ();
+            for (int chunk = 0; chunk < nchunks; ++chunk) {
+#ifndef ABL_NOLOAD
+                commit (chunk + 1, (chunk & 1) ^ 1);         // past-the-end chunks: loads return 0 / LDS unread
+                fetch (chunk + 2);
+#endif
+                __syncthreads ();
+            }
+            return;
+        }
+        __syncthreads ();
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            matrix_chunk (chunk, chunk & 1);
+            __syncthreads ();
+        }
+    }
+    else {
+        fetch (0);
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            __syncthreads ();                                // previous chunk fully consumed
+            commit (chunk, 0);
+            __syncthreads ();
+            if (chunk + 1 < nchunks) fetch (chunk + 1);      // global loads fly while the matrix cores work
+            matrix_chunk (chunk, 0);
         }
     }
 
@@ -665,9 +739,9 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
     // MFMA path: exact rational ratio, default numeric mode, interleaved buffers, no history floor, and at
     // least a few periods of work (below that the tile is mostly padding and the general kernel wins)
     const unsigned int total = a->n_end - a->n_begin;
-    const bool mfma_ok = a->mode == ART_MODE_FAST && a->period_out > 0 && a->fix_list && a->in_pitch == 0 && a->out_pitch == 0 &&
+    const bool mfma_ok = a->mode == ART_MODE_FAST && a->period_out > 0 && a->fix_list && a->scratch && a->in_pitch == 0 && a->out_pitch == 0 &&
                          segs->lin_floor == INT_MIN && kernel_pref != ART_KERNEL_GENERAL &&
-                         (total >= 4u * (unsigned int) a->period_out || kernel_pref == ART_KERNEL_MFMA) && total >= (unsigned int) a->period_out;
+                         (total >= 4u * (unsigned int) a->period_out || kernel_pref >= ART_KERNEL_MFMA) && total >= (unsigned int) a->period_out;
 
     if (mfma_ok) {
         MfmaGeom g;
@@ -683,15 +757,28 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
         const unsigned int periods = (total + g.P - 1) / g.P;
         g.period_groups = (int)((periods + g.ppw - 1) / g.ppw);
         g.groups_per_xcd = (g.period_groups + 7) / 8;
+        {   // carve the per-launch tables out of the scratch buffer
+            const size_t rows = (size_t) g.slot_tiles * 32, eff_bytes = rows * g.ktot * sizeof (float);
+            char *base = (char *) a->scratch;
+            g.eff = (float *) base;
+            g.canon_frac = (double *)(base + ((eff_bytes + 15) & ~(size_t) 15));
+            g.canon_ip = (int *)(g.canon_frac + rows);
+            g.canon_fi = g.canon_ip + rows;
+            if (!base || (size_t)((char *)(g.canon_fi + rows) - base) > a->scratch_bytes) goto general_path;
+        }
         dim3 grid ((unsigned int)(8 * g.groups_per_xcd * g.slot_tiles), (unsigned int)((a->C + g.cg - 1) / g.cg));
 
         if (hipMemsetAsync (a->fix_count, 0, sizeof (unsigned int), st) != hipSuccess) return -1;
+        if (a->interpolate) hipLaunchKernelGGL (mfma_prepare_kernel<true>, dim3 (g.slot_tiles), dim3 (256), 0, st, *a, *segs, g);
+        else hipLaunchKernelGGL (mfma_prepare_kernel<false>, dim3 (g.slot_tiles), dim3 (256), 0, st, *a, *segs, g);
         if (a->ev_start) arthip_event_record (a->ev_start, stream);
         // compile-time channel count where the whole stream is one column group and the buffers allow
         // vector loads; otherwise the generic instantiation
         const bool small = (size_t) a->in_frames * a->C * 4 < 0xffff0000ull && ((uintptr_t) a->in % 16) == 0 && ((uintptr_t) a->hist % 16) == 0;
         const int cgt = (small && (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8)) ? a->C : 0;
-#define MF_GO(I, CGT) hipLaunchKernelGGL ((fir_mfma_kernel<I, CGT>), grid, dim3 (MF_THREADS), 0, st, *a, *segs, g)
+        const bool ws = kernel_pref != 3;                    // kernel_pref 3 = the non-specialised variant (ablation)
+#define MF_GO(I, CGT) do { if (ws && CGT) hipLaunchKernelGGL ((fir_mfma_kernel<I, CGT, (CGT != 0)>), grid, dim3 (2 * MF_THREADS), 0, st, *a, *segs, g); \
+                           else hipLaunchKernelGGL ((fir_mfma_kernel<I, CGT, false>), grid, dim3 (MF_THREADS), 0, st, *a, *segs, g); } while (0)
         if (a->interpolate) switch (cgt) { case 8: MF_GO (true, 8); break; case 4: MF_GO (true, 4); break; case 2: MF_GO (true, 2); break;
                                             case 1: MF_GO (true, 1); break; default: MF_GO (true, 0); }
         else                switch (cgt) { case 8: MF_GO (false, 8); break; case 4: MF_GO (false, 4); break; case 2: MF_GO (false, 2); break;
@@ -703,6 +790,7 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
         return hipGetLastError () == hipSuccess ? ART_KERNEL_MFMA : -1;
     }
 
+general_path:
     if (a->ev_start) arthip_event_record (a->ev_start, stream);
     if (run_general (*a, *segs, st, 0)) return -1;
     if (a->ev_stop) arthip_event_record (a->ev_stop, stream);
