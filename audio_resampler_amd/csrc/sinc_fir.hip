@@ -358,38 +358,36 @@ template <> struct VecLoad<4> { static __device__ __forceinline__ void load (flo
     u32x4 v = __builtin_amdgcn_raw_buffer_load_b128 (r, (int) off, 0, 0);
     dst [0] = __uint_as_float (v.x); dst [1] = __uint_as_float (v.y); dst [2] = __uint_as_float (v.z); dst [3] = __uint_as_float (v.w); } };
 
-// One block per slot tile: canonical (ip, fi, frac) of its 32 slots from the first period of the launch,
-// and their effective rows g_i[k - shift_i] (lerp folded in, fp64, one rounding) laid out exactly as the
-// main kernel stages them: [row][ktot], zero outside the row's T taps.
+// Grid (slot tile, row): canonical (ip, fi, frac) of the slot from the first period of the launch, and its
+// effective row g_i[k - shift_i] (lerp folded in, fp64, one rounding) laid out exactly as the main kernel
+// stages it: [row][ktot], zero outside the row's T taps.
 template <bool INTERP>
 __global__ __launch_bounds__ (256)
 void mfma_prepare_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
 {
-    __shared__ int s_ip [32], s_fi [32];
-    __shared__ double s_frac [32];
-    const int st = blockIdx.x, tid = threadIdx.x;
+    const int st = blockIdx.x, row = blockIdx.y, tid = threadIdx.x;
     const int rows_valid = min (32, g.P - st * 32);
-    if (tid < 32) {
-        const Pos p = locate<INTERP> (a, segs, a.n_begin + st * 32 + min (tid, rows_valid - 1));
-        s_ip [tid] = p.ip; s_fi [tid] = p.fi; s_frac [tid] = p.frac;
-        g.canon_ip [st * 32 + tid] = p.ip; g.canon_fi [st * 32 + tid] = p.fi; g.canon_frac [st * 32 + tid] = p.frac;
+    // every thread derives the two positions it needs (uniform, a few dozen fp64 ops)
+    const Pos p0 = locate<INTERP> (a, segs, a.n_begin + st * 32);
+    const Pos p = locate<INTERP> (a, segs, a.n_begin + st * 32 + min (row, rows_valid - 1));
+    if (tid == 0) {
+        g.canon_ip [st * 32 + row] = p.ip; g.canon_fi [st * 32 + row] = p.fi; g.canon_frac [st * 32 + row] = p.frac;
     }
-    __syncthreads ();
-    for (int e = tid; e < 32 * g.ktot; e += 256) {
-        const int row = e / g.ktot, k = e - row * g.ktot;
-        const int tap = k - (s_ip [row] - s_ip [0]);
+    const float *h0 = a.bank + (size_t) p.fi * a.T;
+    const int shift = p.ip - p0.ip;
+    float *dst = g.eff + (size_t)(st * 32 + row) * g.ktot;
+    for (int k = tid; k < g.ktot; k += 256) {
+        const int tap = k - shift;
         float c = 0.0f;
         if (tap >= 0 && tap < a.T) {
-            const float *h0 = a.bank + (size_t) s_fi [row] * a.T;
             if (INTERP) {
-                const double f = s_frac [row];
-                const double left = (double) h0 [tap] * (1.0 - f);
-                const double right = (double) h0 [tap + a.T] * f;
+                const double left = (double) h0 [tap] * (1.0 - p.frac);
+                const double right = (double) h0 [tap + a.T] * p.frac;
                 c = (float)(left + right);
             }
             else c = h0 [tap];
         }
-        g.eff [(size_t)(st * 32 + row) * g.ktot + k] = c;
+        dst [k] = c;
     }
 }
 
@@ -769,8 +767,8 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
         dim3 grid ((unsigned int)(8 * g.groups_per_xcd * g.slot_tiles), (unsigned int)((a->C + g.cg - 1) / g.cg));
 
         if (hipMemsetAsync (a->fix_count, 0, sizeof (unsigned int), st) != hipSuccess) return -1;
-        if (a->interpolate) hipLaunchKernelGGL (mfma_prepare_kernel<true>, dim3 (g.slot_tiles), dim3 (256), 0, st, *a, *segs, g);
-        else hipLaunchKernelGGL (mfma_prepare_kernel<false>, dim3 (g.slot_tiles), dim3 (256), 0, st, *a, *segs, g);
+        if (a->interpolate) hipLaunchKernelGGL (mfma_prepare_kernel<true>, dim3 (g.slot_tiles, 32), dim3 (256), 0, st, *a, *segs, g);
+        else hipLaunchKernelGGL (mfma_prepare_kernel<false>, dim3 (g.slot_tiles, 32), dim3 (256), 0, st, *a, *segs, g);
         if (a->ev_start) arthip_event_record (a->ev_start, stream);
         // compile-time channel count where the whole stream is one column group and the buffers allow
         // vector loads; otherwise the generic instantiation
