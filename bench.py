@@ -156,6 +156,17 @@ def main():
         avg_ms = kernel_ms / max(launches, 1)
         tflops = per_launch_samples * FLOP_PER_SAMPLE / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         gbs = per_launch_samples * BYTES_PER_SAMPLE / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM traffic of the dominant kernel is a PMC measurement (tools/pmc.sh: separate rocprofv3 --pmc passes, FETCH_SIZE
+        # with the gfx950 wide-read correction + WRITE_SIZE); it cannot be taken inside this process, so the committed
+        # per-launch figure is reported when — and only when — this run is the workload it was measured on.
+        traffic = None
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+            w = tr["workload"]
+            if kernel_used == 2 and (w["block_frames"], w["channels"], w["taps"]) == (block, Cn, TAPS) and launches == args.steps:
+                traffic = tr["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         line = {
             "metric": "Msamples/s (out) 44.1k->48k preset -4, 8ch float32",
             "value": round(samples_total / dt_max / 1e6, 2),
@@ -171,12 +182,17 @@ def main():
                        "fir_kernel": {1: "general", 2: "mfma"}.get(kernel_used, str(kernel_used)),
                        "parallelism": f"channel-shard x{world}, no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": round(tflops, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(tflops / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                         "frac": round(tflops / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "bytes/launch (HBM, PMC)", "algorithmic_bytes_per_launch": int(per_launch_samples * BYTES_PER_SAMPLE),
                          "kernel": "fir", "avg_kernel_ms": round(avg_ms, 4), "launches": launches,
                          "flop_per_sample": FLOP_PER_SAMPLE, "bytes_per_sample": round(BYTES_PER_SAMPLE, 3),
                          # the MFMA kernel folds the lerp into one effective row per phase: it EXECUTES 2*Kpad flop per
                          # sample on the matrix cores (Kpad = 1024 columns for T = 988), half the algorithmic count
                          "executed_mfma_TFLOPs": round(tflops * (2 * 1024) / FLOP_PER_SAMPLE, 3) if kernel_used == 2 else None,
+                         "executed_frac": round(tflops * (2 * 1024) / FLOP_PER_SAMPLE / PEAK_FP32_TFLOPS, 4) if kernel_used == 2 else None,
+                         "note": "achieved/frac use the ALGORITHMIC 4T+3 flop per sample of the reference formulation (SURVEY 8d); the kernel "
+                                 "blends the two interpolation rows once per phase (lerp is linear), so frac can exceed 1 while the matrix "
+                                 "cores run at executed_frac of their f32 peak",
                          "hbm_algorithmic_GBps": round(gbs, 2), "hbm_frac": round(gbs / PEAK_HBM_GBS, 5)},
         }
         if world == 1 and not args.no_cpu_baseline:
