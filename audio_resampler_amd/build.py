@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(os.path.dirname(HERE), "include")
 OUT = os.path.join(HERE, "libartamd.so")
 
-C_SOURCES = ["resampler_host.c", "pcm_host.c"]
+C_SOURCES = ["resampler_host.c", "pcm_host.c", "extrapolate_host.c"]
 HIP_SOURCES = ["device_rt.hip", "sinc_fir.hip", "pcm_kernels.hip"]
 HEADERS = [os.path.join(CSRC, "art_internal.h")] + [os.path.join(INC, h) for h in ("art_hip.h", "resampler.h", "biquad.h", "decimator.h")]
 

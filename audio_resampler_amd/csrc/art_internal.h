@@ -76,6 +76,10 @@ int arthip_roll_history (float *new_hist, const float *hist, const float *in, lo
 int arthip_interleave (float *dst, const float *src_planar, long pitch, int frames, int C, void *stream);
 int arthip_deinterleave (float *dst_planar, long pitch, const float *src, int frames, int C, void *stream);
 
+/* ---- extrapolate_host.c (host, scalar) ---- */
+void art_extrapolate_forward (float *x, int count, int extra);
+void art_extrapolate_backward (const float *known_newest_last, int count, float *older_nearest_first, int extra);
+
 /* ---- pcm_kernels.hip ---- */
 typedef struct {
     int C, bits, bytes, dither_type, dither_on, shaping_on;

@@ -38,6 +38,7 @@ struct artamd_resampler {
     double period_ratio; int period_out, period_in;
     /* optional HIP-event timing of FIR launches */
     int timing; void **ev; int ev_count, ev_cap;
+    float *d_patch; size_t patch_cap;        /* end-point extrapolation: samples computed on the host */
     void *d_scratch; size_t scratch_cap;     /* MFMA path: effective rows + canonical positions of one launch */
     unsigned int *d_fix; size_t fix_cap;    /* [0] = counter, [1..] = output indices handed back by the MFMA kernel */
 };
@@ -344,7 +345,7 @@ void resampleFree (Resample *cxt)
     if (hip) {
         arthip_sync (hip->stream);
         arthip_free (hip->d_bank); arthip_free (hip->d_hist [0]); arthip_free (hip->d_hist [1]);
-        arthip_free (hip->d_in); arthip_free (hip->d_out); arthip_free (hip->d_tmp); arthip_free (hip->d_fix); arthip_free (hip->d_scratch);
+        arthip_free (hip->d_in); arthip_free (hip->d_out); arthip_free (hip->d_tmp); arthip_free (hip->d_fix); arthip_free (hip->d_scratch); arthip_free (hip->d_patch);
         for (int i = 0; i < hip->ev_cap; ++i) arthip_event_destroy (hip->ev [i]);
         free (hip->ev);
         free (hip->segs);
@@ -486,6 +487,97 @@ unsigned int resampleHipLastHandedBack (Resample *cxt)
     return n;
 }
 
+
+/* ------------------------------------------------------------------------------------------
+ * End-point extrapolation (EXTRAPOLATE_ENDPOINTS; reference resampler.c:677-680, :691-698, :812-819).
+ * The LPC fit is scalar host work on a few hundred samples, at most twice per stream; the samples it
+ * produces are written into HBM and consumed by the kernels like ordinary history / input.
+ * ---------------------------------------------------------------------------------------- */
+
+/* fetch `count` frames starting at linear index `lin` of (history ++ input) into planes[c][0..count) */
+static void gather_linear (Resample *cxt, const float *d_in, long in_pitch, int lin, int count, float *planes)
+{
+    struct artamd_resampler *hip = cxt->hip;
+    const int C = cxt->numChannels, H = HIST_FRAMES (cxt->numTaps);
+    float *tmp = malloc (sizeof (float) * (size_t) count * C);
+    const int from_hist = lin < H ? (H - lin < count ? H - lin : count) : 0;
+
+    if (from_hist)
+        arthip_d2h (tmp, hip->d_hist [hip->cur] + (size_t) lin * C, sizeof (float) * (size_t) from_hist * C, hip->stream);
+    if (count > from_hist) {
+        const int first = lin + from_hist - H, n = count - from_hist;
+        if (in_pitch)
+            for (int c = 0; c < C; ++c)      /* planar: land directly in the plane */
+                arthip_d2h (planes + (size_t) c * count + from_hist, d_in + (size_t) c * in_pitch + first, sizeof (float) * (size_t) n, hip->stream);
+        else
+            arthip_d2h (tmp + (size_t) from_hist * C, d_in + (size_t) first * C, sizeof (float) * (size_t) n * C, hip->stream);
+    }
+    arthip_sync (hip->stream);
+
+    const int inter = in_pitch ? from_hist : count;     /* frames that arrived interleaved in tmp */
+    for (int f = 0; f < inter; ++f)
+        for (int c = 0; c < C; ++c)
+            planes [(size_t) c * count + f] = tmp [(size_t) f * C + c];
+    free (tmp);
+}
+
+/* Backward extrapolation into the silent pre-history, just before the first output of a stream. */
+static void prefill_history (Resample *cxt, const float *d_in, long in_pitch)
+{
+    struct artamd_resampler *hip = cxt->hip;
+    const int T = cxt->numTaps, C = cxt->numChannels, H = HIST_FRAMES (T), half = T / 2;
+    long first_emit = (long) floor (cxt->outputOffset) + half + 1;     /* inputIndex when output 0 becomes possible */
+    if (first_emit < cxt->inputIndex) first_emit = cxt->inputIndex;
+    const int known = (int)(first_emit - T), extra = T - known;
+
+    if (known < 8 || extra <= 0) return;                                /* reference resampler.c:695 / :815 */
+
+    const int lin_known = T + H - cxt->inputIndex;                      /* ring index T in linear terms */
+    float *planes = malloc (sizeof (float) * (size_t) known * C);
+    float *older = malloc (sizeof (float) * (size_t) extra);
+    float *patch = malloc (sizeof (float) * (size_t) extra * C);
+
+    gather_linear (cxt, d_in, in_pitch, lin_known, known, planes);
+
+    for (int c = 0; c < C; ++c) {
+        art_extrapolate_backward (planes + (size_t) c * known, known, older, extra);
+        for (int e = 0; e < extra; ++e)                                 /* older[e] is ring index T-1-e */
+            patch [(size_t)(extra - 1 - e) * C + c] = older [e];
+    }
+
+    /* ring [known, T) = linear [lin_known - extra, lin_known): inside the history buffer by construction */
+    arthip_h2d (hip->d_hist [hip->cur] + (size_t)(lin_known - extra) * C, patch, sizeof (float) * (size_t) extra * C, hip->stream);
+    arthip_sync (hip->stream);
+    free (planes); free (older); free (patch);
+}
+
+/* Forward extrapolation of half a window at flush time; returns a device buffer of T/2 frames x C. */
+static const float *flush_tail (Resample *cxt)
+{
+    struct artamd_resampler *hip = cxt->hip;
+    const int T = cxt->numTaps, C = cxt->numChannels, H = HIST_FRAMES (T), half = T / 2;
+    float *planes = malloc (sizeof (float) * (size_t) half * C);
+    float *work = malloc (sizeof (float) * (size_t) T);
+    float *patch = malloc (sizeof (float) * (size_t) half * C);
+
+    gather_linear (cxt, NULL, 0, H - half, half, planes);
+
+    for (int c = 0; c < C; ++c) {
+        memcpy (work, planes + (size_t) c * half, sizeof (float) * (size_t) half);
+        art_extrapolate_forward (work, half, half);
+        for (int f = 0; f < half; ++f)
+            patch [(size_t) f * C + c] = work [half + f];
+    }
+
+    hip->d_patch = grow (hip->d_patch, &hip->patch_cap, sizeof (float) * (size_t) half * C);
+    if (hip->d_patch) {
+        arthip_h2d (hip->d_patch, patch, sizeof (float) * (size_t) half * C, hip->stream);
+        arthip_sync (hip->stream);
+    }
+    free (planes); free (work); free (patch);
+    return hip->d_patch;
+}
+
 /* Plan one call, enqueue the FIR launches and the history roll.  `d_in` holds the call's input on
  * the device (interleaved, or planar with `in_pitch`); `d_out` receives the output likewise. */
 static ResampleResult enqueue_call (Resample *cxt, const float *d_in, long in_pitch, int nIn,
@@ -517,12 +609,24 @@ static ResampleResult enqueue_call (Resample *cxt, const float *d_in, long in_pi
     }
 
     const int appended = is_flush ? T / 2 : (int) res.input_used;
+    const float *flush_in = NULL;
+
+    if (cxt->flags & EXTRAPOLATE_ENDPOINTS) {
+        /* prefill: first output of the stream, produced by an ordinary call whose first output precedes any
+         * ring rewind (streams that emit nothing until a flush, or only after 15*T frames, start from silence) */
+        if ((cxt->flags & EXTRAPOLATE_PREFILL) && res.output_generated && !(nIn < 0) &&
+            (nseg == 1 || hip->segs [1].first_output > 0))
+            prefill_history (cxt, d_in, in_pitch);
+        if (is_flush)
+            flush_in = flush_tail (cxt);
+    }
 
     if (res.output_generated) {
         ArtFirArgs a;
         memset (&a, 0, sizeof (a));
         a.bank = hip->d_bank; a.hist = hip->d_hist [hip->cur];
-        a.in = is_flush ? NULL : d_in; a.in_pitch = in_pitch; a.in_frames = is_flush ? 0 : (int) res.input_used;
+        a.in = is_flush ? flush_in : d_in; a.in_pitch = is_flush ? 0 : in_pitch;
+        a.in_frames = is_flush ? (flush_in ? T / 2 : 0) : (int) res.input_used;
         a.out = d_out; a.out_pitch = out_pitch;
         a.C = C; a.T = T; a.F = cxt->numFilters; a.H = H;
         a.interpolate = (cxt->flags & SUBSAMPLE_INTERPOLATE) != 0;
@@ -566,7 +670,7 @@ static ResampleResult enqueue_call (Resample *cxt, const float *d_in, long in_pi
     }
 
     if (appended > 0) {
-        arthip_roll_history (hip->d_hist [hip->cur ^ 1], hip->d_hist [hip->cur], is_flush ? NULL : d_in, in_pitch, appended, H, C, hip->stream);
+        arthip_roll_history (hip->d_hist [hip->cur ^ 1], hip->d_hist [hip->cur], is_flush ? flush_in : d_in, is_flush ? 0 : in_pitch, appended, H, C, hip->stream);
         hip->cur ^= 1;
     }
 

@@ -33,7 +33,7 @@ typedef float artsample_t;
 #define RESAMPLE_MULTITHREADED  0x8      /* accepted, no effect: channels are already parallel on the GPU */
 #define NO_FILTER_REDUCTION     0x10
 #define RESAMPLE_FIXED_RATIO    0x20     /* internal */
-#define EXTRAPOLATE_ENDPOINTS   0x40     /* accepted; end-point LPC extrapolation runs on the host */
+#define EXTRAPOLATE_ENDPOINTS   0x40     /* end-point LPC extrapolation (fit on the host, samples consumed on the GPU) */
 #define EXTRAPOLATE_PREFILL     0x80     /* internal */
 #define EXTEND_CONVOLUTION_MATH 0x100    /* fp64 accumulation in the FIR */
 #define RESAMPLER_FLUSHED       0x200    /* internal */

@@ -284,6 +284,112 @@ static double evaluate_at (const OraResampler *r, const float *ring, double pos)
     }
 }
 
+
+/* ------------------------------------------------------------------------------------------
+ * End-point extrapolation  (extrapolator.c:22-277): 4-tap LPC by coordinate descent, PARCOR clamp
+ * ---------------------------------------------------------------------------------------- */
+#define LPC_N 4
+
+static void lpc_to_refl (const double *lpc, double *k)
+{
+    double t [LPC_N], u [LPC_N];
+    for (int i = 0; i < LPC_N; ++i) t [i] = lpc [i];
+    for (int m = LPC_N - 1; m >= 0; --m) {
+        k [m] = t [m];
+        double den = 1.0 - (k [m] * k [m]);
+        if (fabs (den) < 1e-6) { k [m] = k [m] < 0.0 ? -0.9999995 : 0.9999995; den = 1.0 - (k [m] * k [m]); }
+        for (int i = 0; i < m; ++i) u [i] = (t [i] - k [m] * t [m - i - 1]) / den;
+        for (int i = 0; i < m; ++i) t [i] = u [i];
+    }
+}
+
+static void refl_to_lpc (const double *k, double *lpc)
+{
+    for (int i = 0; i < LPC_N; i++) {
+        lpc [i] = k [i];
+        for (int j = 0; j < i / 2; j++) { double t = lpc [j]; lpc [j] += k [i] * lpc [i - 1 - j]; lpc [i - 1 - j] += k [i] * t; }
+        if (i & 1) lpc [i >> 1] += lpc [i >> 1] * k [i];
+    }
+}
+
+static void lpc_fit (const float *v, int n, float *co)
+{
+    int ne = n - LPC_N, loops = 0, changes = 0;
+    double vrms = 0.0, drms = 0.0, err, step = 3.0 / (1 << 4);
+    double *sums = malloc (sizeof (double) * (ne > 0 ? ne : 1));
+
+    for (int i = 0; i < LPC_N; ++i) co [i] = 0.0f;
+    for (int i = 0; i < ne; ++i) {
+        drms += (v [i + LPC_N] - v [i + LPC_N - 1]) * (v [i + LPC_N] - v [i + LPC_N - 1]);
+        vrms += v [i + LPC_N] * v [i + LPC_N];
+    }
+    if (vrms == 0.0) { free (sums); return; }
+    err = vrms;
+
+    while (err > 0.0 && loops < 100000) {
+        int tc;
+        for (int k = 0; k < ne; ++k) {
+            double z = 0.0;
+            for (int c = 0; c < LPC_N; ++c) z += co [LPC_N - c - 1] * v [k + c];
+            sums [k] = z + v [k + LPC_N];
+        }
+        for (tc = 0; loops++, tc < LPC_N; tc++) {
+            double lo = 0.0, hi = 0.0;
+            for (int k = 0; k < ne; ++k) {
+                double d = v [k + LPC_N - tc - 1] * step;
+                lo += (sums [k] - d) * (sums [k] - d);
+                hi += (sums [k] + d) * (sums [k] + d);
+            }
+            if (lo < err || hi < err) {
+                if (lo < hi) { err = lo; co [tc] -= step; } else { err = hi; co [tc] += step; }
+                changes++;
+                break;
+            }
+        }
+        if (tc == LPC_N) { if (step > 3.0 / (1 << 22)) step *= 0.5; else break; }
+    }
+    free (sums);
+
+    if (changes) {
+        double d [LPC_N], k [LPC_N];
+        int out = 0;
+        for (int i = 0; i < LPC_N; ++i) d [i] = co [i];
+        lpc_to_refl (d, k);
+        for (int i = 0; i < LPC_N; ++i) if (fabs (k [i]) > 0.9999) { k [i] = k [i] < 0.0 ? -0.9999 : 0.9999; out++; }
+        if (out) { refl_to_lpc (k, d); for (int i = 0; i < LPC_N; ++i) co [i] = d [i]; }
+    }
+
+    err = 0.0;
+    for (int k = 0; k < ne; ++k) {
+        double z = 0.0;
+        for (int c = 0; c < LPC_N; ++c) z += co [LPC_N - c - 1] * v [k + c];
+        err += (z + v [k + LPC_N]) * (z + v [k + LPC_N]);
+    }
+    if (drms < err && drms < vrms) { for (int i = 0; i < LPC_N; ++i) co [i] = 0.0f; co [0] = -1.0; }
+    else if (vrms <= err) for (int i = 0; i < LPC_N; ++i) co [i] = 0.0f;
+}
+
+static void lpc_forward (float *v, int n, int extra)
+{
+    float co [LPC_N];
+    memset (v + n, 0, sizeof (float) * extra);
+    lpc_fit (v, n, co);
+    for (int i = 0; i < extra; ++i) {
+        double z = 0.0;
+        for (int c = 0; c < LPC_N; ++c) z += v [n - LPC_N + i + c] * co [LPC_N - c - 1];
+        v [n + i] = -z;
+    }
+}
+
+static void lpc_reverse (float *past_end, int n, int extra)      /* past_end[-1] is the newest known sample */
+{
+    float *r = calloc (n + extra, sizeof (float));
+    for (int i = 0; i < n; ++i) r [i] = past_end [-1 - i];
+    lpc_forward (r, n, extra);
+    for (int i = n; i < n + extra; ++i) past_end [-1 - i] = r [i];
+    free (r);
+}
+
 /* ------------------------------------------------------------------------------------------
  * Streaming state machine  (resampler.c:487-537 == 604-654 == 766-834; flush :663-685)
  * One channel at a time; every channel replays the identical position sequence.
@@ -325,6 +431,8 @@ static void *run_channel (void *arg)
             ring_rewind (r, c->ring, &pos, &wp);
 
         memset (c->ring + wp, 0, sizeof (float) * (r->ring_len - wp));
+        if (flags & ORA_EXTRAPOLATE)                    /* resampler.c:677-680 */
+            lpc_forward (c->ring + wp - half, half, half);
         flags |= ORA_FLUSHED;
         wp += half;
     }
@@ -342,7 +450,12 @@ static void *run_channel (void *arg)
             used++; n_in--;
         }
         else {
-            flags &= ~ORA_PREFILL;                      /* (extrapolation prefill hook: not restated) */
+            if (flags & ORA_PREFILL) {                  /* resampler.c:812-819: once, before the first output */
+                int known = wp - r->taps;
+                if (known >= 8)
+                    lpc_reverse (c->ring + wp, known, r->taps - known);
+                flags &= ~ORA_PREFILL;
+            }
             *out = (float) evaluate_at (r, c->ring, pos + step);
             out += c->out_stride;
             step = (double)(++made) / c->ratio;         /* division, not accumulation (resampler.c:526) */

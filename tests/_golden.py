@@ -10,7 +10,7 @@ from _oracle import noise
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 # constructor recipes of the golden configs (must mirror tests/golden/make_golden.py CONFIGS)
-from _oracle import BH, INTERP, LOWPASS, NO_REDUCTION  # noqa: E402
+from _oracle import BH, INTERP, LOWPASS, NO_REDUCTION, EXTRAP  # noqa: E402
 
 CTOR = {
     "P_mono_48x48": dict(args=(1, 48, 48, 0.0, BH | INTERP), adv=24.0),
@@ -28,6 +28,10 @@ CTOR = {
     "no_reduction": dict(args=(2, 32, 64), kw=dict(flags=BH | INTERP | NO_REDUCTION, fixed=(44100., 48000., 0)), adv=16.0),
     "down_3x": dict(args=(2, 128, 256, 0.0, BH | INTERP), adv=64.0),
     "up_4x_pow2": dict(args=(2, 64, 4), kw=dict(flags=BH | INTERP, fixed=(12000., 48000., 0)), adv=32.0),
+    "X_art_160x380": dict(args=(2, 380, 380), kw=dict(flags=BH | INTERP | LOWPASS | EXTRAP, fixed=(44100., 48000., 0)), adv=190.0),
+    "X_art_147x156_lp": dict(args=(3, 156, 320), kw=dict(flags=BH | INTERP | LOWPASS | EXTRAP, fixed=(96000., 44100., 0)), adv=78.0),
+    "X_interp_48": dict(args=(1, 48, 48, 0.0, BH | INTERP | EXTRAP), adv=24.0),
+    "X_8ch_988": dict(args=(8, 988, 988, 0.0, BH | INTERP | EXTRAP), adv=494.0),
 }
 NAMES = list(CTOR)
 

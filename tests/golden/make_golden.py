@@ -73,6 +73,14 @@ CONFIGS = {
     "down_3x": dict(args=(2, 128, 256, 0.0, BH | INTERP), adv=64.0, script=SCRIPT_SHORT(1 / 3.0), full=True),
     "up_4x_pow2": dict(args=(2, 64, 4), kw=dict(flags=BH | INTERP, fixed=(12000., 48000., 0)), adv=32.0,
                        script=SCRIPT_SHORT(4.0), full=True),
+    # EXTRAPOLATE_ENDPOINTS (LPC prefill before the first output + extrapolated flush), the way ART calls it (art.c:821-827)
+    "X_art_160x380": dict(args=(2, 380, 380), kw=dict(flags=BH | INTERP | LOWPASS | EXTRAP, fixed=(44100., 48000., 0)), adv=190.0,
+                          script=SCRIPT_SHORT(R4448), full=True),
+    "X_art_147x156_lp": dict(args=(3, 156, 320), kw=dict(flags=BH | INTERP | LOWPASS | EXTRAP, fixed=(96000., 44100., 0)), adv=78.0,
+                             script=SCRIPT_SHORT(R9644), full=True),
+    "X_interp_48": dict(args=(1, 48, 48, 0.0, BH | INTERP | EXTRAP), adv=24.0, script=SCRIPT_SHORT(R4448), full=True),
+    "X_8ch_988": dict(args=(8, 988, 988, 0.0, BH | INTERP | EXTRAP), adv=494.0,
+                      script=[(4096, 4962, R4448, False), (4096, 4962, R4448, False), (0, 4962, R4448, True)], full=False),
 }
 
 

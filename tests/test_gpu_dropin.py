@@ -54,3 +54,48 @@ def test_reference_artest_binary_planar_simulator_and_default_mode():
     # default (fast) numeric mode: same frame counts, program's own self-checks pass (exit code 0)
     c = run("-4 -c8 -n2 -s44100 -d48000", strict=False)
     assert c["output"][0] == G.kat()["strict"]["-4 -c8 -n2 -o16 -s44100 -d48000"]["output"]["count"]
+
+
+# ------------------------------------------------------------------------------------------------
+# the whole ART command-line tool (reference art.c + stretch.c, unmodified) on the HIP library
+# ------------------------------------------------------------------------------------------------
+ART_AMD = os.path.join(ORACLE_DIR, "_ref", "art_amd")
+ART_REF = os.path.join(ORACLE_DIR, "_ref", "art_strict")
+
+
+def _write_wav(path, rate, channels, seconds, bits=16):
+    import wave
+    import numpy as np
+    from _oracle import noise
+    n = int(rate * seconds)
+    x, _ = noise(n * channels)
+    t = np.arange(n)[:, None] / rate
+    sig = 0.35 * x.reshape(n, channels) + 0.4 * np.sin(2 * np.pi * (440.0 * (1 + np.arange(channels))[None, :]) * t)
+    pcm = np.clip(np.round(sig * 32767), -32768, 32767).astype("<i2")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(channels)
+        w.setsampwidth(2)
+        w.setframerate(rate)
+        w.writeframes(pcm.tobytes())
+
+
+@pytest.mark.skipif(not (os.path.exists(ART_AMD) and os.path.exists(ART_REF)), reason="oracle/_ref/art_* not built")
+@pytest.mark.parametrize("opts,rate_in,chans", [
+    ("-4 -r48000", 44100, 2),                # ART default: fixed ratio 160x988 no-lerp, end-point extrapolation, 16-bit dither+ATH shaping
+    ("-3 -r44100 -p", 96000, 2),             # downsample with auto low-pass + cascaded biquad pre-filter (BASELINE configs[2] shape)
+    ("-2 -r48000 -o24 -d1 -n2", 44100, 1),   # 24-bit out, flat dither, 2nd-order shaping
+    ("-3 -r32000 -x -o8", 48000, 2),         # no extrapolation, 8-bit output
+])
+def test_art_cli_on_hip_library_writes_the_same_file_as_reference_art(tmp_path, opts, rate_in, chans):
+    src = str(tmp_path / "in.wav")
+    _write_wav(src, rate_in, chans, 1.5)
+    out_ref, out_amd = str(tmp_path / "ref.wav"), str(tmp_path / "amd.wav")
+    env = dict(os.environ, ARTAMD_STRICT="1")
+    r = subprocess.run([ART_REF] + opts.split() + ["-q", "-y", src, out_ref], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    a = subprocess.run([ART_AMD] + opts.split() + ["-q", "-y", src, out_amd], capture_output=True, text=True, env=env, timeout=600)
+    assert a.returncode == 0, a.stderr[-1500:]
+    with open(out_ref, "rb") as f1, open(out_amd, "rb") as f2:
+        b1, b2 = f1.read(), f2.read()
+    assert len(b1) == len(b2) and len(b1) > 10000
+    assert b1 == b2, f"{sum(x != y for x, y in zip(b1, b2))} of {len(b1)} bytes differ"
