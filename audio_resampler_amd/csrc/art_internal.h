@@ -83,6 +83,7 @@ void art_extrapolate_backward (const float *known_newest_last, int count, float 
 /* ---- pcm_kernels.hip ---- */
 typedef struct {
     int C, bits, bytes, dither_type, dither_on, shaping_on;
+    int shaping_order;                   /* order of the error-feedback filter (same for every channel) */
     float scale;
     float *feedback;                     /* device [C] */
     uint32_t *gens;                      /* device [C] */
@@ -92,6 +93,8 @@ typedef struct {
 int arthip_decimate (const ArtDecArgs *a, const float *d_in, int frames, unsigned char *d_out, void *stream);
 int arthip_decimate_planar (const ArtDecArgs *a, const float *d_in, long in_pitch, int frames, unsigned char *d_out, long out_pitch, void *stream);
 int arthip_biquad_chain (Biquad *d_sections, int C, int S, float *d_buf, int frames, int stride, void *stream);
+/* every section has order 2, S = 1 or 2, interleaved frames: hand-scheduled kernel */
+int arthip_biquad_order2 (Biquad *d_sections, int C, int S, float *d_buf, int frames, void *stream);
 int arthip_ingest (const unsigned char *d_in, float gain_factor, int bits, int bytes, int stride, float *d_out, int n, void *stream);
 
 #ifdef __cplusplus

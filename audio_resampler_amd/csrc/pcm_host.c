@@ -119,6 +119,7 @@ artsample_t biquad_apply_sample (Biquad *f, artsample_t input)
 struct artamd_biquad_bank {
     Biquad *d_sections;
     int C, S;
+    int all_order2;                      /* every section is second order: hand-scheduled kernel */
     void *stream;
 };
 
@@ -131,6 +132,9 @@ BiquadBank *biquadBankCreate (const Biquad *sections, int numChannels, int numSe
     BiquadBank *b = calloc (1, sizeof (*b));
     const size_t bytes = sizeof (Biquad) * (size_t) numChannels * numSections;
     b->C = numChannels; b->S = numSections;
+    b->all_order2 = numSections <= 2;
+    for (int i = 0; i < numChannels * numSections; ++i)
+        if (sections [i].order != 2) b->all_order2 = 0;
     b->d_sections = arthip_malloc (bytes);
     if (!b->d_sections || arthip_h2d (b->d_sections, sections, bytes, NULL) || arthip_sync (NULL)) { biquadBankFree (b); return NULL; }
     return b;
@@ -140,7 +144,10 @@ void biquadBankSetStream (BiquadBank *b, void *stream) { b->stream = stream; }
 
 void biquadBankApplyInterleavedDevice (BiquadBank *b, artsample_t *d_buffer, int numFrames)
 {
-    arthip_biquad_chain (b->d_sections, b->C, b->S, d_buffer, numFrames, b->C, b->stream);
+    if (b->all_order2 && numFrames >= 64)
+        arthip_biquad_order2 (b->d_sections, b->C, b->S, d_buffer, numFrames, b->stream);
+    else
+        arthip_biquad_chain (b->d_sections, b->C, b->S, d_buffer, numFrames, b->C, b->stream);
 }
 
 void biquadBankRead (BiquadBank *b, Biquad *sections)
@@ -272,6 +279,7 @@ static void dec_args (Decimate *cxt, ArtDecArgs *a)
     a->dither_type = cxt->dither_type;
     a->dither_on = (cxt->flags & DITHER_ENABLED) != 0;
     a->shaping_on = (cxt->flags & SHAPING_ENABLED) != 0;
+    a->shaping_order = (a->shaping_on && cxt->noise_shapers) ? cxt->noise_shapers [0].order : 0;
     a->scale = (float)((1 << cxt->outputBits) / 2.0 * cxt->outputGain);
     a->feedback = hip->d_feedback; a->gens = hip->d_gens; a->shapers = hip->d_shapers; a->clipped = hip->d_clipped;
 }

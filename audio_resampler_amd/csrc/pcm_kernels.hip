@@ -163,6 +163,369 @@ __global__ void decimate_kernel (ArtDecArgs a, const float *in, long in_pitch, i
     if (clips) atomicAdd (a.clipped, clips);
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// LDS-staged forms (interleaved frames, stride == channel count).  The recurrences stay one lane per
+// channel — that is what bit-exactness costs — but memory traffic is taken off the serial path: the whole
+// workgroup moves a chunk of frames HBM <-> LDS with coalesced 16-byte accesses, then lanes 0..Cg-1 of
+// wave 0 run the chunk out of LDS (inputs are known ahead of the recurrence, so the LDS reads pipeline).
+// Algorithmic HBM bytes per sample: biquad 8 (in-place), decimator 4 + output bytes.
+// ---------------------------------------------------------------------------------------------------
+constexpr int ST_THREADS = 256;
+constexpr int ST_CHUNK_FLOATS = 8192;            // 32 KiB of samples per chunk
+
+__global__ __launch_bounds__ (ST_THREADS)
+void biquad_chain_lds_kernel (Biquad *sections, int C, int S, float *buf, int frames)
+{
+    __shared__ __attribute__ ((aligned (16))) float tile [ST_CHUNK_FLOATS];
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * 64, Cg = min (64, C - c0);          // this block's channel group
+    const int chunk_frames = ST_CHUNK_FLOATS / Cg;
+
+    SectionRegs r [MAX_CHAIN];
+    if (tid < Cg) {
+#pragma unroll
+        for (int s = 0; s < MAX_CHAIN; ++s)
+            if (s < S) load_section (r [s], sections [(size_t)(c0 + tid) * S + s]);
+    }
+
+    for (int f0 = 0; f0 < frames; f0 += chunk_frames) {
+        const int nf = min (chunk_frames, frames - f0);
+        // HBM -> LDS (coalesced when the group is the whole frame)
+        for (int e = tid; e < nf * Cg; e += ST_THREADS) {
+            const int f = e / Cg, c = e - f * Cg;
+            tile [e] = buf [(size_t)(f0 + f) * C + c0 + c];
+        }
+        __syncthreads ();
+        if (tid < Cg) {
+            float *p = tile + tid;
+            for (int f = 0; f < nf; ++f, p += Cg) {
+                float v = *p;
+#pragma unroll
+                for (int s = 0; s < MAX_CHAIN; ++s)
+                    if (s < S) v = step_buffer_order (r [s], v);
+                *p = v;
+            }
+        }
+        __syncthreads ();
+        for (int e = tid; e < nf * Cg; e += ST_THREADS) {
+            const int f = e / Cg, c = e - f * Cg;
+            buf [(size_t)(f0 + f) * C + c0 + c] = tile [e];
+        }
+        __syncthreads ();
+    }
+
+    if (tid < Cg) {
+#pragma unroll
+        for (int s = 0; s < MAX_CHAIN; ++s)
+            if (s < S) store_section (sections [(size_t)(c0 + tid) * S + s], r [s], frames, false);
+    }
+}
+
+
+// ---- order-2 cascade, hand-scheduled -------------------------------------------------------------
+// Section math (buffer form, reference biquad.c:140-142), un-fused, left to right:
+//     y = ((((x*a0) + (x1*a1)) - (b1*y1)) + (x2*a2)) - (b2*y2)
+// Only b1*y1 and the three adds after it depend on the previous output, so everything else is issued
+// ahead; with two sections the second runs one sample behind the first in the same lane, which gives the
+// scheduler two independent dependency chains to interleave.
+struct Sec2 { float a0, a1, a2, b1, b2, x1, x2, y1, y2; };
+
+__device__ __forceinline__ float sec2_step (Sec2 &s, float x)
+{
+    const float p0 = x * s.a0, p1 = s.x1 * s.a1, p3 = s.x2 * s.a2, p4 = s.b2 * s.y2;
+    const float u = p0 + p1;
+    const float m = s.b1 * s.y1;
+    const float t2 = u - m;
+    const float t3 = t2 + p3;
+    const float y = t3 - p4;
+    s.x2 = s.x1; s.x1 = x; s.y2 = s.y1; s.y1 = y;
+    return y;
+}
+
+__device__ __forceinline__ void sec2_load (Sec2 &s, const Biquad &f)
+{
+    const int i = f.index;
+    s.a0 = f.a [0]; s.a1 = f.a [1]; s.a2 = f.a [2]; s.b1 = f.b [1]; s.b2 = f.b [2];
+    s.x1 = f.x [i & 3]; s.x2 = f.x [(i - 1) & 3]; s.y1 = f.y [i & 3]; s.y2 = f.y [(i - 1) & 3];
+}
+
+// x[] / y[] hold the four most recent values; only two are live in an order-2 section, the other two
+// slots must end up holding what the reference's circular buffer would hold (the 3rd/4th most recent)
+__device__ __forceinline__ void sec2_store (Biquad &f, const Sec2 &s, float x3, float x4, float y3, float y4, int steps)
+{
+    const int i = f.index + steps;
+    f.x [i & 3] = s.x1; f.x [(i - 1) & 3] = s.x2; f.x [(i - 2) & 3] = x3; f.x [(i - 3) & 3] = x4;
+    f.y [i & 3] = s.y1; f.y [(i - 1) & 3] = s.y2; f.y [(i - 2) & 3] = y3; f.y [(i - 3) & 3] = y4;
+    f.index = i;
+}
+
+template <int S>                                   // S = 1 or 2 order-2 sections per channel
+__global__ __launch_bounds__ (ST_THREADS)
+void biquad_order2_lds_kernel (Biquad *sections, int C, float *buf, int frames)
+{
+    __shared__ __attribute__ ((aligned (16))) float tile [ST_CHUNK_FLOATS];
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * 64, Cg = min (64, C - c0);
+    const int chunk_frames = (ST_CHUNK_FLOATS - 64) / Cg;          // last 64 floats: cross-chunk hand-over slot
+
+    Sec2 s1, s2;
+    // the 3rd/4th most recent inputs/outputs of each section (kept only to write the state back faithfully)
+    float x3a = 0, x4a = 0, y3a = 0, y4a = 0, x3b = 0, x4b = 0, y3b = 0, y4b = 0;
+    float carry = 0.0f;                            // output of section 1 waiting for section 2 (skew of one sample)
+    if (tid < Cg) {
+        const Biquad &f1 = sections [(size_t)(c0 + tid) * S];
+        sec2_load (s1, f1);
+        x3a = f1.x [(f1.index - 2) & 3]; x4a = f1.x [(f1.index - 3) & 3]; y3a = f1.y [(f1.index - 2) & 3]; y4a = f1.y [(f1.index - 3) & 3];
+        if (S == 2) {
+            const Biquad &f2 = sections [(size_t)(c0 + tid) * S + 1];
+            sec2_load (s2, f2);
+            x3b = f2.x [(f2.index - 2) & 3]; x4b = f2.x [(f2.index - 3) & 3]; y3b = f2.y [(f2.index - 2) & 3]; y4b = f2.y [(f2.index - 3) & 3];
+        }
+    }
+
+    bool primed = false;                           // carry holds a valid section-1 output
+    for (int f0 = 0; f0 < frames; f0 += chunk_frames) {
+        const int nf = min (chunk_frames, frames - f0);
+        for (int e = tid; e < nf * Cg; e += ST_THREADS) {
+            const int f = e / Cg, c = e - f * Cg;
+            tile [e] = buf [(size_t)(f0 + f) * C + c0 + c];
+        }
+        __syncthreads ();
+        if (tid < Cg) {
+            // register blocks of 8 samples: the LDS reads of a block are issued together, ahead of the
+            // recurrence, and its writes after it, so LDS latency is off the loop-carried path
+            constexpr int UB = 8;
+            float *p = tile + tid;
+            int f = 0;
+
+            // one step of the cascade.  S == 1: returns the finished sample.  S == 2: pushes x into section 1
+            // and returns the finished PREVIOUS sample (section 2 of the value carried from the last step)
+            auto advance = [&] (float x) -> float {
+                x4a = x3a; x3a = s1.x2; y4a = y3a; y3a = s1.y2;
+                const float mid = sec2_step (s1, x);
+                if (S == 1) return mid;
+                x4b = x3b; x3b = s2.x2; y4b = y3b; y3b = s2.y2;
+                const float done = sec2_step (s2, carry);
+                carry = mid;
+                return done;
+            };
+
+            if (S == 2 && !primed) {               // very first sample of the call: section 1 only
+                x4a = x3a; x3a = s1.x2; y4a = y3a; y3a = s1.y2;
+                carry = sec2_step (s1, *p);
+                primed = true; f = 1; p += Cg;
+            }
+            for (; f + UB <= nf; f += UB, p += UB * Cg) {
+                float x [UB], y [UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) x [u] = p [u * Cg];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) y [u] = advance (x [u]);
+                if (S == 1) {
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) p [u * Cg] = y [u];
+                }
+                else {                             // y[u] is the finished sample f+u-1
+                    if (f > 0) p [-Cg] = y [0]; else tile [ST_CHUNK_FLOATS - 64 + tid] = y [0];
+#pragma unroll
+                    for (int u = 1; u < UB; ++u) p [(u - 1) * Cg] = y [u];
+                }
+            }
+            for (; f < nf; ++f, p += Cg) {         // remainder, one sample at a time
+                const float done = advance (*p);
+                if (S == 1) *p = done;
+                else if (f > 0) p [-Cg] = done;
+                else tile [ST_CHUNK_FLOATS - 64 + tid] = done;
+            }
+        }
+        __syncthreads ();
+        // write back: frames [f0-1 (if any), f0+nf-1) are final; the last frame of the chunk still waits in `carry`
+        if (S == 2) {
+            if (f0 > 0 && tid < Cg) buf [(size_t)(f0 - 1) * C + c0 + tid] = tile [ST_CHUNK_FLOATS - 64 + tid];
+            for (int e = tid; e < (nf - 1) * Cg; e += ST_THREADS) {
+                const int f = e / Cg, c = e - f * Cg;
+                buf [(size_t)(f0 + f) * C + c0 + c] = tile [e];
+            }
+        }
+        else
+            for (int e = tid; e < nf * Cg; e += ST_THREADS) {
+                const int f = e / Cg, c = e - f * Cg;
+                buf [(size_t)(f0 + f) * C + c0 + c] = tile [e];
+            }
+        __syncthreads ();
+    }
+
+    if (tid < Cg) {
+        if (S == 2 && primed) {                    // drain: the last sample through section 2
+            x4b = x3b; x3b = s2.x2; y4b = y3b; y3b = s2.y2;
+            buf [(size_t)(frames - 1) * C + c0 + tid] = sec2_step (s2, carry);
+        }
+        sec2_store (sections [(size_t)(c0 + tid) * S], s1, x3a, x4a, y3a, y4a, frames);
+        if (S == 2) sec2_store (sections [(size_t)(c0 + tid) * S + 1], s2, x3b, x4b, y3b, y4b, frames);
+    }
+}
+
+// error-feedback filter with a compile-time order (per-sample association, reference biquad.c:83-95):
+//     acc = in*a0;  for k = ORDER..1:  acc += (x_k*a_k) - (b_k*y_k)
+// x_k / y_k for k >= 2 do not depend on the newest output, so those terms are formed ahead of the chain.
+template <int ORDER>
+__device__ __forceinline__ float shaper_step (SectionRegs &r, float in)
+{
+    float term [4];
+#pragma unroll
+    for (int k = 1; k <= 4; ++k)
+        if (k <= ORDER) { const float fwd = r.x [k - 1] * r.a [k]; const float back = r.b [k] * r.y [k - 1]; term [k - 1] = fwd - back; }
+    float acc = in * r.a [0];
+#pragma unroll
+    for (int k = 4; k >= 1; --k)
+        if (k <= ORDER) acc = acc + term [k - 1];
+    push (r, in, acc);
+    return acc;
+}
+
+// The dither generator (decimator.c:370-382) steps r <- 15 r ^ 1 five times per sample.  15 r keeps the
+// parity of r and "^ 1" flips it, so a step is 15 r + 1 on even r and 15 r - 1 on odd r and the parity
+// alternates every step: five steps are one of two affine maps (chosen by the parity of the start state),
+// the parity alternates every SAMPLE, and two samples are a single fixed affine map.  That gives an
+// O(log n) jump-ahead, so a chunk's dither can be produced by all threads at once.
+struct Affine { uint32_t a, b; };                  // r -> a r + b  (mod 2^32)
+__device__ __forceinline__ Affine compose (Affine second, Affine first) { return { second.a * first.a, second.a * first.b + second.b }; }
+
+__device__ __forceinline__ Affine five_steps (bool even_start)
+{
+    Affine m = { 1u, 0u };
+    bool even = even_start;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { m = compose (Affine { 15u, even ? 1u : 0xffffffffu }, m); even = !even; }
+    return m;
+}
+
+__device__ __forceinline__ uint32_t jump_pairs (uint32_t g, unsigned int pairs)     // advance by 2*pairs samples
+{
+    const bool even = (g & 1u) == 0;
+    Affine two = compose (five_steps (!even), five_steps (even));                   // parity returns after two samples
+    Affine acc = { 1u, 0u };
+    while (pairs) {
+        if (pairs & 1u) acc = compose (two, acc);
+        two = compose (two, two);
+        pairs >>= 1;
+    }
+    return acc.a * g + acc.b;
+}
+
+constexpr int DEC_CHUNK = 4096;                    // samples per chunk (16 KiB of float each for data and dither)
+constexpr int DEC_SEG = 32;                        // consecutive samples of one channel per dither task (even)
+
+template <int ORDER, bool DITHER>                  // ORDER 0 = no noise shaping
+__global__ __launch_bounds__ (ST_THREADS)
+void decimate_lds_kernel (ArtDecArgs a, const float *in, int frames, unsigned char *out)
+{
+    __shared__ __attribute__ ((aligned (16))) float tile [DEC_CHUNK];          // input, then the rounded code values
+    __shared__ __attribute__ ((aligned (16))) float dth [DITHER ? DEC_CHUNK : 1];
+    __shared__ uint32_t s_gen [64], s_next [64];   // generator state at the start of this / the next chunk
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * 64, Cg = min (64, a.C - c0);
+    const int chunk_frames = (DEC_CHUNK / Cg) & ~1;                            // even: chunk boundaries keep generator parity
+
+    float fb = 0.0f; SectionRegs sh; unsigned long long clips = 0;
+    if (tid < Cg) {
+        fb = a.feedback [c0 + tid];
+        if (DITHER) s_gen [tid] = a.gens [c0 + tid];
+        if (ORDER) load_section (sh, a.shapers [c0 + tid]);
+    }
+    const int nbytes = a.bytes, width = (a.bits + 7) / 8, pad = nbytes - width;
+    const int hi = (1 << (a.bits - 1)) - 1, lo = ~hi;
+    const int shift = (24 - a.bits) % 8;
+    const uint32_t bias = a.bits <= 8 ? 128u : 0u;
+    const int dtype = a.dither_type;
+    const float scale = a.scale;
+    __syncthreads ();
+
+    for (int f0 = 0; f0 < frames; f0 += chunk_frames) {
+        const int nf = min (chunk_frames, frames - f0);
+
+        // ---- phase A (all threads): load the chunk; produce its dither by jump-ahead
+        for (int e = tid; e < nf * Cg; e += ST_THREADS) {
+            const int f = e / Cg, c = e - f * Cg;
+            tile [e] = in [(size_t)(f0 + f) * a.C + c0 + c];
+        }
+        if (DITHER) {
+            const int segs_per_ch = (nf + DEC_SEG - 1) / DEC_SEG;
+            for (int task = tid; task < segs_per_ch * Cg; task += ST_THREADS) {
+                const int c = task % Cg, k = task / Cg, n0 = k * DEC_SEG;
+                uint32_t g = jump_pairs (s_gen [c], (unsigned int)(n0 / 2));
+                const int cnt = min (DEC_SEG, nf - n0);
+                for (int i = 0; i < cnt; ++i) {
+                    const uint32_t start = g;
+                    uint32_t r = lcg (lcg (start));
+                    const uint32_t first = dtype < 0 ? ~start : dtype > 0 ? start : ~r;
+                    r = lcg (lcg (lcg (r)));
+                    g = r;
+                    // ((first>>1)+(r>>1))/2^31 - 1.0, converted to float, is exactly this (power-of-two scale)
+                    const uint32_t u = (first >> 1) + (r >> 1);
+                    dth [(n0 + i) * Cg + c] = (float)(int)(u ^ 0x80000000u) * 4.656612873077392578125e-10f;
+                }
+                if (n0 + cnt == nf) s_next [c] = g;          // the channel's last task publishes the next chunk's state
+            }
+        }
+        __syncthreads ();
+
+        // ---- phase B (one lane per channel): the error-feedback recurrence only.
+        // floor ((double) d + 0.5) == floorf (d) + (d - floorf (d) >= 0.5f) exactly (d - floorf (d) is exact in float)
+        if (tid < Cg) {
+            if (DITHER) s_gen [tid] = s_next [tid];          // phase A of the next chunk is two barriers away
+            auto one = [&] (float smp, float dither) -> float {
+                const float scaled = smp * scale;
+                const float code = scaled - fb;
+                const float dithered = code + dither;
+                const float base = floorf (dithered);
+                const float frac = dithered - base;
+                const float qf = frac >= 0.5f ? base + 1.0f : base;
+                if (ORDER) {
+                    const float err = qf - code;
+                    fb = shaper_step<ORDER> (sh, err);
+                }
+                return qf;
+            };
+            constexpr int UB = 8;
+            int f = 0;
+            for (; f + UB <= nf; f += UB) {
+                float x [UB], d [UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) { x [u] = tile [(f + u) * Cg + tid]; d [u] = DITHER ? dth [(f + u) * Cg + tid] : 0.0f; }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) x [u] = one (x [u], d [u]);
+#pragma unroll
+                for (int u = 0; u < UB; ++u) tile [(f + u) * Cg + tid] = x [u];
+            }
+            for (; f < nf; ++f) tile [f * Cg + tid] = one (tile [f * Cg + tid], DITHER ? dth [f * Cg + tid] : 0.0f);
+        }
+        __syncthreads ();
+
+        // ---- phase C (all threads): clip, pack little-endian, store
+        for (int e = tid; e < nf * Cg; e += ST_THREADS) {
+            const int f = e / Cg, c = e - f * Cg;
+            int q = (int) tile [e];
+            if (q > hi) { q = hi; clips++; }
+            else if (q < lo) { q = lo; clips++; }
+            const uint32_t v = ((uint32_t) q << shift) + bias;
+            unsigned char *o = out + ((size_t)(f0 + f) * a.C + c0 + c) * nbytes;
+            for (int j = 0; j < pad; ++j) *o++ = 0;
+            *o++ = (unsigned char) v;
+            if (width > 1) { *o++ = (unsigned char)(v >> 8); if (width > 2) *o++ = (unsigned char)(v >> 16); }
+        }
+        __syncthreads ();
+    }
+
+    if (tid < Cg) {
+        a.feedback [c0 + tid] = fb;
+        if (DITHER) a.gens [c0 + tid] = s_gen [tid];
+        if (ORDER) store_section (a.shapers [c0 + tid], sh, frames, true);
+    }
+    if (clips) atomicAdd (a.clipped, clips);
+}
+
 __global__ void ingest_kernel (const unsigned char *in, float g, int bits, int bytes, int stride, float *out, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -180,11 +543,24 @@ __global__ void ingest_kernel (const unsigned char *in, float g, int bits, int b
 
 extern "C" {
 
+int arthip_biquad_order2 (Biquad *d_sections, int C, int S, float *d_buf, int frames, void *stream)
+{
+    if (frames <= 0) return 0;
+    if (S == 1) hipLaunchKernelGGL (biquad_order2_lds_kernel<1>, dim3 ((C + 63) / 64), dim3 (ST_THREADS), 0, (hipStream_t) stream, d_sections, C, d_buf, frames);
+    else if (S == 2) hipLaunchKernelGGL (biquad_order2_lds_kernel<2>, dim3 ((C + 63) / 64), dim3 (ST_THREADS), 0, (hipStream_t) stream, d_sections, C, d_buf, frames);
+    else return -1;
+    return hipGetLastError () == hipSuccess ? 0 : -1;
+}
+
 int arthip_biquad_chain (Biquad *d_sections, int C, int S, float *d_buf, int frames, int stride, void *stream)
 {
     if (S < 1 || S > MAX_CHAIN || frames <= 0) return S < 1 || S > MAX_CHAIN ? -1 : 0;
     const int sample_form = stride < 0;                  // negative stride selects the per-sample association
     if (sample_form) stride = -stride;
+    if (!sample_form && stride == C && frames >= 64) {   // interleaved frames: LDS-staged form
+        hipLaunchKernelGGL (biquad_chain_lds_kernel, dim3 ((C + 63) / 64), dim3 (ST_THREADS), 0, (hipStream_t) stream, d_sections, C, S, d_buf, frames);
+        return hipGetLastError () == hipSuccess ? 0 : -1;
+    }
     hipLaunchKernelGGL (biquad_chain_kernel, dim3 ((C + 63) / 64), dim3 (64), 0, (hipStream_t) stream, d_sections, C, S, d_buf, frames, stride, sample_form);
     return hipGetLastError () == hipSuccess ? 0 : -1;
 }
@@ -198,6 +574,16 @@ static int decimate_launch (const ArtDecArgs *a, const float *d_in, long in_pitc
 
 int arthip_decimate (const ArtDecArgs *a, const float *d_in, int frames, unsigned char *d_out, void *stream)
 {
+    if (frames >= 64) {
+        const dim3 grid ((a->C + 63) / 64), block (ST_THREADS);
+        hipStream_t st = (hipStream_t) stream;
+        const int order = a->shaping_on ? a->shaping_order : 0;
+#define DEC_GO(O) do { if (a->dither_on) hipLaunchKernelGGL ((decimate_lds_kernel<O, true>), grid, block, 0, st, *a, d_in, frames, d_out); \
+                       else hipLaunchKernelGGL ((decimate_lds_kernel<O, false>), grid, block, 0, st, *a, d_in, frames, d_out); } while (0)
+        switch (order) { case 0: DEC_GO (0); break; case 1: DEC_GO (1); break; case 2: DEC_GO (2); break; case 3: DEC_GO (3); break; default: DEC_GO (4); }
+#undef DEC_GO
+        return hipGetLastError () == hipSuccess ? 0 : -1;
+    }
     return decimate_launch (a, d_in, 0, frames, d_out, 0, stream);
 }
 

@@ -773,13 +773,13 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
         // compile-time channel count where the whole stream is one column group and the buffers allow
         // vector loads; otherwise the generic instantiation
         const bool small = (size_t) a->in_frames * a->C * 4 < 0xffff0000ull && ((uintptr_t) a->in % 16) == 0 && ((uintptr_t) a->hist % 16) == 0;
-        const int cgt = (small && (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8)) ? a->C : 0;
+        const int cgt = (small && (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32)) ? a->C : 0;
         const bool ws = kernel_pref != 3;                    // kernel_pref 3 = the non-specialised variant (ablation)
 #define MF_GO(I, CGT) do { if (ws && CGT) hipLaunchKernelGGL ((fir_mfma_kernel<I, CGT, (CGT != 0)>), grid, dim3 (2 * MF_THREADS), 0, st, *a, *segs, g); \
                            else hipLaunchKernelGGL ((fir_mfma_kernel<I, CGT, false>), grid, dim3 (MF_THREADS), 0, st, *a, *segs, g); } while (0)
-        if (a->interpolate) switch (cgt) { case 8: MF_GO (true, 8); break; case 4: MF_GO (true, 4); break; case 2: MF_GO (true, 2); break;
+        if (a->interpolate) switch (cgt) { case 32: MF_GO (true, 32); break; case 16: MF_GO (true, 16); break; case 8: MF_GO (true, 8); break; case 4: MF_GO (true, 4); break; case 2: MF_GO (true, 2); break;
                                             case 1: MF_GO (true, 1); break; default: MF_GO (true, 0); }
-        else                switch (cgt) { case 8: MF_GO (false, 8); break; case 4: MF_GO (false, 4); break; case 2: MF_GO (false, 2); break;
+        else                switch (cgt) { case 32: MF_GO (false, 32); break; case 16: MF_GO (false, 16); break; case 8: MF_GO (false, 8); break; case 4: MF_GO (false, 4); break; case 2: MF_GO (false, 2); break;
                                             case 1: MF_GO (false, 1); break; default: MF_GO (false, 0); }
 #undef MF_GO
         if (a->ev_stop) arthip_event_record (a->ev_stop, stream);
