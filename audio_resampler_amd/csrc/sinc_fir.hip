@@ -734,12 +734,15 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
         return hipGetLastError () == hipSuccess ? ART_KERNEL_GENERAL : -1;
     }
 
-    // MFMA path: exact rational ratio, default numeric mode, interleaved buffers, no history floor, and at
-    // least a few periods of work (below that the tile is mostly padding and the general kernel wins)
+    // MFMA path: exact rational ratio, default numeric mode, interleaved buffers, no history floor — and enough
+    // work.  A workgroup of the MFMA kernel walks all K chunks of its tile serially (~50-90 us floor), while the
+    // general kernel spreads even a small call over many workgroups; measured crossover (tools/bench_crossover.py,
+    // C in {2,8}, T in {380,988}) is at outputs x channels x taps of roughly 1.2e8.
     const unsigned int total = a->n_end - a->n_begin;
+    const double work = (double) total * a->C * a->T;
     const bool mfma_ok = a->mode == ART_MODE_FAST && a->period_out > 0 && a->fix_list && a->scratch && a->in_pitch == 0 && a->out_pitch == 0 &&
                          segs->lin_floor == INT_MIN && kernel_pref != ART_KERNEL_GENERAL &&
-                         (total >= 4u * (unsigned int) a->period_out || kernel_pref >= ART_KERNEL_MFMA) && total >= (unsigned int) a->period_out;
+                         (work >= 1.2e8 || kernel_pref >= ART_KERNEL_MFMA) && total >= (unsigned int) a->period_out;
 
     if (mfma_ok) {
         MfmaGeom g;

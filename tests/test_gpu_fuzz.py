@@ -1,0 +1,110 @@
+"""GPU: randomised streaming sessions, HIP library vs the oracle on identical call sequences.
+strict mode must agree bit for bit (host planner, history roll, ring-epoch segments, flush floor, extrapolation,
+strict kernel); default mode (general kernel, MFMA kernel forced on where the ratio is rational) must stay within
+the float tolerance of the double-accumulate oracle."""
+import numpy as np
+import pytest
+
+import audio_resampler_amd as A
+from _hip import HipResampler, tolerance_ok
+from _oracle import OracleResampler, noise, BH, INTERP, LOWPASS, PRECISE, EXTRAP, NO_REDUCTION
+
+pytestmark = pytest.mark.gpu
+STRICT = A.RESAMPLE_STRICT_ORDER
+
+
+def random_session(seed):
+    rng = np.random.default_rng(seed)
+    T = int(rng.choice([4, 8, 16, 32, 48, 64, 156, 380, 988]))
+    ch = int(rng.choice([1, 2, 3, 4, 5, 8, 9]))
+    mode = int(rng.integers(0, 3))
+    flags = int(rng.choice([BH | INTERP, BH, INTERP, 0]))
+    extrap = bool(rng.integers(0, 3) == 0)
+    if mode == 0:      # free ratio
+        F = int(rng.choice([1, 2, 7, 32, 160, 380, 1024]))
+        ratio = float(rng.choice([48000 / 44100, 44100 / 96000, 0.5, 2.0, 1.0, 1 / 3.0, 3.7, 0.731, 160 / 147 * (1 + 37e-6)]))
+        lowpass = float(rng.choice([0.0, 0.0, 0.45, 0.9]))
+        ctor = dict(args=(ch, T, F, lowpass, flags | (EXTRAP if extrap else 0)), kw={})
+    else:              # fixed ratio (ART style)
+        src, dst = [(44100, 48000), (96000, 44100), (48000, 32000), (8000, 48000), (44100, 44100 * 2), (48000, 44100)][int(rng.integers(0, 6))]
+        F = int(rng.choice([16, 160, 380, 988]))
+        ratio = dst / src
+        fl = flags | LOWPASS | (EXTRAP if extrap else 0) | (NO_REDUCTION if rng.integers(0, 5) == 0 else 0)
+        ctor = dict(args=(ch, T, F), kw=dict(flags=fl, fixed=(float(src), float(dst), int(rng.choice([0, 0, int(0.4 * min(src, dst))])))))
+    interp_on = bool(flags & INTERP)
+    adv = float(rng.choice([0.0, T / 2, T / 2 + (0.37 if interp_on and mode == 0 else 0.0)]))
+    calls = []
+    first = True
+    for k in range(int(rng.integers(6, 14))):
+        kind = int(rng.integers(0, 12))
+        n = int(rng.integers(0, 8 * T + 50)) if kind < 8 else int(rng.integers(14 * T, 19 * T)) if kind < 10 else int(rng.integers(0, 4))
+        cap = int(rng.integers(1, 12 * T + 64)) if kind != 3 else int(rng.integers(1, 12))
+        if first and extrap:          # documented corner: the first output must come from an ordinary call, before any ring rewind
+            n, cap = max(n, 2 * T + 16), max(cap, 64)
+            n = min(n, 12 * T)
+        first = False
+        r = ratio * (1 + rng.uniform(-2e-4, 2e-4)) if (kind == 5 and mode == 0) else ratio
+        calls.append(("run", n, cap, r))
+        if kind == 9 and k > 3 and not extrap:
+            calls.append(("reset",))
+    calls.append(("flush", int(rng.integers(1, 6 * T + 8)), ratio))
+    calls.append(("flush", 4 * T, ratio))          # continue a flush that may have been cut short
+    calls.append(("run", 10, 50, ratio))           # ignored after a flush
+    total = sum(c[1] for c in calls if c[0] == "run") + 64
+    return ctor, adv, calls, ch, total
+
+
+def play(cls, session, extra=0, **kw):
+    ctor, adv, calls, ch, total = session
+    args, ckw = list(ctor["args"]), dict(ctor["kw"])
+    if "flags" in ckw:
+        ckw["flags"] |= extra
+    else:
+        args[4] |= extra
+    r = cls(*args, **ckw, **kw)
+    r.advance(adv)
+    x, _ = noise(total * ch, state=0x9E3779B97F4A7C15 | 1)
+    x = x.reshape(-1, ch)
+    pos, ys, trace = 0, [], []
+    for c in calls:
+        if c[0] == "reset":
+            r.reset()
+            r.advance(adv)
+            continue
+        if c[0] == "flush":
+            u, g, y = r.process(None, c[1], c[2], flush=True)
+        else:
+            u, g, y = r.process(x[pos:pos + c[1]], c[2], c[3])
+            pos += u
+        ys.append(np.array(y, copy=True))
+        trace.append((u, g) + tuple(r.state())[:2])
+    return np.concatenate(ys), trace
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_session_strict_bit_exact(seed):
+    s = random_session(seed)
+    y, tr = play(HipResampler, s, STRICT)
+    yo, tro = play(OracleResampler, s)
+    assert tr == tro
+    assert y.shape == yo.shape and np.array_equal(y.view(np.uint32), yo.view(np.uint32))
+
+
+@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("kernel", [0, 2])
+def test_random_session_fast_within_tolerance(seed, kernel):
+    s = random_session(seed)
+    y, tr = play(HipResampler, s, kernel=kernel)
+    yo, tro = play(OracleResampler, s, PRECISE)
+    assert tr == tro
+    ok, worst, rms = tolerance_ok(y, yo)
+    assert ok, (worst, rms)
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_random_session_precise_mode(seed):
+    s = random_session(seed)
+    y, _ = play(HipResampler, s, PRECISE)
+    yo, _ = play(OracleResampler, s, PRECISE)
+    d = np.abs(y.astype(np.float64) - yo.astype(np.float64))
+    assert np.all(d <= np.spacing(np.abs(yo)).astype(np.float64) + 1e-45)       # <= 1 float ulp
