@@ -87,9 +87,11 @@ typedef struct {
     float scale;
     float *feedback;                     /* device [C] */
     uint32_t *gens;                      /* device [C] */
+    uint32_t *gens_next;                 /* device [C]: where the fully parallel kernel leaves the generator state */
     Biquad *shapers;                     /* device [C] */
     unsigned long long *clipped;         /* device counter */
 } ArtDecArgs;
+/* returns 1 when the generator state was written to a->gens_next (caller swaps), 0 otherwise, <0 on error */
 int arthip_decimate (const ArtDecArgs *a, const float *d_in, int frames, unsigned char *d_out, void *stream);
 int arthip_decimate_planar (const ArtDecArgs *a, const float *d_in, long in_pitch, int frames, unsigned char *d_out, long out_pitch, void *stream);
 int arthip_biquad_chain (Biquad *d_sections, int C, int S, float *d_buf, int frames, int stride, void *stream);

@@ -167,7 +167,7 @@ void biquadBankFree (BiquadBank *b)
 
 struct artamd_decimator {
     void *stream;
-    float *d_feedback; uint32_t *d_gens; Biquad *d_shapers;
+    float *d_feedback; uint32_t *d_gens, *d_gens_alt; Biquad *d_shapers;
     unsigned long long *d_clipped;
     unsigned long long clipped_seen;
     float *d_in; size_t in_cap;
@@ -238,6 +238,7 @@ Decimate *decimateInit (int numChannels, int outputBits, int outputBytes, double
             }
         cxt->dither_type = (flags & DITHER_HIGHPASS) ? -1 : (flags & DITHER_LOWPASS) ? 1 : 0;
         hip->d_gens = arthip_malloc (sizeof (uint32_t) * C);
+        hip->d_gens_alt = arthip_malloc (sizeof (uint32_t) * C);
         arthip_h2d (hip->d_gens, cxt->tpdf_generators, sizeof (uint32_t) * C, NULL);
     }
 
@@ -264,7 +265,7 @@ void decimateFree (Decimate *cxt)
     struct artamd_decimator *hip = cxt->hip;
     if (hip) {
         arthip_sync (hip->stream);
-        arthip_free (hip->d_feedback); arthip_free (hip->d_gens); arthip_free (hip->d_shapers);
+        arthip_free (hip->d_feedback); arthip_free (hip->d_gens); arthip_free (hip->d_gens_alt); arthip_free (hip->d_shapers);
         arthip_free (hip->d_clipped); arthip_free (hip->d_in); arthip_free (hip->d_out);
         free (hip);
     }
@@ -281,16 +282,21 @@ static void dec_args (Decimate *cxt, ArtDecArgs *a)
     a->shaping_on = (cxt->flags & SHAPING_ENABLED) != 0;
     a->shaping_order = (a->shaping_on && cxt->noise_shapers) ? cxt->noise_shapers [0].order : 0;
     a->scale = (float)((1 << cxt->outputBits) / 2.0 * cxt->outputGain);
-    a->feedback = hip->d_feedback; a->gens = hip->d_gens; a->shapers = hip->d_shapers; a->clipped = hip->d_clipped;
+    a->feedback = hip->d_feedback; a->gens = hip->d_gens; a->gens_next = hip->d_gens_alt; a->shapers = hip->d_shapers; a->clipped = hip->d_clipped;
 }
 
 void decimateHipSetStream (Decimate *cxt, void *stream) { cxt->hip->stream = stream; }
+
+static void dec_swap_if (Decimate *cxt, int rc)
+{
+    if (rc == 1) { uint32_t *t = cxt->hip->d_gens; cxt->hip->d_gens = cxt->hip->d_gens_alt; cxt->hip->d_gens_alt = t; }
+}
 
 void decimateProcessInterleavedLEDevice (Decimate *cxt, const artsample_t *d_input, int numInputFrames, unsigned char *d_output)
 {
     ArtDecArgs a;
     dec_args (cxt, &a);
-    arthip_decimate (&a, d_input, numInputFrames, d_output, cxt->hip->stream);
+    dec_swap_if (cxt, arthip_decimate (&a, d_input, numInputFrames, d_output, cxt->hip->stream));
 }
 
 long decimateHipClipped (Decimate *cxt)
@@ -340,7 +346,7 @@ int decimateProcessInterleavedLE (Decimate *cxt, const artsample_t *input, int n
     }
     dec_args (cxt, &a);
     arthip_h2d (hip->d_in, input, samples * sizeof (float), hip->stream);
-    arthip_decimate (&a, hip->d_in, numInputFrames, hip->d_out, hip->stream);
+    dec_swap_if (cxt, arthip_decimate (&a, hip->d_in, numInputFrames, hip->d_out, hip->stream));
     arthip_d2h (output, hip->d_out, samples * cxt->outputBytes, hip->stream);
     return dec_finish (cxt);
 }

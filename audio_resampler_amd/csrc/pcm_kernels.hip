@@ -471,9 +471,19 @@ void decimate_lds_kernel (ArtDecArgs a, const float *in, int frames, unsigned ch
         }
         __syncthreads ();
 
-        // ---- phase B (one lane per channel): the error-feedback recurrence only.
-        // floor ((double) d + 0.5) == floorf (d) + (d - floorf (d) >= 0.5f) exactly (d - floorf (d) is exact in float)
-        if (tid < Cg) {
+        // ---- phase B: rounding.  floor ((double) d + 0.5) == floorf (d) + (d - floorf (d) >= 0.5f) exactly
+        // (d - floorf (d) is exact in float).  Without noise shaping the feedback term never changes, so there is
+        // no recurrence and every thread rounds its own samples; with shaping one lane per channel walks time.
+        if (!ORDER) {
+            for (int e = tid; e < nf * Cg; e += ST_THREADS) {
+                const int c = e % Cg;
+                const float code = tile [e] * scale - a.feedback [c0 + c];
+                const float dithered = code + (DITHER ? dth [e] : 0.0f);
+                const float base = floorf (dithered);
+                tile [e] = (dithered - base) >= 0.5f ? base + 1.0f : base;
+            }
+        }
+        else if (tid < Cg) {
             if (DITHER) s_gen [tid] = s_next [tid];          // phase A of the next chunk is two barriers away
             auto one = [&] (float smp, float dither) -> float {
                 const float scaled = smp * scale;
@@ -482,10 +492,8 @@ void decimate_lds_kernel (ArtDecArgs a, const float *in, int frames, unsigned ch
                 const float base = floorf (dithered);
                 const float frac = dithered - base;
                 const float qf = frac >= 0.5f ? base + 1.0f : base;
-                if (ORDER) {
-                    const float err = qf - code;
-                    fb = shaper_step<ORDER> (sh, err);
-                }
+                const float err = qf - code;
+                fb = shaper_step<ORDER> (sh, err);
                 return qf;
             };
             constexpr int UB = 8;
@@ -501,6 +509,7 @@ void decimate_lds_kernel (ArtDecArgs a, const float *in, int frames, unsigned ch
             }
             for (; f < nf; ++f) tile [f * Cg + tid] = one (tile [f * Cg + tid], DITHER ? dth [f * Cg + tid] : 0.0f);
         }
+        if (!ORDER && DITHER && tid < Cg) s_gen [tid] = s_next [tid];   // (s_next was published before the barrier above)
         __syncthreads ();
 
         // ---- phase C (all threads): clip, pack little-endian, store
@@ -524,6 +533,59 @@ void decimate_lds_kernel (ArtDecArgs a, const float *in, int frames, unsigned ch
         if (ORDER) store_section (a.shapers [c0 + tid], sh, frames, true);
     }
     if (clips) atomicAdd (a.clipped, clips);
+}
+
+
+// No noise shaping => no recurrence at all: the time axis is cut into segments of DEC_SEG frames, each thread
+// jumps its channel's dither generator to its segment and converts it.  Adjacent threads are adjacent
+// channels of the same frames.  The generator state after the call is written to a second array (the first
+// is still being read by other threads); the host swaps them.
+template <bool DITHER>
+__global__ __launch_bounds__ (256)
+void decimate_parallel_kernel (ArtDecArgs a, const float *in, int frames, unsigned char *out, uint32_t *gens_out)
+{
+    const long task = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (int)(task % a.C);
+    const long seg = task / a.C;
+    const long n0 = seg * DEC_SEG;
+    if (n0 >= frames) return;
+    const int cnt = (int) min ((long) DEC_SEG, frames - n0);
+
+    const int nbytes = a.bytes, width = (a.bits + 7) / 8, pad = nbytes - width;
+    const int hi = (1 << (a.bits - 1)) - 1, lo = ~hi;
+    const int shift = (24 - a.bits) % 8;
+    const uint32_t bias = a.bits <= 8 ? 128u : 0u;
+    const float fb = a.feedback [c];                      // constant without shaping (decimator.c:264-265)
+    uint32_t g = DITHER ? jump_pairs (a.gens [c], (unsigned int)(n0 / 2)) : 0u;
+    unsigned int clips = 0;
+
+    for (int i = 0; i < cnt; ++i) {
+        float dither = 0.0f;
+        if (DITHER) {
+            const uint32_t start = g;
+            uint32_t r = lcg (lcg (start));
+            const uint32_t first = a.dither_type < 0 ? ~start : a.dither_type > 0 ? start : ~r;
+            r = lcg (lcg (lcg (r)));
+            g = r;
+            const uint32_t u = (first >> 1) + (r >> 1);
+            dither = (float)(int)(u ^ 0x80000000u) * 4.656612873077392578125e-10f;
+        }
+        const size_t e = (size_t)(n0 + i) * a.C + c;
+        const float scaled = in [e] * a.scale;
+        const float code = scaled - fb;
+        const float dithered = code + dither;
+        const float base = floorf (dithered);
+        int q = (int)((dithered - base) >= 0.5f ? base + 1.0f : base);
+        if (q > hi) { q = hi; clips++; }
+        else if (q < lo) { q = lo; clips++; }
+        const uint32_t v = ((uint32_t) q << shift) + bias;
+        unsigned char *o = out + e * nbytes;
+        for (int j = 0; j < pad; ++j) *o++ = 0;
+        *o++ = (unsigned char) v;
+        if (width > 1) { *o++ = (unsigned char)(v >> 8); if (width > 2) *o++ = (unsigned char)(v >> 16); }
+    }
+    if (DITHER && n0 + cnt == frames) gens_out [c] = g;
+    if (clips) atomicAdd (a.clipped, (unsigned long long) clips);
 }
 
 __global__ void ingest_kernel (const unsigned char *in, float g, int bits, int bytes, int stride, float *out, int n)
@@ -574,6 +636,13 @@ static int decimate_launch (const ArtDecArgs *a, const float *d_in, long in_pitc
 
 int arthip_decimate (const ArtDecArgs *a, const float *d_in, int frames, unsigned char *d_out, void *stream)
 {
+    if (frames >= 64 && !a->shaping_on && (!a->dither_on || a->gens_next) && (DEC_SEG % 2) == 0) {
+        const long tasks = (long) a->C * ((frames + DEC_SEG - 1) / DEC_SEG);
+        const dim3 grid ((unsigned int)((tasks + 255) / 256)), block (256);
+        if (a->dither_on) hipLaunchKernelGGL (decimate_parallel_kernel<true>, grid, block, 0, (hipStream_t) stream, *a, d_in, frames, d_out, a->gens_next);
+        else hipLaunchKernelGGL (decimate_parallel_kernel<false>, grid, block, 0, (hipStream_t) stream, *a, d_in, frames, d_out, a->gens_next);
+        return hipGetLastError () == hipSuccess ? 1 : -1;      // 1: generator state now lives in gens_next
+    }
     if (frames >= 64) {
         const dim3 grid ((a->C + 63) / 64), block (ST_THREADS);
         hipStream_t st = (hipStream_t) stream;

@@ -76,6 +76,13 @@ def stage(which):
             dec.process_device(d_out, gg, d_pcm); g = gg
         return g * ch
     return step
+dec0 = A.Decimator(ch, 16, 2, 1.0, dst, A.DITHER_HIGHPASS); dec0.set_stream(stream)
+def dither_only():
+    dec0.process_device(d_out, cap - 16, d_pcm)
+    return (cap - 16) * ch
+n, dt = timed(dither_only, args.steps)
+print(json.dumps({"config": "C' 16-bit decimation, HP-TPDF dither, no noise shaping (no recurrence => fully parallel)", "Msamples_per_s": round(n / dt / 1e6, 1),
+                  "ms_per_step": round(dt / args.steps * 1e3, 3)}), flush=True)
 for which in ("resample", "biquad", "decimate", "all"):
     n, dt = timed(stage(which), max(2, args.steps // 3))
     print(json.dumps({"config": f"C  8ch 96k->44.1k -4 fixed (147x988 no-lerp, LP) + 2x biquad + 16-bit ATH decimate: stage={which}",
