@@ -101,12 +101,21 @@ def main():
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         args.gpus = world
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU.  (ARTAMD_BENCH_BACKEND=gloo lets a multi-rank run be smoke-tested on a box with fewer GPUs
+    # than ranks: ranks then share devices and the few scalars of the reduction travel over gloo.)
+    backend = os.environ.get("ARTAMD_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and backend == "nccl":
+        raise SystemExit(f"bench.py: rank {rank} needs cuda:{local_rank} but only {ndev} device(s) are visible")
+    torch.cuda.set_device(local_rank % ndev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     Cn, block = args.channels, args.block_frames
     ratio = DST / SRC
@@ -146,7 +155,7 @@ def main():
     kernel_used = rs.last_kernel()
 
     from audio_resampler_amd.shard import agree_and_aggregate
-    agg = agree_and_aggregate(dist, "cuda", dt, out_frames, Cn, kernel_ms, launches)
+    agg = agree_and_aggregate(dist, "cuda" if backend == "nccl" else "cpu", dt, out_frames, Cn, kernel_ms, launches)
     dt_max, samples_total = agg["seconds_max"], agg["samples_total"]
     assert agg["frames_consistent"], "ranks disagree on the number of generated frames"
 

@@ -1,0 +1,81 @@
+"""GPU: parity at BASELINE.json's full sizes (the bench workload: 1,048,576 input frames x 8 channels per call).
+The oracle is fast enough (a few seconds) to check EVERY sample of one such call; the rest are
+size-independent properties (block-size invariance, device == host entry points, checksum equalities)."""
+import math
+
+import numpy as np
+import pytest
+
+import audio_resampler_amd as A
+from _hip import HipResampler, tolerance_ok
+from _oracle import OracleResampler, load_oracle, checksum_bytes, BH, INTERP, LOWPASS, PRECISE, f32p, u8p, DITHER_HP, SHAPE_ATH
+from audio_resampler_amd.synth import noise
+
+pytestmark = pytest.mark.gpu
+T, C, BLOCK, RATIO = 988, 8, 1 << 20, 48000 / 44100
+
+
+def test_headline_block_every_sample_within_tolerance_of_oracle():
+    torch = pytest.importorskip("torch")
+    x, _ = noise(BLOCK * C)
+    x = x.reshape(BLOCK, C)
+    cap = int(math.floor((BLOCK + T // 2) * RATIO + 10))
+    g = HipResampler(C, T, T, 0.0, BH | INTERP)
+    g.advance(T / 2)
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.empty(cap, C, device="cuda")
+    used, made = g.process_device(d_in, BLOCK, d_out, cap, RATIO)
+    assert g.last_kernel() == 2 and g.handed_back() == 0
+    y = d_out[:made].cpu().numpy()
+    # a second call continues the stream across the history seam
+    used2, made2 = g.process_device(d_in, 65536, d_out, cap, RATIO)
+    y2 = d_out[:made2].cpu().numpy()
+
+    o = OracleResampler(C, T, T, 0.0, BH | INTERP | PRECISE)
+    o.advance(T / 2)
+    uo, go, yo = o.process(x, cap, RATIO, threads=C)
+    uo2, go2, yo2 = o.process(x[:65536], cap, RATIO, threads=C)
+    assert (used, made, used2, made2) == (uo, go, uo2, go2) and g.state()[:2] == o.state()[:2]
+    ok, worst, rms = tolerance_ok(y, yo)
+    assert ok and rms < 2.0e-8, (worst, rms)
+    ok2, worst2, _ = tolerance_ok(y2, yo2)
+    assert ok2, worst2
+
+
+def test_fixed_ratio_full_size_block_equals_small_blocks_bit_for_bit():
+    """ART's form of the conversion (160 x 988, no interpolation, SNAP), strict numeric mode: one 262,144-frame call
+    == four 65,536-frame calls == sixty-four 4,096-frame calls, bit for bit (size-independent property)."""
+    x, _ = noise((BLOCK // 4) * C)
+    x = x.reshape(-1, C)
+    n = x.shape[0]
+    outs = []
+    for block in (n, 65536, 4096):
+        r = HipResampler(C, T, T, flags=BH | INTERP | LOWPASS, fixed=(44100.0, 48000.0, 0), extra=A.RESAMPLE_STRICT_ORDER)
+        r.advance(T / 2)
+        ys = []
+        for p in range(0, n, block):
+            u, g, y = r.process(x[p:p + block], int(block * 1.09) + T, 0.0)
+            assert u == min(block, n - p)
+            ys.append(y)
+        outs.append(np.concatenate(ys))
+    m = min(len(o) for o in outs)
+    assert np.array_equal(outs[0][:m].view(np.uint32), outs[1][:m].view(np.uint32))
+    assert np.array_equal(outs[0][:m].view(np.uint32), outs[2][:m].view(np.uint32))
+
+
+def test_full_size_decimation_checksum_equals_oracle():
+    L = load_oracle()
+    frames = 1 << 19
+    x, _ = noise(frames * C)
+    x = (x * 1.6).reshape(frames, C)
+    for flags, nbytes, bits in ((DITHER_HP | SHAPE_ATH, 2, 16), (DITHER_HP, 3, 24), (0, 1, 8)):
+        d = A.Decimator(C, bits, nbytes, 1.0, 48000, flags)
+        got, clips = d.process(x)
+        od = L.ora_decimate_init(C, bits, nbytes, 1.0, 48000, flags)
+        want = np.zeros(x.size * nbytes, np.uint8)
+        wclips = L.ora_decimate_interleaved(od, x.ctypes.data_as(f32p), frames, want.ctypes.data_as(u8p))
+        L.ora_decimate_free(od)
+        assert clips == wclips
+        assert checksum_bytes(got) == checksum_bytes(want)
+        assert np.array_equal(got, want)
