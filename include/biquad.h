@@ -4,10 +4,9 @@
  * (36 bytes) and Biquad (80 bytes) are caller-allocated PODs whose layout is ABI
  * (ART allocates them itself, art.c:726-729, 869-870).
  *
- * biquad_lowpass/_highpass/_init are host-side design code.  biquad_apply_buffer and
- * biquad_apply_sample run the recurrence in a gfx950 kernel (one lane per section chain,
- * un-fused float ops in the reference's order => bit-identical to the reference built with
- * -ffp-contract=off).  Batched, device-resident forms are in art_hip.h.
+ * The design functions are host code.  biquad_apply_buffer / biquad_apply_sample run the recurrence in a
+ * gfx950 kernel (one lane per section chain, un-fused float ops in the reference's order => bit-identical to
+ * the reference built with -ffp-contract=off).  Batched, device-resident forms are in art_hip.h.
  */
 #ifndef ARTAMD_BIQUAD_H
 #define ARTAMD_BIQUAD_H
@@ -19,13 +18,16 @@
 typedef float artsample_t;
 #endif
 
+/* transfer function (a0 + a1 z^-1 + ... + a4 z^-4) / (1 + b1 z^-1 + ... + b4 z^-4) */
 typedef struct {
-    artsample_t a0, a1, a2, a3, a4, b1, b2, b3, b4;
+    artsample_t a0, a1, a2, a3, a4;
+    artsample_t b1, b2, b3, b4;
 } BiquadCoefficients;
 
+/* one running section: coefficients (gain folded into a[]), four-deep circular input/output history */
 typedef struct {
-    artsample_t a[5], b[5];               /* coefficients (gain folded into a[]) */
-    artsample_t x[4], y[4];               /* circular input / output history */
+    artsample_t a[5], b[5];
+    artsample_t x[4], y[4];
     int order, index;
 } Biquad;
 
@@ -33,10 +35,17 @@ typedef struct {
 extern "C" {
 #endif
 
-void biquad_init (Biquad *f, const BiquadCoefficients *coeffs, double gain);
+/* design: Butterworth-Q second-order sections, `frequency` as a fraction of the sample rate */
 void biquad_lowpass (BiquadCoefficients *filter, double frequency);
 void biquad_highpass (BiquadCoefficients *filter, double frequency);
+
+/* clear the state, fold `gain` into the numerator, derive the order from the non-zero coefficients */
+void biquad_init (Biquad *f, const BiquadCoefficients *coeffs, double gain);
+
+/* filter num_samples values in place, stepping `stride` samples between them (interleaved channels) */
 void biquad_apply_buffer (Biquad *f, artsample_t *buffer, int num_samples, int stride);
+
+/* one value through the section (the association the decimator's noise shaper uses) */
 artsample_t biquad_apply_sample (Biquad *f, artsample_t input);
 
 #ifdef __cplusplus

@@ -14,29 +14,30 @@
 #include <stdint.h>
 #include "biquad.h"
 
-#define DITHER_HIGHPASS     0x1
-#define DITHER_FLAT         0x2
-#define DITHER_LOWPASS      0x4
-#define DITHER_ENABLED      (DITHER_HIGHPASS | DITHER_FLAT | DITHER_LOWPASS)
-
-#define SHAPING_1ST_ORDER   0x100
-#define SHAPING_2ND_ORDER   0x200
-#define SHAPING_3RD_ORDER   0x400
-#define SHAPING_ATH_CURVE   0x800
-#define SHAPING_ENABLED     (SHAPING_1ST_ORDER | SHAPING_2ND_ORDER | SHAPING_3RD_ORDER | SHAPING_ATH_CURVE)
-
-#define DECIMATE_MULTITHREADED  0x1000   /* accepted, no effect */
+/* `flags` of decimateInit: at most one dither shape, at most one shaping choice.  Values are ABI. */
+enum {
+    DITHER_HIGHPASS        = 0x0001,     /* TPDF with negative inter-sample correlation */
+    DITHER_FLAT            = 0x0002,     /* independent TPDF */
+    DITHER_LOWPASS         = 0x0004,     /* TPDF with positive inter-sample correlation */
+    SHAPING_1ST_ORDER      = 0x0100,
+    SHAPING_2ND_ORDER      = 0x0200,
+    SHAPING_3RD_ORDER      = 0x0400,
+    SHAPING_ATH_CURVE      = 0x0800,     /* threshold-of-hearing curves for 32/44.1/48/88.2/96 kHz, else 1st order */
+    DECIMATE_MULTITHREADED = 0x1000      /* accepted, no effect */
+};
+#define DITHER_ENABLED   (DITHER_HIGHPASS | DITHER_FLAT | DITHER_LOWPASS)
+#define SHAPING_ENABLED  (SHAPING_1ST_ORDER | SHAPING_2ND_ORDER | SHAPING_3RD_ORDER | SHAPING_ATH_CURVE)
 
 struct artamd_decimator;
 
 typedef struct {
-    /* ---- reference-layout prefix (reference decimator.h:42-47) */
+    /* reference-layout prefix (reference decimator.h:42-47) */
     int numChannels, outputBits, outputBytes, dither_type, flags;
     double outputGain;
-    artsample_t *feedback;               /* host mirrors, refreshed after every host-pointer call */
+    artsample_t *feedback;               /* host mirrors of the device state, refreshed after every host-pointer call */
     uint32_t *tpdf_generators;
     Biquad *noise_shapers;
-    /* ---- private */
+    /* private */
     struct artamd_decimator *hip;
 } Decimate;
 
@@ -44,11 +45,29 @@ typedef struct {
 extern "C" {
 #endif
 
-void floatIntegersLE (unsigned char *input, double inputGain, int inputBits, int inputBytes, int inputStride, artsample_t *output, int numSamples);
-Decimate *decimateInit (int numChannels, int outputBits, int outputBytes, double outputGain, int sampleRate, int flags);
-int decimateProcessLE (Decimate *cxt, const artsample_t *const *input, int numInputFrames, unsigned char *const *output);
-int decimateProcessInterleavedLE (Decimate *cxt, const artsample_t *input, int numInputFrames, unsigned char *output);
+/* outputBits 1..24 significant bits, left-justified in outputBytes little-endian bytes (8-bit output is
+ * offset-binary); outputGain is applied before quantisation; sampleRate selects the ATH curve */
+Decimate *decimateInit (int numChannels,
+                        int outputBits,
+                        int outputBytes,
+                        double outputGain,
+                        int sampleRate,
+                        int flags);
 void decimateFree (Decimate *cxt);
+
+/* both return the number of samples that had to be clipped */
+int decimateProcessInterleavedLE (Decimate *cxt,
+                                  const artsample_t *input, int numInputFrames,
+                                  unsigned char *output);
+int decimateProcessLE (Decimate *cxt,
+                       const artsample_t *const *input, int numInputFrames,
+                       unsigned char *const *output);
+
+/* the inverse direction: little-endian integers (inputBits in inputBytes, inputStride samples apart) to float */
+void floatIntegersLE (unsigned char *input,
+                      double inputGain,
+                      int inputBits, int inputBytes, int inputStride,
+                      artsample_t *output, int numSamples);
 
 #ifdef __cplusplus
 }

@@ -23,26 +23,31 @@
 #endif
 #ifndef ARTSAMPLE_T_DEFINED
 #define ARTSAMPLE_T_DEFINED
-typedef float artsample_t;
+typedef float artsample_t;              /* one audio sample */
 #endif
 
-/* flag bits — numerically identical to the reference (ABI) */
-#define SUBSAMPLE_INTERPOLATE   0x1
-#define BLACKMAN_HARRIS         0x2
-#define INCLUDE_LOWPASS         0x4
-#define RESAMPLE_MULTITHREADED  0x8      /* accepted, no effect: channels are already parallel on the GPU */
-#define NO_FILTER_REDUCTION     0x10
-#define RESAMPLE_FIXED_RATIO    0x20     /* internal */
-#define EXTRAPOLATE_ENDPOINTS   0x40     /* end-point LPC extrapolation (fit on the host, samples consumed on the GPU) */
-#define EXTRAPOLATE_PREFILL     0x80     /* internal */
-#define EXTEND_CONVOLUTION_MATH 0x100    /* fp64 accumulation in the FIR */
-#define RESAMPLER_FLUSHED       0x200    /* internal */
-#define RESAMPLER_SNAP_OFFSET   0x400    /* internal */
-/* extension (no reference equivalent; also selectable with env ARTAMD_STRICT=1): evaluate the FIR
- * in the reference's C source order, un-fused — bit-identical to the reference built with
- * `-O2 -ffp-contract=off`.  Slow; meant for parity runs. */
-#define RESAMPLE_STRICT_ORDER   0x10000
+/* Behaviour flags for the `flags` argument of the init calls.  Values are ABI (identical to the reference). */
+enum {
+    /* ---- what the caller asks for ---- */
+    SUBSAMPLE_INTERPOLATE   = 0x001,    /* blend the two neighbouring phase filters (needed for arbitrary ratios) */
+    BLACKMAN_HARRIS         = 0x002,    /* 4-term Blackman-Harris window; otherwise Hann */
+    INCLUDE_LOWPASS         = 0x004,    /* fold a low-pass into the sinc (set automatically when lowpassRatio < 1) */
+    RESAMPLE_MULTITHREADED  = 0x008,    /* accepted, no effect: channels already run in parallel on the GPU */
+    NO_FILTER_REDUCTION     = 0x010,    /* fixed-ratio init: keep the full filter count (allows phase shifts) */
+    EXTRAPOLATE_ENDPOINTS   = 0x040,    /* LPC-extrapolate before the first / after the last input sample */
+    EXTEND_CONVOLUTION_MATH = 0x100,    /* fp64 accumulation in the FIR */
+    /* ---- state bits the library keeps in Resample.flags (do not set) ---- */
+    RESAMPLE_FIXED_RATIO    = 0x020,
+    EXTRAPOLATE_PREFILL     = 0x080,
+    RESAMPLER_FLUSHED       = 0x200,
+    RESAMPLER_SNAP_OFFSET   = 0x400,
+    /* ---- extension, no reference equivalent (also: environment ARTAMD_STRICT=1) ----
+     * evaluate the FIR in the reference's C source order, un-fused: bit-identical to the reference built
+     * with `-O2 -ffp-contract=off`.  Slow; meant for parity runs. */
+    RESAMPLE_STRICT_ORDER   = 0x10000
+};
 
+/* frames consumed / produced by one process call */
 typedef struct {
     unsigned int input_used, output_generated;
 } ResampleResult;
@@ -50,14 +55,14 @@ typedef struct {
 struct artamd_resampler;                 /* private device-side state */
 
 typedef struct resample {
-    /* ---- reference-layout prefix (reference resampler.h:45-48); numChannels is read by callers */
+    /* reference-layout prefix (reference resampler.h:45-48); callers read numChannels */
     int numChannels, numSamples, numFilters, numTaps, inputIndex, flags;
     double *tempFilter;                  /* always NULL */
     double outputOffset, fixedRatio, lowpassRatio;
     void *subsample;                     /* always NULL: evaluation happens on the device */
     artsample_t **buffers;               /* always NULL: sample history lives in HBM */
     artsample_t **filters;               /* host copy of the (numFilters+1) x numTaps bank rows */
-    /* ---- private */
+    /* private */
     struct artamd_resampler *hip;
 } Resample;
 
@@ -65,21 +70,65 @@ typedef struct resample {
 extern "C" {
 #endif
 
-Resample *resampleInit (int numChannels, int numTaps, int numFilters, double lowpassRatio, int flags);
-Resample *resampleFixedRatioInit (int numChannels, int numTaps, int maxFilters, double sourceRate, double destinRate, int lowpassFreq, int flags);
-ResampleResult resampleProcess (Resample *cxt, const artsample_t *const *input, int numInputFrames, artsample_t *const *output, int numOutputFrames, double ratio);
-ResampleResult resampleProcessInterleaved (Resample *cxt, const artsample_t *input, int numInputFrames, artsample_t *output, int numOutputFrames, double ratio);
-ResampleResult resampleProcessAndFlush (Resample *cxt, const artsample_t *const *input, int numInputFrames, artsample_t *const *output, int numOutputFrames, double ratio);
-ResampleResult resampleProcessAndFlushInterleaved (Resample *cxt, const artsample_t *input, int numInputFrames, artsample_t *output, int numOutputFrames, double ratio);
-unsigned int resampleGetRequiredSamples (Resample *cxt, int numOutputFrames, double ratio);
-unsigned int resampleGetExpectedOutput (Resample *cxt, int numInputFrames, double ratio);
-void resampleAdvancePosition (Resample *cxt, double delta);
+/* ---- construction / destruction ------------------------------------------------------------- */
+
+/* Arbitrary-ratio context.  taps: 4..1024, multiple of 4;  filters: 1..1024;
+ * lowpassRatio: cutoff relative to the source Nyquist, (0,1) enables the low-pass, anything else disables it. */
+Resample *resampleInit (int numChannels,
+                        int numTaps,
+                        int numFilters,
+                        double lowpassRatio,
+                        int flags);
+
+/* Fixed-ratio context: when destinRate / gcd fits in maxFilters the bank shrinks to exactly the phases in use
+ * and interpolation is dropped.  lowpassFreq in Hz, or 0 with INCLUDE_LOWPASS for an automatic cutoff when
+ * downsampling.  The `ratio` argument of the process calls is ignored for such contexts. */
+Resample *resampleFixedRatioInit (int numChannels,
+                                  int numTaps,
+                                  int maxFilters,
+                                  double sourceRate,
+                                  double destinRate,
+                                  int lowpassFreq,
+                                  int flags);
+
+void resampleReset (Resample *cxt);      /* forget history and position (also re-arms a flushed context) */
+void resampleFree (Resample *cxt);       /* NULL is fine */
+
+/* ---- streaming ---------------------------------------------------------------------------------
+ * Runs until the input is exhausted or numOutputFrames have been written, whichever comes first.
+ * numInputFrames == -1 flushes: half a window of silence (or extrapolation) is appended; input may be NULL. */
+
+/* planar: one pointer per channel */
+ResampleResult resampleProcess (Resample *cxt,
+                                const artsample_t *const *input, int numInputFrames,
+                                artsample_t *const *output, int numOutputFrames,
+                                double ratio);
+
+/* interleaved: frame-major */
+ResampleResult resampleProcessInterleaved (Resample *cxt,
+                                           const artsample_t *input, int numInputFrames,
+                                           artsample_t *output, int numOutputFrames,
+                                           double ratio);
+
+/* process, then — if all input was taken and room remains — flush into the tail of the same buffer */
+ResampleResult resampleProcessAndFlush (Resample *cxt,
+                                        const artsample_t *const *input, int numInputFrames,
+                                        artsample_t *const *output, int numOutputFrames,
+                                        double ratio);
+ResampleResult resampleProcessAndFlushInterleaved (Resample *cxt,
+                                                   const artsample_t *input, int numInputFrames,
+                                                   artsample_t *output, int numOutputFrames,
+                                                   double ratio);
+
+/* ---- position and queries ---------------------------------------------------------------------- */
+
+void   resampleAdvancePosition (Resample *cxt, double delta);   /* forward only; fractional only when interpolating */
+double resampleGetPosition (Resample *cxt);                     /* in input samples; negative: an output is due */
+unsigned int resampleGetRequiredSamples (Resample *cxt, int numOutputFrames, double ratio);   /* dry run */
+unsigned int resampleGetExpectedOutput (Resample *cxt, int numInputFrames, double ratio);     /* dry run */
 double resampleGetLowpassRatio (Resample *cxt);
-double resampleGetPosition (Resample *cxt);
-int resampleGetNumFilters (Resample *cxt);
-int resampleInterpolationUsed (Resample *cxt);
-void resampleReset (Resample *cxt);
-void resampleFree (Resample *cxt);
+int    resampleGetNumFilters (Resample *cxt);
+int    resampleInterpolationUsed (Resample *cxt);
 
 #ifdef __cplusplus
 }
