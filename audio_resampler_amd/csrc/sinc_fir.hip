@@ -325,7 +325,8 @@ constexpr int MF_BSLOTS = (MF_KC * 32 + MF_THREADS - 1) / MF_THREADS;   // stagi
 
 struct MfmaGeom {
     int P, Q;                             // outputs / inputs per period
-    int slot_tiles;                       // ceil (P / 32)
+    int tile_rows;                        // slots per workgroup tile: 32, or 64 (two MFMA m-tiles sharing one X tile)
+    int slot_tiles;                       // ceil (P / tile_rows)
     int ppw;                              // periods per workgroup
     int cg;                               // channels per column group
     int ktot;                             // K columns, multiple of MF_KC
@@ -333,8 +334,8 @@ struct MfmaGeom {
     int groups_per_xcd;                   // ceil (period_groups / 8)
     int band_lo, band_hi;
     // per-launch tables in device scratch (written by mfma_prepare_kernel)
-    float *eff;                           // [slot_tiles*32][ktot]  blended rows, shifted to the tile's K origin, zero padded
-    int *canon_ip, *canon_fi;             // [slot_tiles*32]        canonical position of each slot (period 0 of the launch)
+    float *eff;                           // [slot_tiles*tile_rows][ktot]  blended rows, shifted to the tile's K origin, zero padded
+    int *canon_ip, *canon_fi;             // [slot_tiles*tile_rows]        canonical position of each slot (period 0 of the launch)
     double *canon_frac;                 // K columns [band_lo, band_hi) hold every row's central taps
 };
 
@@ -366,16 +367,18 @@ __global__ __launch_bounds__ (256)
 void mfma_prepare_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
 {
     const int st = blockIdx.x, row = blockIdx.y, tid = threadIdx.x;
-    const int rows_valid = min (32, g.P - st * 32);
+    const int R = g.tile_rows;
+    const int rows_valid = min (R, g.P - st * R);
     // every thread derives the two positions it needs (uniform, a few dozen fp64 ops)
-    const Pos p0 = locate<INTERP> (a, segs, a.n_begin + st * 32);
-    const Pos p = locate<INTERP> (a, segs, a.n_begin + st * 32 + min (row, rows_valid - 1));
+    const Pos p0 = locate<INTERP> (a, segs, a.n_begin + st * R);
+    const Pos p = locate<INTERP> (a, segs, a.n_begin + st * R + min (row, rows_valid - 1));
     if (tid == 0) {
-        g.canon_ip [st * 32 + row] = p.ip; g.canon_fi [st * 32 + row] = p.fi; g.canon_frac [st * 32 + row] = p.frac;
+        g.canon_ip [st * R + row] = p.ip; g.canon_fi [st * R + row] = p.fi; g.canon_frac [st * R + row] = p.frac;
+        if (st == 0 && row == 0) a.fix_count [0] = 0;       // per-launch hand-back counter (the main kernel follows in-stream)
     }
     const float *h0 = a.bank + (size_t) p.fi * a.T;
     const int shift = p.ip - p0.ip;
-    float *dst = g.eff + (size_t)(st * 32 + row) * g.ktot;
+    float *dst = g.eff + (size_t)(st * R + row) * g.ktot;
     for (int k = tid; k < g.ktot; k += 256) {
         const int tap = k - shift;
         float c = 0.0f;
@@ -397,17 +400,21 @@ void mfma_prepare_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
 // waves 0-3 are the MATRIX waves — LDS operand reads, the MFMA chain and its fp64 flush, nothing else.
 // Each SIMD hosts one wave of each kind per workgroup, so staging (VALU/VMEM/LDS-write) and matrix work
 // overlap in hardware with one barrier per chunk, instead of relying on instruction scheduling.
-template <bool INTERP, int CG, bool WS>
-__global__ __launch_bounds__ (WS ? 2 * MF_THREADS : MF_THREADS, WS ? 4 : 2)
+// MT: MFMA m-tiles (32 slots each) per workgroup.  With MT = 2 the workgroup owns 64 consecutive slots whose two
+// A tiles multiply the SAME X tile: X staging and barriers per MFMA halve and every matrix wave runs two
+// independent accumulator chains.
+template <bool INTERP, int CG, bool WS, int MT>
+__global__ __launch_bounds__ (WS ? 2 * MF_THREADS : MF_THREADS, (WS && MT == 1) ? 4 : 2)
 void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
 {
     constexpr int THREADS = WS ? 2 * MF_THREADS : MF_THREADS;
     constexpr int NBUF = WS ? 2 : 1;
-    __shared__ __attribute__ ((aligned (16))) float As_ [NBUF] [32 * MF_LD];
+    constexpr int ROWS = 32 * MT;
+    __shared__ __attribute__ ((aligned (16))) float As_ [NBUF] [ROWS * MF_LD];
     __shared__ __attribute__ ((aligned (16))) float Bs_ [NBUF] [MF_COLS * MF_LD];
-    __shared__ unsigned char s_status [32 * MF_MAX_PPW];      // 0 ok, 1 handed back, 2 masked, 3 pass-through
-    __shared__ int s_fi [32], s_shift [32], s_ip [32];
-    __shared__ double s_frac [32];
+    __shared__ unsigned char s_status [ROWS * MF_MAX_PPW];    // 0 ok, 1 handed back, 2 masked, 3 pass-through
+    __shared__ int s_fi [ROWS], s_shift [ROWS], s_ip [ROWS];
+    __shared__ double s_frac [ROWS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool loader = WS && wave >= 4;
@@ -424,25 +431,25 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
     const int cg = CG ? CG : g.cg, ppw = CG ? (MF_COLS / CG > MF_MAX_PPW ? MF_MAX_PPW : MF_COLS / CG) : g.ppw;
     const int ch_base = blockIdx.y * cg;
     const int half = a.T / 2;
-    const int r0 = st * 32;
-    const int rows_valid = min (32, g.P - r0);
+    const int r0 = st * ROWS;
+    const int rows_valid = min (ROWS, g.P - r0);
     const unsigned int n_tile = a.n_begin + (unsigned int)(jg * ppw) * g.P + r0;       // slot 0, first period
     if (n_tile >= a.n_end) return;
 
     // ---- canonical (ip, fi, frac) of the 32 slots: period 0 of the launch (mfma_prepare_kernel), moved to
     // this workgroup's first period
     const int j_first = jg * ppw;
-    if (tid < 32) {
-        s_ip [tid] = g.canon_ip [st * 32 + tid] + j_first * g.Q;
-        s_fi [tid] = g.canon_fi [st * 32 + tid]; s_frac [tid] = g.canon_frac [st * 32 + tid];
+    if (tid < ROWS) {
+        s_ip [tid] = g.canon_ip [st * ROWS + tid] + j_first * g.Q;
+        s_fi [tid] = g.canon_fi [st * ROWS + tid]; s_frac [tid] = g.canon_frac [st * ROWS + tid];
     }
     __syncthreads ();
     const int w0 = s_ip [0] - half + 1;                      // linear index of K column 0 (first period)
-    if (tid < 32) s_shift [tid] = s_ip [tid] - s_ip [0];
+    if (tid < ROWS) s_shift [tid] = s_ip [tid] - s_ip [0];
 
     // ---- exact position of every (slot, period) of the tile, checked against the canonical pattern
-    for (int e = tid; e < 32 * ppw; e += THREADS) {
-        const int i = e & 31, jl = e >> 5;
+    for (int e = tid; e < ROWS * ppw; e += THREADS) {
+        const int i = e & (ROWS - 1), jl = e / ROWS;
         const unsigned int n = n_tile + (unsigned int) jl * g.P + i;
         unsigned char status = 2;
         if (i < rows_valid && n < a.n_end) {
@@ -472,8 +479,9 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
 
     // A: thread -> (row, 4 consecutive k) of the prepared effective rows: one aligned dwordx4 per chunk
     const int a_row = pt >> 3, a_kseg = (pt & 7) * 4;
-    const __amdgpu_buffer_rsrc_t rs_eff = make_rsrc (g.eff + (size_t) st * 32 * g.ktot, (unsigned int)((size_t) 32 * g.ktot * 4));
+    const __amdgpu_buffer_rsrc_t rs_eff = make_rsrc (g.eff + (size_t) st * ROWS * g.ktot, (unsigned int)((size_t) ROWS * g.ktot * 4));
     const unsigned int a_off0 = (unsigned int)(a_row * g.ktot + a_kseg) * 4u;
+    const unsigned int a_tile_stride = (unsigned int)(32 * g.ktot) * 4u;       // second m-tile: 32 rows further
 
     // B: thread -> NB vectors of VEC channels of one frame of one period
     constexpr int VEC = CG >= 4 ? 4 : (CG == 2 ? 2 : 1);
@@ -482,12 +490,14 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
     constexpr int PPW_C = CG ? (MF_COLS / CG > MF_MAX_PPW ? MF_MAX_PPW : MF_COLS / CG) : 1;
     constexpr int NB = CG ? (PPW_C * VPP) / MF_THREADS : 1;
 
-    float ra [4];
+    float ra [MT * 4];
     float rb [NB * VEC];
 
     auto fetch = [&] (int chunk) {
         const int k0 = chunk * MF_KC;
-        VecLoad<4>::load (ra, rs_eff, a_off0 + (unsigned int) k0 * 4u);      // past ktot: out of range => 0
+#pragma unroll
+        for (int m = 0; m < MT; ++m)                        // past ktot / past the last row: out of range => 0
+            VecLoad<4>::load (&ra [m * 4], rs_eff, a_off0 + m * a_tile_stride + (unsigned int) k0 * 4u);
         if (CG) {
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
@@ -508,9 +518,12 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
 
     auto commit = [&] (int chunk, int buf) {
         float *As = As_ [buf], *Bs = Bs_ [buf];
-        f32x4 v;
-        v [0] = ra [0]; v [1] = ra [1]; v [2] = ra [2]; v [3] = ra [3];
-        *reinterpret_cast<f32x4 *> (&As [a_row * MF_LD + a_kseg]) = v;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            f32x4 v;
+            v [0] = ra [m * 4]; v [1] = ra [m * 4 + 1]; v [2] = ra [m * 4 + 2]; v [3] = ra [m * 4 + 3];
+            *reinterpret_cast<f32x4 *> (&As [(m * 32 + a_row) * MF_LD + a_kseg]) = v;
+        }
 
         if (CG) {
 #pragma unroll
@@ -545,63 +558,87 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
         for (int e = tid; e < (MF_COLS - ncols) * MF_LD; e += THREADS)
             for (int b = 0; b < NBUF; ++b) Bs_ [b] [ncols * MF_LD + e] = 0.0f;
 
-    double sum [16];
+    double sum [MT] [16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sum [r] = 0.0;
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum [m] [r] = 0.0;
+    const bool second_tile = MT > 1 && rows_valid > 32;       // (uniform) the last super-tile of a period may be half empty
 
     const int nchunks = g.ktot / MF_KC;
     const int arow = (lane & 31) * MF_LD + 4 * (lane >> 5);
     const int brow = (wave * 32 + (lane & 31)) * MF_LD + 4 * (lane >> 5);
 
     // one chunk of matrix work on LDS buffer `buf`: 32 k's = 4 groups of 8; lanes 0-31 take k 0-3 of a
-    // group, lanes 32-63 k 4-7
-    auto matrix_chunk = [&] (int chunk, int buf) {
+    // group, lanes 32-63 k 4-7.  NT = m-tiles actually computed (1 or MT).
+    auto matrix_rows = [&] (auto nt_tag, int chunk, int buf) {
+        constexpr int NT = decltype (nt_tag)::value;
         const float *As = As_ [buf], *Bs = Bs_ [buf];
         const int k0 = chunk * MF_KC;
         const bool band = k0 < g.band_hi && k0 + MF_KC > g.band_lo;
         if (!band) {
-            f32x16 acc;
+            f32x16 acc [NT];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc [r] = 0.0f;
+            for (int m = 0; m < NT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc [m] [r] = 0.0f;
 #pragma unroll
             for (int grp = 0; grp < MF_KC / 8; ++grp) {
-                const f32x4 av = *reinterpret_cast<const f32x4 *> (&As [arow + grp * 8]);
                 const f32x4 bv = *reinterpret_cast<const f32x4 *> (&Bs [brow + grp * 8]);
+                f32x4 av [NT];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int m = 0; m < NT; ++m) av [m] = *reinterpret_cast<const f32x4 *> (&As [m * 32 * MF_LD + arow + grp * 8]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) {
 #ifndef ABL_NOMFMA
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [q], bv [q], acc, 0, 0, 0);
+                        acc [m] = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [m] [q], bv [q], acc [m], 0, 0, 0);
 #else
-                    acc [q] += av [q] * bv [q];
+                        acc [m] [q] += av [m] [q] * bv [q];
 #endif
-                }
+                    }
             }
+#pragma unroll
+            for (int m = 0; m < NT; ++m) {
 #ifndef ABL_NOFLUSH
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sum [r] = sum [r] + (double) acc [r];
+                for (int r = 0; r < 16; ++r) sum [m] [r] = sum [m] [r] + (double) acc [m] [r];
 #else
 #pragma unroll
-            for (int r = 0; r < 16; ++r) asm volatile ("" :: "v" (acc [r]));
-            sum [0] = sum [0] + (double) acc [0];
+                for (int r = 0; r < 16; ++r) asm volatile ("" :: "v" (acc [m] [r]));
+                sum [m] [0] = sum [m] [0] + (double) acc [m] [0];
 #endif
+            }
         }
         else {
 #pragma unroll
             for (int grp = 0; grp < MF_KC / 8; ++grp) {
-                const f32x4 av = *reinterpret_cast<const f32x4 *> (&As [arow + grp * 8]);
                 const f32x4 bv = *reinterpret_cast<const f32x4 *> (&Bs [brow + grp * 8]);
+                f32x4 av [NT];
+#pragma unroll
+                for (int m = 0; m < NT; ++m) av [m] = *reinterpret_cast<const f32x4 *> (&As [m * 32 * MF_LD + arow + grp * 8]);
 #pragma unroll
                 for (int q = 0; q < 4; q += 2) {
-                    f32x16 acc;
+                    f32x16 acc [NT];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc [r] = 0.0f;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [q], bv [q], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [q + 1], bv [q + 1], acc, 0, 0, 0);
+                    for (int m = 0; m < NT; ++m) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) sum [r] = sum [r] + (double) acc [r];
+                        for (int r = 0; r < 16; ++r) acc [m] [r] = 0.0f;
+                        acc [m] = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [m] [q], bv [q], acc [m], 0, 0, 0);
+                        acc [m] = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [m] [q + 1], bv [q + 1], acc [m], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int m = 0; m < NT; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sum [m] [r] = sum [m] [r] + (double) acc [m] [r];
                 }
             }
         }
+    };
+    auto matrix_chunk = [&] (int chunk, int buf) {
+        if (second_tile) matrix_rows (std::integral_constant<int, MT> {}, chunk, buf);
+        else matrix_rows (std::integral_constant<int, 1> {}, chunk, buf);
     };
 
     if (WS) {
@@ -642,15 +679,19 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
     const int jl = col / cg, c = col - jl * cg;
     if (ch_base + c >= a.C) return;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const unsigned char status = s_status [jl * 32 + i];
-        if (status == 0 || status == 3) {
-            const size_t n = (size_t) n_tile + (size_t) jl * g.P + i;
-            float y = (float) sum [r];
-            if (!INTERP && status == 3)
-                y = load_frame (a, INT_MIN, s_ip [i] + jl * g.Q + s_fi [i] / a.F, ch_base + c);
-            a.out [n * a.C + ch_base + c] = y;
+    for (int m = 0; m < MT; ++m) {
+        if (m && !second_tile) break;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const unsigned char status = s_status [jl * ROWS + i];
+            if (status == 0 || status == 3) {
+                const size_t n = (size_t) n_tile + (size_t) jl * g.P + i;
+                float y = (float) sum [m] [r];
+                if (!INTERP && status == 3)
+                    y = load_frame (a, INT_MIN, s_ip [i] + jl * g.Q + s_fi [i] / a.F, ch_base + c);
+                a.out [n * a.C + ch_base + c] = y;
+            }
         }
     }
 }
@@ -747,11 +788,20 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
     if (mfma_ok) {
         MfmaGeom g;
         g.P = a->period_out; g.Q = a->period_in;
-        g.slot_tiles = (g.P + 31) / 32;
+        // compile-time channel count where the whole stream is one column group and the buffers allow vector
+        // loads => wave-specialised kernel on 64-slot tiles; otherwise the generic instantiation on 32-slot tiles
+        const bool small = (size_t) a->in_frames * a->C * 4 < 0xffff0000ull && ((uintptr_t) a->in % 16) == 0 && ((uintptr_t) a->hist % 16) == 0;
+        const int cgt = (small && (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32)) ? a->C : 0;
+        const bool ws = kernel_pref != 3 && cgt != 0;         // kernel_pref 3 = the non-specialised variant (ablation)
+        // 64-slot tiles (two m-tiles per X tile) are correct but currently lose: 156 VGPRs => one workgroup per CU
+        // (measured 29 vs 36 Gsamples/s); kept selectable (kernel_pref 4) for tuning
+        const bool wide = ws && kernel_pref == 4;
+        g.tile_rows = wide ? 64 : 32;
+        g.slot_tiles = (g.P + g.tile_rows - 1) / g.tile_rows;
         g.cg = a->C < 32 ? a->C : 32;
         g.ppw = MF_COLS / g.cg;
         if (g.ppw > MF_MAX_PPW) g.ppw = MF_MAX_PPW;
-        const int shift_max = (int)(31.0 * g.Q / g.P) + 2;
+        const int shift_max = (int)((g.tile_rows - 1.0) * g.Q / g.P) + 2;
         g.ktot = ((a->T + shift_max + MF_KC - 1) / MF_KC) * MF_KC;
         g.band_lo = a->T / 2 - 1 - 6;                       // central taps of the first row ...
         g.band_hi = a->T / 2 + shift_max + 6;               // ... to those of the last
@@ -759,7 +809,7 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
         g.period_groups = (int)((periods + g.ppw - 1) / g.ppw);
         g.groups_per_xcd = (g.period_groups + 7) / 8;
         {   // carve the per-launch tables out of the scratch buffer
-            const size_t rows = (size_t) g.slot_tiles * 32, eff_bytes = rows * g.ktot * sizeof (float);
+            const size_t rows = (size_t) g.slot_tiles * g.tile_rows, eff_bytes = rows * g.ktot * sizeof (float);
             char *base = (char *) a->scratch;
             g.eff = (float *) base;
             g.canon_frac = (double *)(base + ((eff_bytes + 15) & ~(size_t) 15));
@@ -769,17 +819,12 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
         }
         dim3 grid ((unsigned int)(8 * g.groups_per_xcd * g.slot_tiles), (unsigned int)((a->C + g.cg - 1) / g.cg));
 
-        if (hipMemsetAsync (a->fix_count, 0, sizeof (unsigned int), st) != hipSuccess) return -1;
-        if (a->interpolate) hipLaunchKernelGGL (mfma_prepare_kernel<true>, dim3 (g.slot_tiles, 32), dim3 (256), 0, st, *a, *segs, g);
-        else hipLaunchKernelGGL (mfma_prepare_kernel<false>, dim3 (g.slot_tiles, 32), dim3 (256), 0, st, *a, *segs, g);
+        if (a->interpolate) hipLaunchKernelGGL (mfma_prepare_kernel<true>, dim3 (g.slot_tiles, g.tile_rows), dim3 (256), 0, st, *a, *segs, g);
+        else hipLaunchKernelGGL (mfma_prepare_kernel<false>, dim3 (g.slot_tiles, g.tile_rows), dim3 (256), 0, st, *a, *segs, g);
         if (a->ev_start) arthip_event_record (a->ev_start, stream);
-        // compile-time channel count where the whole stream is one column group and the buffers allow
-        // vector loads; otherwise the generic instantiation
-        const bool small = (size_t) a->in_frames * a->C * 4 < 0xffff0000ull && ((uintptr_t) a->in % 16) == 0 && ((uintptr_t) a->hist % 16) == 0;
-        const int cgt = (small && (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32)) ? a->C : 0;
-        const bool ws = kernel_pref != 3;                    // kernel_pref 3 = the non-specialised variant (ablation)
-#define MF_GO(I, CGT) do { if (ws && CGT) hipLaunchKernelGGL ((fir_mfma_kernel<I, CGT, (CGT != 0)>), grid, dim3 (2 * MF_THREADS), 0, st, *a, *segs, g); \
-                           else hipLaunchKernelGGL ((fir_mfma_kernel<I, CGT, false>), grid, dim3 (MF_THREADS), 0, st, *a, *segs, g); } while (0)
+#define MF_GO(I, CGT) do { if (wide && CGT) hipLaunchKernelGGL ((fir_mfma_kernel<I, CGT, (CGT != 0), (CGT != 0 ? 2 : 1)>), grid, dim3 (2 * MF_THREADS), 0, st, *a, *segs, g); \
+                           else if (ws && CGT) hipLaunchKernelGGL ((fir_mfma_kernel<I, CGT, (CGT != 0), 1>), grid, dim3 (2 * MF_THREADS), 0, st, *a, *segs, g); \
+                           else hipLaunchKernelGGL ((fir_mfma_kernel<I, CGT, false, 1>), grid, dim3 (MF_THREADS), 0, st, *a, *segs, g); } while (0)
         if (a->interpolate) switch (cgt) { case 32: MF_GO (true, 32); break; case 16: MF_GO (true, 16); break; case 8: MF_GO (true, 8); break; case 4: MF_GO (true, 4); break; case 2: MF_GO (true, 2); break;
                                             case 1: MF_GO (true, 1); break; default: MF_GO (true, 0); }
         else                switch (cgt) { case 32: MF_GO (false, 32); break; case 16: MF_GO (false, 16); break; case 8: MF_GO (false, 8); break; case 4: MF_GO (false, 4); break; case 2: MF_GO (false, 2); break;
