@@ -460,7 +460,9 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
                 const double d = (double)(dip * a.F + dfi) + (p.frac - s_frac [i]);   // signed distance in filter steps
                 status = (d >= -MF_PHASE_TOL && d <= MF_PHASE_TOL) ? 0 : 1;
             }
-            else status = (dip == 0 && dfi == 0) ? 0 : 1;
+            // nearest-filter mode: (ip-1, fi=F) and (ip, fi=0) are the same position — row F is row 0 one tap later
+            // (resampler.c:156-168), so window and products are identical, as is the pass-through sample
+            else status = (dip * a.F + dfi == 0) ? 0 : 1;
             if (!INTERP && status == 0 && !a.lowpass && (p.fi % a.F) == 0) status = 3;
             if (status == 1) {
                 const unsigned int slot = atomicAdd (a.fix_count, 1u);

@@ -108,3 +108,58 @@ def test_random_session_precise_mode(seed):
     yo, _ = play(OracleResampler, s, PRECISE)
     d = np.abs(y.astype(np.float64) - yo.astype(np.float64))
     assert np.all(d <= np.spacing(np.abs(yo)).astype(np.float64) + 1e-45)       # <= 1 float ulp
+
+
+# ------------------------------------------------------------------------------------------------
+# less-travelled geometry: many channels (several column groups), maximum taps / filters, strong ratios
+# ------------------------------------------------------------------------------------------------
+EDGE_CASES = [
+    # (channels, taps, filters, src, dst, fixed, flags)
+    (12, 64, 64, 44100, 48000, False, BH | INTERP),          # generic column group (12 | 128 no)
+    (33, 48, 48, 44100, 48000, False, BH | INTERP),          # two channel groups (32 + 1)
+    (40, 156, 320, 96000, 44100, True, BH | INTERP | LOWPASS),
+    (64, 32, 16, 48000, 44100, True, BH | INTERP | LOWPASS),
+    (6, 1024, 1024, 44100, 48000, False, BH | INTERP),       # maximum taps and filters, 5.1 layout
+    (2, 1024, 1024, 192000, 44100, True, BH | INTERP | LOWPASS),    # P = 147, Q = 640: long input span per period
+    (2, 380, 380, 8000, 48000, True, BH | INTERP | LOWPASS),        # x6 upsampling, P = 6
+    (1, 156, 320, 44100, 8000, True, BH | INTERP | LOWPASS),        # P = 80, Q = 441
+    (4, 48, 48, 32000, 96000, True, INTERP | LOWPASS),              # Hann, x3
+    (16, 380, 380, 44100, 48000, False, BH | INTERP),               # compile-time CG = 16
+    (32, 156, 156, 44100, 48000, False, BH),                        # compile-time CG = 32, nearest filter
+]
+
+
+@pytest.mark.parametrize("case", EDGE_CASES, ids=lambda c: f"c{c[0]}_t{c[1]}_f{c[2]}_{c[3]}to{c[4]}{'_fixed' if c[5] else ''}")
+@pytest.mark.parametrize("kernel", [0, 2])
+def test_edge_geometries(case, kernel):
+    ch, T, F, src, dst, fixed, flags = case
+    ratio = dst / src
+    n1, n2 = 20 * T + 77, 9 * T + 5
+    x, _ = noise((n1 + n2) * ch, state=0xDEADBEEFCAFEF00D | 1)
+    x = x.reshape(-1, ch)
+
+    def make(cls, extra=0, **kw):
+        r = cls(ch, T, F, flags=flags | extra, fixed=(float(src), float(dst), 0), **kw) if fixed else cls(ch, T, F, 0.0, flags | extra, **kw)
+        r.advance(T / 2)
+        return r
+
+    def run(r):
+        outs, tr = [], []
+        for seg, cap in ((x[:n1], int(n1 * ratio) + 2 * T), (x[n1:], int(n2 * ratio) + 2 * T)):
+            u, g, y = r.process(seg, cap, 0.0 if fixed else ratio)
+            outs.append(y)
+            tr.append((u, g) + tuple(r.state())[:2])
+        u, g, y = r.process(None, 4 * T + int(T * ratio), ratio, flush=True)
+        outs.append(y)
+        tr.append((u, g) + tuple(r.state())[:2])
+        return np.concatenate(outs), tr
+
+    y, tr = run(make(HipResampler, kernel=kernel))
+    yo, tro = run(make(OracleResampler, PRECISE))
+    assert tr == tro
+    ok, worst, rms = tolerance_ok(y, yo)
+    assert ok, (worst, rms)
+    if kernel == 0:
+        ys, trs = run(make(HipResampler, STRICT))
+        yos, _ = run(make(OracleResampler))
+        assert np.array_equal(ys.view(np.uint32), yos.view(np.uint32))
