@@ -733,6 +733,10 @@ int launch_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st
     const int max_span = lds_budget / (4 * CG);
     int tile = (int) floor ((max_span - a.T - 3) * a.ratio);
     if (tile > GEN_MAX_TILE) tile = GEN_MAX_TILE;
+    // small calls: prefer many small tiles (each wave walks its tile's outputs serially, so latency ~ tile/4
+    // outputs) over staging efficiency, until there are about four workgroups per CU
+    const unsigned int total_outputs = a.n_end - a.n_begin;
+    while (tile > 4 && (total_outputs + tile - 1) / tile < 1024u) tile >>= 1;
     if (tile < 1 || from_list) tile = 1;
     long span = a.T + (long) ceil (tile / a.ratio) + 3;
     size_t lds = (size_t) span * CG * 4;
