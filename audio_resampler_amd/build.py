@@ -16,6 +16,8 @@ OUT = os.path.join(HERE, "libartamd.so")
 
 C_SOURCES = ["resampler_host.c", "pcm_host.c", "extrapolate_host.c"]
 HIP_SOURCES = ["device_rt.hip", "sinc_fir.hip", "pcm_kernels.hip"]
+# per-file extra flags (tried: -fno-slp-vectorize on pcm_kernels.hip — 10 % slower, so none)
+EXTRA_FLAGS = {}
 HEADERS = [os.path.join(CSRC, "art_internal.h")] + [os.path.join(INC, h) for h in ("art_hip.h", "resampler.h", "biquad.h", "decimator.h")]
 
 
@@ -44,7 +46,7 @@ def build(force=False, verbose=False):
         objs.append(o)
         if force or _stale(o, [s] + HEADERS):
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
-                   "-I", INC, "-I", CSRC, "-c", s, "-o", o]
+                   "-I", INC, "-I", CSRC, "-c", s, "-o", o] + EXTRA_FLAGS.get(src, [])
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

@@ -300,16 +300,21 @@ void biquad_order2_lds_kernel (Biquad *sections, int C, float *buf, int frames)
             int f = 0;
 
             // one step of the cascade.  S == 1: returns the finished sample.  S == 2: pushes x into section 1
-            // and returns the finished PREVIOUS sample (section 2 of the value carried from the last step)
-            auto advance = [&] (float x) -> float {
-                x4a = x3a; x3a = s1.x2; y4a = y3a; y3a = s1.y2;
+            // and returns the finished PREVIOUS sample (section 2 of the value carried from the last step).
+            // `mid_out` receives section 1's output (needed only for the history bookkeeping below).
+            auto advance = [&] (float x, float &mid_out) -> float {
                 const float mid = sec2_step (s1, x);
+                mid_out = mid;
                 if (S == 1) return mid;
-                x4b = x3b; x3b = s2.x2; y4b = y3b; y3b = s2.y2;
                 const float done = sec2_step (s2, carry);
                 carry = mid;
                 return done;
             };
+            // The state written back at the end holds the FOUR most recent inputs/outputs of each section while the
+            // recurrence only needs two; the 3rd/4th most recent are refreshed once per register block (or per
+            // sample in the short remainder loops) instead of being shifted along with every sample.
+            auto track1 = [&] (float x3, float x4, float y3, float y4) { x3a = x3; x4a = x4; y3a = y3; y4a = y4; };
+            auto track2 = [&] (float x3, float x4, float y3, float y4) { x3b = x3; x4b = x4; y3b = y3; y4b = y4; };
 
             if (S == 2 && !primed) {               // very first sample of the call: section 1 only
                 x4a = x3a; x3a = s1.x2; y4a = y3a; y3a = s1.y2;
@@ -317,23 +322,32 @@ void biquad_order2_lds_kernel (Biquad *sections, int C, float *buf, int frames)
                 primed = true; f = 1; p += Cg;
             }
             for (; f + UB <= nf; f += UB, p += UB * Cg) {
-                float x [UB], y [UB];
+                float x [UB], y [UB], mid [UB];
+                const float carry_in = carry, s2y1 = s2.y1, s2y2 = s2.y2, s2x1 = s2.x1, s2x2 = s2.x2;
 #pragma unroll
                 for (int u = 0; u < UB; ++u) x [u] = p [u * Cg];
 #pragma unroll
-                for (int u = 0; u < UB; ++u) y [u] = advance (x [u]);
+                for (int u = 0; u < UB; ++u) y [u] = advance (x [u], mid [u]);
+                // section 1 consumed x[0..7] and produced mid[0..7]: its 3rd/4th most recent are x[5],x[4] / mid[5],mid[4]
+                track1 (x [UB - 3], x [UB - 4], mid [UB - 3], mid [UB - 4]);
                 if (S == 1) {
 #pragma unroll
                     for (int u = 0; u < UB; ++u) p [u * Cg] = y [u];
                 }
-                else {                             // y[u] is the finished sample f+u-1
+                else {
+                    // section 2 consumed carry_in, mid[0..6] and produced y[0..7] (sample f+u-1)
+                    track2 (mid [UB - 4], mid [UB - 5], y [UB - 3], y [UB - 4]);
+                    (void) carry_in; (void) s2y1; (void) s2y2; (void) s2x1; (void) s2x2;
                     if (f > 0) p [-Cg] = y [0]; else tile [ST_CHUNK_FLOATS - 64 + tid] = y [0];
 #pragma unroll
                     for (int u = 1; u < UB; ++u) p [(u - 1) * Cg] = y [u];
                 }
             }
-            for (; f < nf; ++f, p += Cg) {         // remainder, one sample at a time
-                const float done = advance (*p);
+            for (; f < nf; ++f, p += Cg) {         // remainder, one sample at a time (per-sample bookkeeping)
+                float mid;
+                x4a = x3a; x3a = s1.x2; y4a = y3a; y3a = s1.y2;
+                if (S == 2) { x4b = x3b; x3b = s2.x2; y4b = y3b; y3b = s2.y2; }
+                const float done = advance (*p, mid);
                 if (S == 1) *p = done;
                 else if (f > 0) p [-Cg] = done;
                 else tile [ST_CHUNK_FLOATS - 64 + tid] = done;
