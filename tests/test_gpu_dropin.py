@@ -99,3 +99,29 @@ def test_art_cli_on_hip_library_writes_the_same_file_as_reference_art(tmp_path, 
         b1, b2 = f1.read(), f2.read()
     assert len(b1) == len(b2) and len(b1) > 10000
     assert b1 == b2, f"{sum(x != y for x, y in zip(b1, b2))} of {len(b1)} bytes differ"
+
+
+# ------------------------------------------------------------------------------------------------
+# tools/art_gpu.py: our own device-resident ART counterpart (ingest, biquads, resample, decimate all in HBM)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.skipif(not os.path.exists(ART_REF), reason="oracle/_ref/art_strict not built")
+@pytest.mark.parametrize("opts,rate_in,chans", [
+    ("-4 -r48000", 44100, 2), ("-3 -r44100 -p", 96000, 2), ("-2 -r48000 -o24 -d1 -n2", 44100, 1), ("-3 -r32000 -x -o8", 48000, 2),
+    ("-1 -r48000", 44100, 3),            # 48 filters < 160 phases: interpolation stays on; 3 channels => extensible header
+    ("-3 -r96000 -p -o24", 44100, 2),    # upsampling with the biquad POST-filter
+])
+def test_device_resident_art_tool_writes_the_same_file_as_reference_art(tmp_path, opts, rate_in, chans):
+    import sys
+    src = str(tmp_path / "in.wav")
+    _write_wav(src, rate_in, chans, 1.5)
+    out_ref, out_gpu = str(tmp_path / "ref.wav"), str(tmp_path / "gpu.wav")
+    r = subprocess.run([ART_REF] + opts.split() + ["-q", "-y", src, out_ref], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    tool = os.path.join(os.path.dirname(ORACLE_DIR), "tools", "art_gpu.py")
+    a = subprocess.run([sys.executable, tool] + opts.split() + ["-q", "-y", src, out_gpu], capture_output=True, text=True,
+                       env=dict(os.environ, ARTAMD_STRICT="1"), timeout=600)
+    assert a.returncode == 0, a.stderr[-2000:]
+    with open(out_ref, "rb") as f1, open(out_gpu, "rb") as f2:
+        b1, b2 = f1.read(), f2.read()
+    assert len(b1) == len(b2), (len(b1), len(b2))
+    assert b1 == b2, f"{sum(x != y for x, y in zip(b1, b2))} of {len(b1)} bytes differ (first at {next(i for i, (x, y) in enumerate(zip(b1, b2)) if x != y)})"

@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""art_gpu — sample-rate conversion of WAV files with every DSP stage resident on the MI355X.
+
+The counterpart of the reference's ART command line (reference art.c:96-1155) built on the
+device-pointer entry points of libartamd.so: the PCM bytes of a block are uploaded once, then
+
+    floatIntegersLEDevice -> [biquadBank x2, pre-filter] -> resampleProcessInterleavedDevice
+                          -> [biquadBank x2, post-filter] -> decimateProcessInterleavedLEDevice
+
+run back to back on one HIP stream and only the packed output bytes come back.  Block size, flag choices, the
+position advance and the output-length rule follow ART (art.c:717, 808-830, 849-874, 924, 933-1067), so with
+ARTAMD_STRICT=1 the output file is byte-identical to the reference tool's (tests/test_gpu_dropin.py).
+
+usage: art_gpu.py [-1|-2|-3|-4] [-r<Hz>] [-g<dB>] [-l<Hz>] [-f<n>] [-t<n>] [-o<bits>] [-d<0|1|2>] [-n<0..3>]
+                  [-a] [-b] [-h] [-e] [-p] [-x] [-y] [-q] in.wav out.wav
+"""
+import ctypes as C
+import math
+import os
+import struct
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+
+BLOCK = 16384                                   # frames per block (art.c:717)
+PRESETS = {"1": (48, 48), "2": (156, 320), "3": (380, 380), "4": (988, 988)}     # taps, filters (art.c:151-166)
+
+
+def read_wav(path):
+    """-> (rate, channels, bits, is_float, channel_mask, raw little-endian sample bytes)"""
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise SystemExit(f'"{path}" is not a valid .WAV file!')
+    pos, fmt, payload = 12, None, None
+    while pos + 8 <= len(data):
+        cid, size = data[pos:pos + 4], struct.unpack_from("<I", data, pos + 4)[0]
+        body = data[pos + 8:pos + 8 + size]
+        if cid == b"fmt ":
+            tag, ch, rate, _, align, bits = struct.unpack_from("<HHIIHH", body, 0)
+            # default speaker mask when the file does not carry one: front L/R (or centre) for <= 2 channels, the first
+            # `ch` positions up to 18 channels, "all" beyond (art.c:540-547)
+            mask, valid = (0x5 - ch) if ch <= 2 else ((1 << ch) - 1 if ch <= 18 else 0xFFFFFFFF), bits
+            if tag == 0xFFFE and size >= 40:
+                valid, mask, tag = struct.unpack_from("<HIH", body, 18)
+            fmt = (rate, ch, valid if valid else bits, tag == 3, mask, align // ch)
+        elif cid == b"data":
+            payload = body
+            break
+        pos += 8 + size + (size & 1)
+    if fmt is None or payload is None:
+        raise SystemExit(f'"{path}" is not a valid .WAV file!')
+    rate, ch, bits, is_float, mask, bytes_per = fmt
+    return rate, ch, bits, is_float, mask, bytes_per, payload
+
+
+def wav_header(bits, channels, frames, rate, mask):
+    """same layout decisions as the reference writer (art.c:1157-1215): plain header for mono/stereo with the default
+    mask, WAVE_FORMAT_EXTENSIBLE otherwise"""
+    bps = (bits + 7) // 8
+    fmt_tag = 3 if bits >= 32 else 1
+    data_bytes = frames * bps * channels
+    base = struct.pack("<HHIIHH", fmt_tag, channels, rate, rate * channels * bps, bps * channels, bits)
+    if channels > 2 or mask != 0x5 - channels:
+        guid = bytearray(14)
+        guid[4], guid[6], guid[9], guid[11], guid[12], guid[13] = 0x10, 0x80, 0xAA, 0x38, 0x9B, 0x71
+        base = struct.pack("<HHIIHH", 0xFFFE, channels, rate, rate * channels * bps, bps * channels, bits)
+        base += struct.pack("<HHIH", 22, bits, mask & 0xFFFFFFFF, fmt_tag) + bytes(guid)
+    riff_size = (12 + len(base) + 8 + data_bytes + 1) & ~1
+    return b"RIFF" + struct.pack("<I", riff_size) + b"WAVE" + b"fmt " + struct.pack("<I", len(base)) + base + \
+        b"data" + struct.pack("<I", data_bytes)
+
+
+def main(argv):
+    import torch
+    import audio_resampler_amd as A
+    L = A.lib()
+
+    taps, filters = PRESETS["3"]
+    rate_out = lowpass = outbits = 0
+    gain, phase = 1.0, 0.0
+    dither, shaping = A.DITHER_HIGHPASS, A.SHAPING_ATH_CURVE
+    bh = hann = allpass = extended = prepost = overwrite = quiet = False
+    extrapolate = True
+    files = []
+    for arg in argv:
+        if arg.startswith("-") and len(arg) > 1:
+            o, v = arg[1], arg[2:]
+            num = lambda: float(v[:-1]) * 1000 if v[-1:] in "kK" else float(v)
+            if o in PRESETS: taps, filters = PRESETS[o]
+            elif o == "r": rate_out = int(num())
+            elif o == "g": gain = 10.0 ** (float(v) / 20.0)
+            elif o == "s": phase = float(v) / 360.0
+            elif o == "l": lowpass = int(num())
+            elif o == "f": filters = int(v)
+            elif o == "t": taps = int(v)
+            elif o == "o": outbits = int(v)
+            elif o == "d": dither = {0: 0, 1: A.DITHER_FLAT, 2: A.DITHER_LOWPASS}[int(v)]
+            elif o == "n": shaping = {0: 0, 1: A.SHAPING_1ST_ORDER, 2: A.SHAPING_2ND_ORDER, 3: A.SHAPING_3RD_ORDER}[int(v)]
+            elif o == "a": allpass = True
+            elif o == "b": bh = True
+            elif o == "h": hann = True
+            elif o == "e": extended = True
+            elif o == "p": prepost = True
+            elif o == "x": extrapolate = False
+            elif o == "y": overwrite = True
+            elif o == "q": quiet = True
+            else: raise SystemExit(f"illegal option: {o} !")
+        else:
+            files.append(arg)
+    if len(files) != 2:
+        raise SystemExit(__doc__)
+    src, dst = files
+    if os.path.exists(dst) and not overwrite:
+        raise SystemExit(f"{dst} exists (use -y to overwrite)")
+
+    rate_in, ch, inbits, is_float, mask, in_bytes, payload = read_wav(src)
+    frames_in = len(payload) // (in_bytes * ch)
+    rate_out = rate_out or rate_in
+    outbits = outbits or inbits
+    out_bytes = (outbits + 7) // 8
+    ratio = rate_out / rate_in
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # ---- contexts (art.c:808-890)
+    rs = None
+    if filters and (ratio != 1.0 or lowpass or phase != 0.0):
+        flags = A.SUBSAMPLE_INTERPOLATE | A.INCLUDE_LOWPASS
+        if bh or not hann: flags |= A.BLACKMAN_HARRIS
+        if phase != 0.0: flags |= A.NO_FILTER_REDUCTION
+        if allpass: flags &= ~A.INCLUDE_LOWPASS
+        if extrapolate: flags |= A.EXTRAPOLATE_ENDPOINTS
+        if extended: flags |= A.EXTEND_CONVOLUTION_MATH
+        rs = A.Resampler(ch, taps, filters, flags=flags, fixed=(float(rate_in), float(rate_out), lowpass))
+        rs.set_stream(stream)
+        rs.advance(taps / 2.0 + phase)
+    pre = post = None
+    if prepost:
+        co = A.BiquadCoefficients()
+        cutoff = rate_out * 0.45 / rate_in if rate_out <= rate_in else rate_in * 0.45 / rate_out
+        L.biquad_lowpass(C.byref(co), cutoff)
+        secs = (A.Biquad * (ch * 2))()
+        for i in range(ch * 2):
+            L.biquad_init(C.byref(secs[i]), C.byref(co), 1.0)
+        bank = A.BiquadBank(secs, ch, 2)
+        bank.set_stream(stream)
+        pre, post = (bank, None) if rate_out <= rate_in else (None, bank)
+    dec = None
+    if outbits < 32:
+        dec = A.Decimator(ch, outbits, out_bytes, 1.0, rate_out, dither | shaping)
+        dec.set_stream(stream)
+
+    cap = int(math.floor((BLOCK + taps // 2) * ratio + 100.0))
+    target = int(math.floor(frames_in * ratio + 0.5))
+    d_raw = torch.empty(BLOCK * ch * in_bytes, dtype=torch.uint8, device="cuda")
+    d_in = torch.empty(BLOCK, ch, dtype=torch.float32, device="cuda")
+    d_out = torch.empty(cap, ch, dtype=torch.float32, device="cuda")
+    d_pcm = torch.empty(cap * ch * out_bytes, dtype=torch.uint8, device="cuda")
+    import numpy as np
+    raw = np.frombuffer(payload, dtype=np.uint8)
+
+    out_chunks, produced, pos = [], 0, 0
+    while produced < target:
+        n = min(BLOCK, frames_in - pos)
+        if n > 0:
+            nbytes = n * ch * in_bytes
+            d_raw[:nbytes].copy_(torch.from_numpy(raw[pos * ch * in_bytes:pos * ch * in_bytes + nbytes].copy()), non_blocking=True)
+            if inbits > 24:                     # 32-bit float input
+                d_in[:n].copy_(d_raw[:nbytes].view(torch.float32).view(n, ch))
+                if gain != 1.0:
+                    d_in[:n].mul_(np.float32(gain).item())
+            else:
+                L.floatIntegersLEDevice(d_raw.data_ptr(), gain, inbits, in_bytes, 1, d_in.data_ptr(), n * ch, stream)
+            pos += n
+            if pre is not None:
+                pre.apply_device(d_in, n)
+        if rs is not None:
+            _, made = rs.process_device(d_in if n > 0 else None, n if n > 0 else -1, d_out, cap, ratio)
+            if made == cap:
+                raise SystemExit("fatal error: outputbuffer too small!")
+            buf = d_out
+        else:
+            made, buf = n, d_in
+        if n <= 0 and made == 0:
+            break
+        if post is not None and made:
+            post.apply_device(buf, made)
+        made = min(made, target - produced)
+        if dec is not None:
+            dec.process_device(buf, made, d_pcm)
+            out_chunks.append(d_pcm[:made * ch * out_bytes].cpu().numpy().tobytes())
+        else:
+            out_chunks.append(buf[:made].contiguous().cpu().numpy().tobytes())
+        produced += made
+
+    body = b"".join(out_chunks)
+    with open(dst, "wb") as f:
+        f.write(wav_header(outbits, ch, produced, rate_out, mask))
+        f.write(body)
+        if len(body) & 1:
+            f.write(b"\0")
+    if not quiet:
+        clipped = dec.clipped() if dec is not None else 0
+        print(f"{produced} frames x {ch} ch written to {dst}" + (f"; {clipped} samples clipped" if clipped else ""), file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
