@@ -1,4 +1,7 @@
-"""Build libartamd.so (C host layer + gfx950 HIP kernels) in-tree.
+"""Build libartamd.so and libartamd64.so (C host layer + gfx950 HIP kernels) in-tree.
+
+libartamd64.so is the same source tree compiled with -DPATH_WIDTH=64 (double-precision samples, the
+reference's art64 / artest64 builds, reference Makefile:13/:19).
 
     python -m audio_resampler_amd.build        # or: from audio_resampler_amd.build import build; build()
 
@@ -13,6 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(os.path.dirname(HERE), "include")
 OUT = os.path.join(HERE, "libartamd.so")
+OUT64 = os.path.join(HERE, "libartamd64.so")
 
 C_SOURCES = ["resampler_host.c", "pcm_host.c", "extrapolate_host.c"]
 HIP_SOURCES = ["device_rt.hip", "sinc_fir.hip", "pcm_kernels.hip"]
@@ -29,15 +33,20 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=False):
+    build_one(OUT64, "_obj64", ["-DPATH_WIDTH=64"], force, verbose)
+    return build_one(OUT, "_obj", [], force, verbose)
+
+
+def build_one(out, objsub, defs, force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(HERE, "_obj")
+    objdir = os.path.join(HERE, objsub)
     os.makedirs(objdir, exist_ok=True)
     objs = []
     for src in C_SOURCES:
         s, o = os.path.join(CSRC, src), os.path.join(objdir, src + ".o")
         objs.append(o)
         if force or _stale(o, [s] + HEADERS):
-            cmd = ["gcc", "-std=c99", "-O2", "-ffp-contract=off", "-fPIC", "-Wall", "-I", INC, "-I", CSRC, "-c", s, "-o", o]
+            cmd = ["gcc", "-std=c99", "-O2", "-ffp-contract=off", "-fPIC", "-Wall", "-I", INC, "-I", CSRC, "-c", s, "-o", o] + defs
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
@@ -46,16 +55,16 @@ def build(force=False, verbose=False):
         objs.append(o)
         if force or _stale(o, [s] + HEADERS):
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
-                   "-I", INC, "-I", CSRC, "-c", s, "-o", o] + EXTRA_FLAGS.get(src, [])
+                   "-I", INC, "-I", CSRC, "-c", s, "-o", o] + defs + EXTRA_FLAGS.get(src, [])
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
-    if force or _stale(OUT, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-lm", "-lpthread"]
+    if force or _stale(out, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-lm", "-lpthread"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

@@ -7,6 +7,13 @@
 #include <stdint.h>
 #include "art_hip.h"
 
+#if defined(PATH_WIDTH) && (PATH_WIDTH==64)
+#define ART_WIDE 1          /* double-precision sample path: general + strict kernels only */
+#else
+#define ART_WIDE 0
+#endif
+typedef artsample_t art_s;   /* the sample type of this build */
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -29,11 +36,11 @@ typedef struct {
 } ArtSegTable;
 
 typedef struct {
-    const float *bank;                   /* device, (F+1) x T */
-    const float *hist;                   /* device, H frames x C, interleaved */
-    const float *in;                     /* device, new input frames */
+    const art_s *bank;                   /* device, (F+1) x T */
+    const art_s *hist;                   /* device, H frames x C, interleaved */
+    const art_s *in;                     /* device, new input frames */
     long in_pitch;                       /* 0: interleaved [frame][C]; else planar, channel c at in + c*in_pitch */
-    float *out;
+    art_s *out;
     long out_pitch;                      /* 0: interleaved; else planar */
     int in_frames;                       /* frames valid at `in` (reads beyond return 0) */
     int C, T, F, H;
@@ -72,32 +79,32 @@ float arthip_event_elapsed_ms (void *start, void *stop);   /* synchronises on `s
 /* returns the kernel actually used (ART_KERNEL_*), <0 on launch failure */
 int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, void *stream);
 /* new_hist[H][C] = last H frames of (hist ++ in[0..appended)); in may be NULL => zeros appended */
-int arthip_roll_history (float *new_hist, const float *hist, const float *in, long in_pitch, int appended, int H, int C, void *stream);
-int arthip_interleave (float *dst, const float *src_planar, long pitch, int frames, int C, void *stream);
-int arthip_deinterleave (float *dst_planar, long pitch, const float *src, int frames, int C, void *stream);
+int arthip_roll_history (art_s *new_hist, const art_s *hist, const art_s *in, long in_pitch, int appended, int H, int C, void *stream);
+int arthip_interleave (art_s *dst, const art_s *src_planar, long pitch, int frames, int C, void *stream);
+int arthip_deinterleave (art_s *dst_planar, long pitch, const art_s *src, int frames, int C, void *stream);
 
 /* ---- extrapolate_host.c (host, scalar) ---- */
-void art_extrapolate_forward (float *x, int count, int extra);
-void art_extrapolate_backward (const float *known_newest_last, int count, float *older_nearest_first, int extra);
+void art_extrapolate_forward (art_s *x, int count, int extra);
+void art_extrapolate_backward (const art_s *known_newest_last, int count, art_s *older_nearest_first, int extra);
 
 /* ---- pcm_kernels.hip ---- */
 typedef struct {
     int C, bits, bytes, dither_type, dither_on, shaping_on;
     int shaping_order;                   /* order of the error-feedback filter (same for every channel) */
-    float scale;
-    float *feedback;                     /* device [C] */
+    art_s scale;
+    art_s *feedback;                     /* device [C] */
     uint32_t *gens;                      /* device [C] */
     uint32_t *gens_next;                 /* device [C]: where the fully parallel kernel leaves the generator state */
     Biquad *shapers;                     /* device [C] */
     unsigned long long *clipped;         /* device counter */
 } ArtDecArgs;
 /* returns 1 when the generator state was written to a->gens_next (caller swaps), 0 otherwise, <0 on error */
-int arthip_decimate (const ArtDecArgs *a, const float *d_in, int frames, unsigned char *d_out, void *stream);
-int arthip_decimate_planar (const ArtDecArgs *a, const float *d_in, long in_pitch, int frames, unsigned char *d_out, long out_pitch, void *stream);
-int arthip_biquad_chain (Biquad *d_sections, int C, int S, float *d_buf, int frames, int stride, void *stream);
+int arthip_decimate (const ArtDecArgs *a, const art_s *d_in, int frames, unsigned char *d_out, void *stream);
+int arthip_decimate_planar (const ArtDecArgs *a, const art_s *d_in, long in_pitch, int frames, unsigned char *d_out, long out_pitch, void *stream);
+int arthip_biquad_chain (Biquad *d_sections, int C, int S, art_s *d_buf, int frames, int stride, void *stream);
 /* every section has order 2, S = 1 or 2, interleaved frames: hand-scheduled kernel */
-int arthip_biquad_order2 (Biquad *d_sections, int C, int S, float *d_buf, int frames, void *stream);
-int arthip_ingest (const unsigned char *d_in, float gain_factor, int bits, int bytes, int stride, float *d_out, int n, void *stream);
+int arthip_biquad_order2 (Biquad *d_sections, int C, int S, art_s *d_buf, int frames, void *stream);
+int arthip_ingest (const unsigned char *d_in, art_s gain_factor, int bits, int bytes, int stride, art_s *d_out, int n, void *stream);
 
 #ifdef __cplusplus
 }

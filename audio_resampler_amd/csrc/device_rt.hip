@@ -16,7 +16,7 @@ static int fail (hipError_t e, const char *what)
 extern "C" {
 
 const char *arthip_last_error (void) { return g_err; }
-const char *artamdVersion (void) { return "artamd 0.1 (gfx950)"; }
+const char *artamdVersion (void) { return ART_WIDE ? "artamd 0.1 (gfx950, 64-bit samples)" : "artamd 0.1 (gfx950)"; }
 
 int arthip_device_count (void)
 {

@@ -56,7 +56,7 @@ static void predictor_from_reflection (const double *refl, double *lpc)
 }
 
 /* fit coeffs[ORDER] so that x[n] ~ -(sum_c coeffs[ORDER-1-c] * x[n-ORDER+c]) */
-static void fit_predictor (const float *x, int count, float *coeffs)
+static void fit_predictor (const art_s *x, int count, float *coeffs)
 {
     const int evals = count - ORDER;
     double energy = 0.0, delta_energy = 0.0, best, step = 3.0 / (1 << 4);
@@ -66,7 +66,7 @@ static void fit_predictor (const float *x, int count, float *coeffs)
     memset (coeffs, 0, sizeof (float) * ORDER);
 
     for (int i = 0; i < evals; ++i) {
-        float d = x [i + ORDER] - x [i + ORDER - 1];
+        art_s d = x [i + ORDER] - x [i + ORDER - 1];
         delta_energy += d * d;
         energy += x [i + ORDER] * x [i + ORDER];
     }
@@ -143,15 +143,15 @@ static void fit_predictor (const float *x, int count, float *coeffs)
 }
 
 /* x[0..count) known; writes x[count .. count+extra) */
-void art_extrapolate_forward (float *x, int count, int extra)
+void art_extrapolate_forward (art_s *x, int count, int extra)
 {
     float coeffs [ORDER];
 
-    memset (x + count, 0, sizeof (float) * (size_t) extra);
+    memset (x + count, 0, sizeof (art_s) * (size_t) extra);
     fit_predictor (x, count, coeffs);
 
     for (int i = 0; i < extra; ++i) {
-        const float *tail = x + count - ORDER + i;
+        const art_s *tail = x + count - ORDER + i;
         double acc = 0.0;
         for (int c = 0; c < ORDER; ++c)
             acc += tail [c] * coeffs [ORDER - c - 1];
@@ -161,13 +161,13 @@ void art_extrapolate_forward (float *x, int count, int extra)
 
 /* newest-first view: known[0] is the most recent of `count` known samples going back in time;
  * fills older[0..extra) with the samples preceding them (older[0] closest in time) */
-void art_extrapolate_backward (const float *known_newest_last, int count, float *older_nearest_first, int extra)
+void art_extrapolate_backward (const art_s *known_newest_last, int count, art_s *older_nearest_first, int extra)
 {
-    float *rev = calloc ((size_t) count + extra, sizeof (float));
+    art_s *rev = calloc ((size_t) count + extra, sizeof (art_s));
 
     for (int i = 0; i < count; ++i)                            /* time-reverse: earliest known sample last */
         rev [i] = known_newest_last [count - 1 - i];
     art_extrapolate_forward (rev, count, extra);
-    memcpy (older_nearest_first, rev + count, sizeof (float) * (size_t) extra);
+    memcpy (older_nearest_first, rev + count, sizeof (art_s) * (size_t) extra);
     free (rev);
 }

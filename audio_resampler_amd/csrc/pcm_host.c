@@ -34,11 +34,11 @@ void biquad_lowpass (BiquadCoefficients *filter, double frequency)
     double K, norm, b1, b2;
     butterworth (frequency, &K, &norm, &b1, &b2);
     memset (filter, 0, sizeof (*filter));
-    filter->a0 = (float)(K * K * norm);
-    filter->a1 = (float)(2 * filter->a0);       /* doubled AFTER rounding to float (reference biquad.c:26) */
+    filter->a0 = (art_s)(K * K * norm);
+    filter->a1 = (art_s)(2 * filter->a0);       /* doubled AFTER rounding to art_s (reference biquad.c:26) */
     filter->a2 = filter->a0;
-    filter->b1 = (float) b1;
-    filter->b2 = (float) b2;
+    filter->b1 = (art_s) b1;
+    filter->b2 = (art_s) b2;
 }
 
 void biquad_highpass (BiquadCoefficients *filter, double frequency)
@@ -46,18 +46,18 @@ void biquad_highpass (BiquadCoefficients *filter, double frequency)
     double K, norm, b1, b2;
     butterworth (frequency, &K, &norm, &b1, &b2);
     memset (filter, 0, sizeof (*filter));
-    filter->a0 = (float) norm;
-    filter->a1 = (float)(-2.0 * norm);
+    filter->a0 = (art_s) norm;
+    filter->a1 = (art_s)(-2.0 * norm);
     filter->a2 = filter->a0;
-    filter->b1 = (float) b1;
-    filter->b2 = (float) b2;
+    filter->b1 = (art_s) b1;
+    filter->b2 = (art_s) b2;
 }
 
 void biquad_init (Biquad *f, const BiquadCoefficients *c, double gain)
 {
     memset (f, 0, sizeof (*f));
-    f->a [0] = (float)(c->a0 * gain); f->a [1] = (float)(c->a1 * gain); f->a [2] = (float)(c->a2 * gain);
-    f->a [3] = (float)(c->a3 * gain); f->a [4] = (float)(c->a4 * gain);
+    f->a [0] = (art_s)(c->a0 * gain); f->a [1] = (art_s)(c->a1 * gain); f->a [2] = (art_s)(c->a2 * gain);
+    f->a [3] = (art_s)(c->a3 * gain); f->a [4] = (art_s)(c->a4 * gain);
     f->b [1] = c->b1; f->b [2] = c->b2; f->b [3] = c->b3; f->b [4] = c->b4;
     f->order = (c->a4 != 0.0F || c->b4 != 0.0F) ? 4 : (c->a3 != 0.0F || c->b3 != 0.0F) ? 3 :
                (c->a2 != 0.0F || c->b2 != 0.0F) ? 2 : 1;
@@ -69,21 +69,21 @@ void biquad_init (Biquad *f, const BiquadCoefficients *c, double gain)
  * ---------------------------------------------------------------------------------------- */
 
 static pthread_mutex_t scratch_lock = PTHREAD_MUTEX_INITIALIZER;
-static float *scratch_buf; static size_t scratch_cap;
+static art_s *scratch_buf; static size_t scratch_cap;
 static Biquad *scratch_state;
 
 static int scratch_reserve (size_t samples)
 {
     if (!scratch_state && !(scratch_state = arthip_malloc (sizeof (Biquad)))) return -1;
-    if (samples * sizeof (float) > scratch_cap) {
+    if (samples * sizeof (art_s) > scratch_cap) {
         arthip_free (scratch_buf);
-        scratch_cap = samples * sizeof (float) * 2;
+        scratch_cap = samples * sizeof (art_s) * 2;
         if (!(scratch_buf = arthip_malloc (scratch_cap))) { scratch_cap = 0; return -1; }
     }
     return 0;
 }
 
-static void biquad_run_host (Biquad *f, float *buffer, int n, int stride, int sample_form)
+static void biquad_run_host (Biquad *f, art_s *buffer, int n, int stride, int sample_form)
 {
     if (n <= 0) return;
     const size_t span = (size_t)(n - 1) * stride + 1;
@@ -94,10 +94,10 @@ static void biquad_run_host (Biquad *f, float *buffer, int n, int stride, int sa
         pthread_mutex_unlock (&scratch_lock);
         abort ();
     }
-    arthip_h2d (scratch_buf, buffer, span * sizeof (float), NULL);
+    arthip_h2d (scratch_buf, buffer, span * sizeof (art_s), NULL);
     arthip_h2d (scratch_state, f, sizeof (Biquad), NULL);
     arthip_biquad_chain (scratch_state, 1, 1, scratch_buf, n, sample_form ? -stride : stride, NULL);
-    arthip_d2h (buffer, scratch_buf, span * sizeof (float), NULL);
+    arthip_d2h (buffer, scratch_buf, span * sizeof (art_s), NULL);
     arthip_d2h (f, scratch_state, sizeof (Biquad), NULL);
     arthip_sync (NULL);
     pthread_mutex_unlock (&scratch_lock);
@@ -167,10 +167,10 @@ void biquadBankFree (BiquadBank *b)
 
 struct artamd_decimator {
     void *stream;
-    float *d_feedback; uint32_t *d_gens, *d_gens_alt; Biquad *d_shapers;
+    art_s *d_feedback; uint32_t *d_gens, *d_gens_alt; Biquad *d_shapers;
     unsigned long long *d_clipped;
     unsigned long long clipped_seen;
-    float *d_in; size_t in_cap;
+    art_s *d_in; size_t in_cap;
     unsigned char *d_out; size_t out_cap;
 };
 
@@ -179,8 +179,8 @@ static void shaper_design (Biquad *f, double a1, double a2, double a3, double a4
 {
     BiquadCoefficients c;
     memset (&c, 0, sizeof (c));
-    c.a0 = (float)(b1 - a1); c.a1 = (float)(b2 - a2); c.a2 = (float)(b3 - a3); c.a3 = (float)(b4 - a4);
-    c.b1 = (float) b1; c.b2 = (float) b2; c.b3 = (float) b3; c.b4 = (float) b4;
+    c.a0 = (art_s)(b1 - a1); c.a1 = (art_s)(b2 - a2); c.a2 = (art_s)(b3 - a3); c.a3 = (art_s)(b4 - a4);
+    c.b1 = (art_s) b1; c.b2 = (art_s) b2; c.b3 = (art_s) b3; c.b4 = (art_s) b4;
     biquad_init (f, &c, 1.0);
 }
 
@@ -221,10 +221,10 @@ Decimate *decimateInit (int numChannels, int outputBits, int outputBytes, double
     cxt->hip = hip;
     cxt->numChannels = C; cxt->outputBits = outputBits; cxt->outputBytes = outputBytes;
     cxt->outputGain = outputGain; cxt->flags = flags;
-    cxt->feedback = calloc (C, sizeof (float));
-    hip->d_feedback = arthip_malloc (sizeof (float) * C);
+    cxt->feedback = calloc (C, sizeof (art_s));
+    hip->d_feedback = arthip_malloc (sizeof (art_s) * C);
     hip->d_clipped = arthip_malloc (sizeof (unsigned long long));
-    arthip_zero (hip->d_feedback, sizeof (float) * C, NULL);
+    arthip_zero (hip->d_feedback, sizeof (art_s) * C, NULL);
     arthip_zero (hip->d_clipped, sizeof (unsigned long long), NULL);
 
     if (flags & DITHER_ENABLED) {
@@ -281,7 +281,7 @@ static void dec_args (Decimate *cxt, ArtDecArgs *a)
     a->dither_on = (cxt->flags & DITHER_ENABLED) != 0;
     a->shaping_on = (cxt->flags & SHAPING_ENABLED) != 0;
     a->shaping_order = (a->shaping_on && cxt->noise_shapers) ? cxt->noise_shapers [0].order : 0;
-    a->scale = (float)((1 << cxt->outputBits) / 2.0 * cxt->outputGain);
+    a->scale = (art_s)((1 << cxt->outputBits) / 2.0 * cxt->outputGain);
     a->feedback = hip->d_feedback; a->gens = hip->d_gens; a->gens_next = hip->d_gens_alt; a->shapers = hip->d_shapers; a->clipped = hip->d_clipped;
 }
 
@@ -323,7 +323,7 @@ static int dec_finish (Decimate *cxt)
     unsigned long long total = 0;
 
     arthip_d2h (&total, hip->d_clipped, sizeof (total), hip->stream);
-    arthip_d2h (cxt->feedback, hip->d_feedback, sizeof (float) * C, hip->stream);
+    arthip_d2h (cxt->feedback, hip->d_feedback, sizeof (art_s) * C, hip->stream);
     if (cxt->tpdf_generators) arthip_d2h (cxt->tpdf_generators, hip->d_gens, sizeof (uint32_t) * C, hip->stream);
     if (cxt->noise_shapers) arthip_d2h (cxt->noise_shapers, hip->d_shapers, sizeof (Biquad) * C, hip->stream);
     arthip_sync (hip->stream);
@@ -340,12 +340,12 @@ int decimateProcessInterleavedLE (Decimate *cxt, const artsample_t *input, int n
     const size_t samples = (size_t) numInputFrames * cxt->numChannels;
     ArtDecArgs a;
 
-    if (dec_reserve (cxt, samples * sizeof (float), samples * cxt->outputBytes)) {
+    if (dec_reserve (cxt, samples * sizeof (art_s), samples * cxt->outputBytes)) {
         fprintf (stderr, "artamd: decimator device allocation failed: %s\n", arthip_last_error ());
         return 0;
     }
     dec_args (cxt, &a);
-    arthip_h2d (hip->d_in, input, samples * sizeof (float), hip->stream);
+    arthip_h2d (hip->d_in, input, samples * sizeof (art_s), hip->stream);
     dec_swap_if (cxt, arthip_decimate (&a, hip->d_in, numInputFrames, hip->d_out, hip->stream));
     arthip_d2h (output, hip->d_out, samples * cxt->outputBytes, hip->stream);
     return dec_finish (cxt);
@@ -359,13 +359,13 @@ int decimateProcessLE (Decimate *cxt, const artsample_t *const *input, int numIn
     const size_t n = (size_t) numInputFrames, plane_bytes = n * cxt->outputBytes;
     ArtDecArgs a;
 
-    if (dec_reserve (cxt, n * C * sizeof (float), plane_bytes * C)) {
+    if (dec_reserve (cxt, n * C * sizeof (art_s), plane_bytes * C)) {
         fprintf (stderr, "artamd: decimator device allocation failed: %s\n", arthip_last_error ());
         return 0;
     }
     dec_args (cxt, &a);
     for (int c = 0; c < C; ++c)
-        arthip_h2d (hip->d_in + n * c, input [c], n * sizeof (float), hip->stream);
+        arthip_h2d (hip->d_in + n * c, input [c], n * sizeof (art_s), hip->stream);
     arthip_decimate_planar (&a, hip->d_in, (long) n, numInputFrames, hip->d_out, (long) plane_bytes, hip->stream);
     for (int c = 0; c < C; ++c)
         arthip_d2h (output [c], hip->d_out + plane_bytes * c, plane_bytes, hip->stream);
@@ -376,9 +376,9 @@ int decimateProcessLE (Decimate *cxt, const artsample_t *const *input, int numIn
  * Integer -> float ingest
  * ---------------------------------------------------------------------------------------- */
 
-static float ingest_gain (double gain, int bits)
+static art_s ingest_gain (double gain, int bits)
 {
-    return bits <= 8 ? (float)(gain / 128.0) : bits <= 16 ? (float)(gain / 32768.0) : (float)(gain / 8388608.0);
+    return bits <= 8 ? (art_s)(gain / 128.0) : bits <= 16 ? (art_s)(gain / 32768.0) : (art_s)(gain / 8388608.0);
 }
 
 void floatIntegersLEDevice (const unsigned char *d_input, double inputGain, int inputBits, int inputBytes, int inputStride,
@@ -393,7 +393,7 @@ void floatIntegersLE (unsigned char *input, double inputGain, int inputBits, int
     if (numSamples <= 0 || inputBits > 24) return;
     const size_t in_bytes = (size_t) numSamples * inputStride * inputBytes;
     unsigned char *d_in = arthip_malloc (in_bytes);
-    float *d_out = arthip_malloc (sizeof (float) * (size_t) numSamples);
+    art_s *d_out = arthip_malloc (sizeof (art_s) * (size_t) numSamples);
 
     if (!d_in || !d_out) {
         fprintf (stderr, "artamd: floatIntegersLE needs a HIP device (no CPU path): %s\n", arthip_last_error ());
@@ -403,7 +403,7 @@ void floatIntegersLE (unsigned char *input, double inputGain, int inputBits, int
     const size_t valid = in_bytes - (size_t)(inputStride - 1) * inputBytes;
     arthip_h2d (d_in, input, valid, NULL);
     floatIntegersLEDevice (d_in, inputGain, inputBits, inputBytes, inputStride, d_out, numSamples, NULL);
-    arthip_d2h (output, d_out, sizeof (float) * (size_t) numSamples, NULL);
+    arthip_d2h (output, d_out, sizeof (art_s) * (size_t) numSamples, NULL);
     arthip_sync (NULL);
     arthip_free (d_in); arthip_free (d_out);
 }

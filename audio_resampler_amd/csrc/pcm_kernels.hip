@@ -14,8 +14,8 @@
 namespace {
 
 struct SectionRegs {
-    float a [5], b [5];
-    float x [4], y [4];       // x[0] = most recent input, x[1] the one before, ...
+    art_s a [5], b [5];
+    art_s x [4], y [4];       // x[0] = most recent input, x[1] the one before, ...
     int order;
 };
 
@@ -40,22 +40,22 @@ __device__ __forceinline__ void store_section (Biquad &f, const SectionRegs &r, 
     f.index = i;
 }
 
-__device__ __forceinline__ void push (SectionRegs &r, float in, float out)
+__device__ __forceinline__ void push (SectionRegs &r, art_s in, art_s out)
 {
     r.x [3] = r.x [2]; r.x [2] = r.x [1]; r.x [1] = r.x [0]; r.x [0] = in;
     r.y [3] = r.y [2]; r.y [2] = r.y [1]; r.y [1] = r.y [0]; r.y [0] = out;
 }
 
 // buffer form: in*a0, then for k = 1..order: + x_k*a_k, - b_k*y_k, strictly left to right
-__device__ __forceinline__ float step_buffer_order (SectionRegs &r, float in)
+__device__ __forceinline__ art_s step_buffer_order (SectionRegs &r, art_s in)
 {
-    float acc = in * r.a [0];
+    art_s acc = in * r.a [0];
 #pragma unroll
     for (int k = 1; k <= 4; ++k)
         if (k <= r.order) {
-            float fwd = r.x [k - 1] * r.a [k];
+            art_s fwd = r.x [k - 1] * r.a [k];
             acc = acc + fwd;
-            float back = r.b [k] * r.y [k - 1];
+            art_s back = r.b [k] * r.y [k - 1];
             acc = acc - back;
         }
     push (r, in, acc);
@@ -63,15 +63,15 @@ __device__ __forceinline__ float step_buffer_order (SectionRegs &r, float in)
 }
 
 // per-sample form: in*a0, then for k = order..1: += (x_k*a_k - b_k*y_k)
-__device__ __forceinline__ float step_sample_order (SectionRegs &r, float in)
+__device__ __forceinline__ art_s step_sample_order (SectionRegs &r, art_s in)
 {
-    float acc = in * r.a [0];
+    art_s acc = in * r.a [0];
 #pragma unroll
     for (int k = 4; k >= 1; --k)
         if (k <= r.order) {
-            float fwd = r.x [k - 1] * r.a [k];
-            float back = r.b [k] * r.y [k - 1];
-            float term = fwd - back;
+            art_s fwd = r.x [k - 1] * r.a [k];
+            art_s back = r.b [k] * r.y [k - 1];
+            art_s term = fwd - back;
             acc = acc + term;
         }
     push (r, in, acc);
@@ -80,7 +80,7 @@ __device__ __forceinline__ float step_sample_order (SectionRegs &r, float in)
 
 constexpr int MAX_CHAIN = 4;
 
-__global__ void biquad_chain_kernel (Biquad *sections, int C, int S, float *buf, int frames, int stride, int sample_form)
+__global__ void biquad_chain_kernel (Biquad *sections, int C, int S, art_s *buf, int frames, int stride, int sample_form)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -90,9 +90,9 @@ __global__ void biquad_chain_kernel (Biquad *sections, int C, int S, float *buf,
     for (int s = 0; s < MAX_CHAIN; ++s)
         if (s < S) load_section (r [s], sections [(size_t) c * S + s]);
 
-    float *p = buf + c;
+    art_s *p = buf + c;
     for (int i = 0; i < frames; ++i, p += stride) {
-        float v = *p;
+        art_s v = *p;
 #pragma unroll
         for (int s = 0; s < MAX_CHAIN; ++s)
             if (s < S) v = sample_form ? step_sample_order (r [s], v) : step_buffer_order (r [s], v);
@@ -106,12 +106,12 @@ __global__ void biquad_chain_kernel (Biquad *sections, int C, int S, float *buf,
 
 __device__ __forceinline__ uint32_t lcg (uint32_t r) { return ((r << 4) - r) ^ 1u; }
 
-__global__ void decimate_kernel (ArtDecArgs a, const float *in, long in_pitch, int frames, unsigned char *out, long out_pitch)
+__global__ void decimate_kernel (ArtDecArgs a, const art_s *in, long in_pitch, int frames, unsigned char *out, long out_pitch)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.C) return;
 
-    float fb = a.feedback [c];
+    art_s fb = a.feedback [c];
     uint32_t gen = a.dither_on ? a.gens [c] : 0u;
     SectionRegs sh;
     if (a.shaping_on) load_section (sh, a.shapers [c]);
@@ -123,8 +123,8 @@ __global__ void decimate_kernel (ArtDecArgs a, const float *in, long in_pitch, i
     unsigned long long clips = 0;
 
     for (int i = 0; i < frames; ++i) {
-        const float s = in_pitch ? in [(size_t) c * in_pitch + i] : in [(size_t) i * a.C + c];
-        float dither = 0.0f;
+        const art_s s = in_pitch ? in [(size_t) c * in_pitch + i] : in [(size_t) i * a.C + c];
+        art_s dither = 0.0f;
 
         if (a.dither_on) {
             const uint32_t start = gen;
@@ -133,16 +133,16 @@ __global__ void decimate_kernel (ArtDecArgs a, const float *in, long in_pitch, i
             r = lcg (lcg (lcg (r)));
             gen = r;
             const double tri = ((double)((first >> 1) + (r >> 1)) / 2147483648.0) - 1.0;
-            dither = (float) tri;
+            dither = (art_s) tri;
         }
 
-        const float scaled = s * a.scale;
-        const float code = scaled - fb;
-        const float dithered = code + dither;
+        const art_s scaled = s * a.scale;
+        const art_s code = scaled - fb;
+        const art_s dithered = code + dither;
         int q = (int) floor ((double) dithered + 0.5);
 
         if (a.shaping_on) {
-            const float err = (float) q - code;
+            const art_s err = (art_s) q - code;
             fb = step_sample_order (sh, err);
         }
 
@@ -172,12 +172,12 @@ __global__ void decimate_kernel (ArtDecArgs a, const float *in, long in_pitch, i
 // Algorithmic HBM bytes per sample: biquad 8 (in-place), decimator 4 + output bytes.
 // ---------------------------------------------------------------------------------------------------
 constexpr int ST_THREADS = 256;
-constexpr int ST_CHUNK_FLOATS = 8192;            // 32 KiB of samples per chunk
+constexpr int ST_CHUNK_FLOATS = ART_WIDE ? 4096 : 8192;   // 32 KiB of samples per chunk
 
 __global__ __launch_bounds__ (ST_THREADS)
-void biquad_chain_lds_kernel (Biquad *sections, int C, int S, float *buf, int frames)
+void biquad_chain_lds_kernel (Biquad *sections, int C, int S, art_s *buf, int frames)
 {
-    __shared__ __attribute__ ((aligned (16))) float tile [ST_CHUNK_FLOATS];
+    __shared__ __attribute__ ((aligned (16))) art_s tile [ST_CHUNK_FLOATS];
     const int tid = threadIdx.x;
     const int c0 = blockIdx.x * 64, Cg = min (64, C - c0);          // this block's channel group
     const int chunk_frames = ST_CHUNK_FLOATS / Cg;
@@ -198,9 +198,9 @@ void biquad_chain_lds_kernel (Biquad *sections, int C, int S, float *buf, int fr
         }
         __syncthreads ();
         if (tid < Cg) {
-            float *p = tile + tid;
+            art_s *p = tile + tid;
             for (int f = 0; f < nf; ++f, p += Cg) {
-                float v = *p;
+                art_s v = *p;
 #pragma unroll
                 for (int s = 0; s < MAX_CHAIN; ++s)
                     if (s < S) v = step_buffer_order (r [s], v);
@@ -229,16 +229,16 @@ void biquad_chain_lds_kernel (Biquad *sections, int C, int S, float *buf, int fr
 // Only b1*y1 and the three adds after it depend on the previous output, so everything else is issued
 // ahead; with two sections the second runs one sample behind the first in the same lane, which gives the
 // scheduler two independent dependency chains to interleave.
-struct Sec2 { float a0, a1, a2, b1, b2, x1, x2, y1, y2; };
+struct Sec2 { art_s a0, a1, a2, b1, b2, x1, x2, y1, y2; };
 
-__device__ __forceinline__ float sec2_step (Sec2 &s, float x)
+__device__ __forceinline__ art_s sec2_step (Sec2 &s, art_s x)
 {
-    const float p0 = x * s.a0, p1 = s.x1 * s.a1, p3 = s.x2 * s.a2, p4 = s.b2 * s.y2;
-    const float u = p0 + p1;
-    const float m = s.b1 * s.y1;
-    const float t2 = u - m;
-    const float t3 = t2 + p3;
-    const float y = t3 - p4;
+    const art_s p0 = x * s.a0, p1 = s.x1 * s.a1, p3 = s.x2 * s.a2, p4 = s.b2 * s.y2;
+    const art_s u = p0 + p1;
+    const art_s m = s.b1 * s.y1;
+    const art_s t2 = u - m;
+    const art_s t3 = t2 + p3;
+    const art_s y = t3 - p4;
     s.x2 = s.x1; s.x1 = x; s.y2 = s.y1; s.y1 = y;
     return y;
 }
@@ -252,7 +252,7 @@ __device__ __forceinline__ void sec2_load (Sec2 &s, const Biquad &f)
 
 // x[] / y[] hold the four most recent values; only two are live in an order-2 section, the other two
 // slots must end up holding what the reference's circular buffer would hold (the 3rd/4th most recent)
-__device__ __forceinline__ void sec2_store (Biquad &f, const Sec2 &s, float x3, float x4, float y3, float y4, int steps)
+__device__ __forceinline__ void sec2_store (Biquad &f, const Sec2 &s, art_s x3, art_s x4, art_s y3, art_s y4, int steps)
 {
     const int i = f.index + steps;
     f.x [i & 3] = s.x1; f.x [(i - 1) & 3] = s.x2; f.x [(i - 2) & 3] = x3; f.x [(i - 3) & 3] = x4;
@@ -262,17 +262,17 @@ __device__ __forceinline__ void sec2_store (Biquad &f, const Sec2 &s, float x3, 
 
 template <int S>                                   // S = 1 or 2 order-2 sections per channel
 __global__ __launch_bounds__ (ST_THREADS)
-void biquad_order2_lds_kernel (Biquad *sections, int C, float *buf, int frames)
+void biquad_order2_lds_kernel (Biquad *sections, int C, art_s *buf, int frames)
 {
-    __shared__ __attribute__ ((aligned (16))) float tile [ST_CHUNK_FLOATS];
+    __shared__ __attribute__ ((aligned (16))) art_s tile [ST_CHUNK_FLOATS];
     const int tid = threadIdx.x;
     const int c0 = blockIdx.x * 64, Cg = min (64, C - c0);
     const int chunk_frames = (ST_CHUNK_FLOATS - 64) / Cg;          // last 64 floats: cross-chunk hand-over slot
 
     Sec2 s1, s2;
     // the 3rd/4th most recent inputs/outputs of each section (kept only to write the state back faithfully)
-    float x3a = 0, x4a = 0, y3a = 0, y4a = 0, x3b = 0, x4b = 0, y3b = 0, y4b = 0;
-    float carry = 0.0f;                            // output of section 1 waiting for section 2 (skew of one sample)
+    art_s x3a = 0, x4a = 0, y3a = 0, y4a = 0, x3b = 0, x4b = 0, y3b = 0, y4b = 0;
+    art_s carry = 0.0f;                            // output of section 1 waiting for section 2 (skew of one sample)
     if (tid < Cg) {
         const Biquad &f1 = sections [(size_t)(c0 + tid) * S];
         sec2_load (s1, f1);
@@ -296,25 +296,25 @@ void biquad_order2_lds_kernel (Biquad *sections, int C, float *buf, int frames)
             // register blocks of 8 samples: the LDS reads of a block are issued together, ahead of the
             // recurrence, and its writes after it, so LDS latency is off the loop-carried path
             constexpr int UB = 8;
-            float *p = tile + tid;
+            art_s *p = tile + tid;
             int f = 0;
 
             // one step of the cascade.  S == 1: returns the finished sample.  S == 2: pushes x into section 1
             // and returns the finished PREVIOUS sample (section 2 of the value carried from the last step).
             // `mid_out` receives section 1's output (needed only for the history bookkeeping below).
-            auto advance = [&] (float x, float &mid_out) -> float {
-                const float mid = sec2_step (s1, x);
+            auto advance = [&] (art_s x, art_s &mid_out) -> art_s {
+                const art_s mid = sec2_step (s1, x);
                 mid_out = mid;
                 if (S == 1) return mid;
-                const float done = sec2_step (s2, carry);
+                const art_s done = sec2_step (s2, carry);
                 carry = mid;
                 return done;
             };
             // The state written back at the end holds the FOUR most recent inputs/outputs of each section while the
             // recurrence only needs two; the 3rd/4th most recent are refreshed once per register block (or per
             // sample in the short remainder loops) instead of being shifted along with every sample.
-            auto track1 = [&] (float x3, float x4, float y3, float y4) { x3a = x3; x4a = x4; y3a = y3; y4a = y4; };
-            auto track2 = [&] (float x3, float x4, float y3, float y4) { x3b = x3; x4b = x4; y3b = y3; y4b = y4; };
+            auto track1 = [&] (art_s x3, art_s x4, art_s y3, art_s y4) { x3a = x3; x4a = x4; y3a = y3; y4a = y4; };
+            auto track2 = [&] (art_s x3, art_s x4, art_s y3, art_s y4) { x3b = x3; x4b = x4; y3b = y3; y4b = y4; };
 
             if (S == 2 && !primed) {               // very first sample of the call: section 1 only
                 x4a = x3a; x3a = s1.x2; y4a = y3a; y3a = s1.y2;
@@ -322,8 +322,8 @@ void biquad_order2_lds_kernel (Biquad *sections, int C, float *buf, int frames)
                 primed = true; f = 1; p += Cg;
             }
             for (; f + UB <= nf; f += UB, p += UB * Cg) {
-                float x [UB], y [UB], mid [UB];
-                const float carry_in = carry, s2y1 = s2.y1, s2y2 = s2.y2, s2x1 = s2.x1, s2x2 = s2.x2;
+                art_s x [UB], y [UB], mid [UB];
+                const art_s carry_in = carry, s2y1 = s2.y1, s2y2 = s2.y2, s2x1 = s2.x1, s2x2 = s2.x2;
 #pragma unroll
                 for (int u = 0; u < UB; ++u) x [u] = p [u * Cg];
 #pragma unroll
@@ -344,10 +344,10 @@ void biquad_order2_lds_kernel (Biquad *sections, int C, float *buf, int frames)
                 }
             }
             for (; f < nf; ++f, p += Cg) {         // remainder, one sample at a time (per-sample bookkeeping)
-                float mid;
+                art_s mid;
                 x4a = x3a; x3a = s1.x2; y4a = y3a; y3a = s1.y2;
                 if (S == 2) { x4b = x3b; x3b = s2.x2; y4b = y3b; y3b = s2.y2; }
-                const float done = advance (*p, mid);
+                const art_s done = advance (*p, mid);
                 if (S == 1) *p = done;
                 else if (f > 0) p [-Cg] = done;
                 else tile [ST_CHUNK_FLOATS - 64 + tid] = done;
@@ -384,13 +384,13 @@ void biquad_order2_lds_kernel (Biquad *sections, int C, float *buf, int frames)
 //     acc = in*a0;  for k = ORDER..1:  acc += (x_k*a_k) - (b_k*y_k)
 // x_k / y_k for k >= 2 do not depend on the newest output, so those terms are formed ahead of the chain.
 template <int ORDER>
-__device__ __forceinline__ float shaper_step (SectionRegs &r, float in)
+__device__ __forceinline__ art_s shaper_step (SectionRegs &r, art_s in)
 {
-    float term [4];
+    art_s term [4];
 #pragma unroll
     for (int k = 1; k <= 4; ++k)
-        if (k <= ORDER) { const float fwd = r.x [k - 1] * r.a [k]; const float back = r.b [k] * r.y [k - 1]; term [k - 1] = fwd - back; }
-    float acc = in * r.a [0];
+        if (k <= ORDER) { const art_s fwd = r.x [k - 1] * r.a [k]; const art_s back = r.b [k] * r.y [k - 1]; term [k - 1] = fwd - back; }
+    art_s acc = in * r.a [0];
 #pragma unroll
     for (int k = 4; k >= 1; --k)
         if (k <= ORDER) acc = acc + term [k - 1];
@@ -428,21 +428,35 @@ __device__ __forceinline__ uint32_t jump_pairs (uint32_t g, unsigned int pairs) 
     return acc.a * g + acc.b;
 }
 
-constexpr int DEC_CHUNK = 4096;                    // samples per chunk (16 KiB of float each for data and dither)
+constexpr int DEC_CHUNK = ART_WIDE ? 2048 : 4096;                    // samples per chunk (16 KiB each for data and dither)
+// floor (d + 0.5) as the reference evaluates it (decimator.c:262).  4-byte samples: the reference widens d to
+// double first, so the sum is exact, and floor ((double) d + 0.5) == floorf (d) + (d - floorf (d) >= 0.5f)
+// (d - floorf (d) is exact in float) — no double-rate instructions on the serial path.  8-byte samples: the
+// reference's own sum rounds (e.g. d = 0.5 - 2^-54 gives 1), so it is evaluated literally.
+__device__ __forceinline__ art_s round_half_up (art_s d)
+{
+#if ART_WIDE
+    return floor (d + 0.5);
+#else
+    const float base = floorf (d);
+    return (d - base) >= 0.5f ? base + 1.0f : base;
+#endif
+}
+
 constexpr int DEC_SEG = 32;                        // consecutive samples of one channel per dither task (even)
 
 template <int ORDER, bool DITHER>                  // ORDER 0 = no noise shaping
 __global__ __launch_bounds__ (ST_THREADS)
-void decimate_lds_kernel (ArtDecArgs a, const float *in, int frames, unsigned char *out)
+void decimate_lds_kernel (ArtDecArgs a, const art_s *in, int frames, unsigned char *out)
 {
-    __shared__ __attribute__ ((aligned (16))) float tile [DEC_CHUNK];          // input, then the rounded code values
-    __shared__ __attribute__ ((aligned (16))) float dth [DITHER ? DEC_CHUNK : 1];
+    __shared__ __attribute__ ((aligned (16))) art_s tile [DEC_CHUNK];          // input, then the rounded code values
+    __shared__ __attribute__ ((aligned (16))) art_s dth [DITHER ? DEC_CHUNK : 1];
     __shared__ uint32_t s_gen [64], s_next [64];   // generator state at the start of this / the next chunk
     const int tid = threadIdx.x;
     const int c0 = blockIdx.x * 64, Cg = min (64, a.C - c0);
     const int chunk_frames = (DEC_CHUNK / Cg) & ~1;                            // even: chunk boundaries keep generator parity
 
-    float fb = 0.0f; SectionRegs sh; unsigned long long clips = 0;
+    art_s fb = 0.0f; SectionRegs sh; unsigned long long clips = 0;
     if (tid < Cg) {
         fb = a.feedback [c0 + tid];
         if (DITHER) s_gen [tid] = a.gens [c0 + tid];
@@ -453,7 +467,7 @@ void decimate_lds_kernel (ArtDecArgs a, const float *in, int frames, unsigned ch
     const int shift = (24 - a.bits) % 8;
     const uint32_t bias = a.bits <= 8 ? 128u : 0u;
     const int dtype = a.dither_type;
-    const float scale = a.scale;
+    const art_s scale = a.scale;
     __syncthreads ();
 
     for (int f0 = 0; f0 < frames; f0 += chunk_frames) {
@@ -476,44 +490,40 @@ void decimate_lds_kernel (ArtDecArgs a, const float *in, int frames, unsigned ch
                     const uint32_t first = dtype < 0 ? ~start : dtype > 0 ? start : ~r;
                     r = lcg (lcg (lcg (r)));
                     g = r;
-                    // ((first>>1)+(r>>1))/2^31 - 1.0, converted to float, is exactly this (power-of-two scale)
+                    // ((first>>1)+(r>>1))/2^31 - 1.0, converted to the sample type, is exactly this (power-of-two scale)
                     const uint32_t u = (first >> 1) + (r >> 1);
-                    dth [(n0 + i) * Cg + c] = (float)(int)(u ^ 0x80000000u) * 4.656612873077392578125e-10f;
+                    dth [(n0 + i) * Cg + c] = (art_s)(int)(u ^ 0x80000000u) * (art_s) 4.656612873077392578125e-10;
                 }
                 if (n0 + cnt == nf) s_next [c] = g;          // the channel's last task publishes the next chunk's state
             }
         }
         __syncthreads ();
 
-        // ---- phase B: rounding.  floor ((double) d + 0.5) == floorf (d) + (d - floorf (d) >= 0.5f) exactly
-        // (d - floorf (d) is exact in float).  Without noise shaping the feedback term never changes, so there is
+        // ---- phase B: rounding (round_half_up).  Without noise shaping the feedback term never changes, so there is
         // no recurrence and every thread rounds its own samples; with shaping one lane per channel walks time.
         if (!ORDER) {
             for (int e = tid; e < nf * Cg; e += ST_THREADS) {
                 const int c = e % Cg;
-                const float code = tile [e] * scale - a.feedback [c0 + c];
-                const float dithered = code + (DITHER ? dth [e] : 0.0f);
-                const float base = floorf (dithered);
-                tile [e] = (dithered - base) >= 0.5f ? base + 1.0f : base;
+                const art_s code = tile [e] * scale - a.feedback [c0 + c];
+                const art_s dithered = code + (DITHER ? dth [e] : 0.0f);
+                tile [e] = round_half_up (dithered);
             }
         }
         else if (tid < Cg) {
             if (DITHER) s_gen [tid] = s_next [tid];          // phase A of the next chunk is two barriers away
-            auto one = [&] (float smp, float dither) -> float {
-                const float scaled = smp * scale;
-                const float code = scaled - fb;
-                const float dithered = code + dither;
-                const float base = floorf (dithered);
-                const float frac = dithered - base;
-                const float qf = frac >= 0.5f ? base + 1.0f : base;
-                const float err = qf - code;
+            auto one = [&] (art_s smp, art_s dither) -> art_s {
+                const art_s scaled = smp * scale;
+                const art_s code = scaled - fb;
+                const art_s dithered = code + dither;
+                const art_s qf = round_half_up (dithered);
+                const art_s err = qf - code;
                 fb = shaper_step<ORDER> (sh, err);
                 return qf;
             };
             constexpr int UB = 8;
             int f = 0;
             for (; f + UB <= nf; f += UB) {
-                float x [UB], d [UB];
+                art_s x [UB], d [UB];
 #pragma unroll
                 for (int u = 0; u < UB; ++u) { x [u] = tile [(f + u) * Cg + tid]; d [u] = DITHER ? dth [(f + u) * Cg + tid] : 0.0f; }
 #pragma unroll
@@ -556,7 +566,7 @@ void decimate_lds_kernel (ArtDecArgs a, const float *in, int frames, unsigned ch
 // is still being read by other threads); the host swaps them.
 template <bool DITHER>
 __global__ __launch_bounds__ (256)
-void decimate_parallel_kernel (ArtDecArgs a, const float *in, int frames, unsigned char *out, uint32_t *gens_out)
+void decimate_parallel_kernel (ArtDecArgs a, const art_s *in, int frames, unsigned char *out, uint32_t *gens_out)
 {
     const long task = (long) blockIdx.x * blockDim.x + threadIdx.x;
     const int c = (int)(task % a.C);
@@ -569,12 +579,12 @@ void decimate_parallel_kernel (ArtDecArgs a, const float *in, int frames, unsign
     const int hi = (1 << (a.bits - 1)) - 1, lo = ~hi;
     const int shift = (24 - a.bits) % 8;
     const uint32_t bias = a.bits <= 8 ? 128u : 0u;
-    const float fb = a.feedback [c];                      // constant without shaping (decimator.c:264-265)
+    const art_s fb = a.feedback [c];                      // constant without shaping (decimator.c:264-265)
     uint32_t g = DITHER ? jump_pairs (a.gens [c], (unsigned int)(n0 / 2)) : 0u;
     unsigned int clips = 0;
 
     for (int i = 0; i < cnt; ++i) {
-        float dither = 0.0f;
+        art_s dither = 0.0f;
         if (DITHER) {
             const uint32_t start = g;
             uint32_t r = lcg (lcg (start));
@@ -582,14 +592,13 @@ void decimate_parallel_kernel (ArtDecArgs a, const float *in, int frames, unsign
             r = lcg (lcg (lcg (r)));
             g = r;
             const uint32_t u = (first >> 1) + (r >> 1);
-            dither = (float)(int)(u ^ 0x80000000u) * 4.656612873077392578125e-10f;
+            dither = (art_s)(int)(u ^ 0x80000000u) * (art_s) 4.656612873077392578125e-10;
         }
         const size_t e = (size_t)(n0 + i) * a.C + c;
-        const float scaled = in [e] * a.scale;
-        const float code = scaled - fb;
-        const float dithered = code + dither;
-        const float base = floorf (dithered);
-        int q = (int)((dithered - base) >= 0.5f ? base + 1.0f : base);
+        const art_s scaled = in [e] * a.scale;
+        const art_s code = scaled - fb;
+        const art_s dithered = code + dither;
+        int q = (int) round_half_up (dithered);
         if (q > hi) { q = hi; clips++; }
         else if (q < lo) { q = lo; clips++; }
         const uint32_t v = ((uint32_t) q << shift) + bias;
@@ -602,16 +611,16 @@ void decimate_parallel_kernel (ArtDecArgs a, const float *in, int frames, unsign
     if (clips) atomicAdd (a.clipped, (unsigned long long) clips);
 }
 
-__global__ void ingest_kernel (const unsigned char *in, float g, int bits, int bytes, int stride, float *out, int n)
+__global__ void ingest_kernel (const unsigned char *in, art_s g, int bits, int bytes, int stride, art_s *out, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int width = (bits + 7) / 8;
     const unsigned char *p = in + (size_t) i * stride * bytes + (bytes - width);
-    float v;
-    if (bits <= 8) v = (float)((int) p [0] - 128) * g;
-    else if (bits <= 16) v = (float)(int)(short)(p [0] | (p [1] << 8)) * g;
-    else v = (float)(int)((uint32_t) p [0] | ((uint32_t) p [1] << 8) | ((uint32_t)(int)(signed char) p [2] << 16)) * g;
+    art_s v;
+    if (bits <= 8) v = (art_s)((int) p [0] - 128) * g;
+    else if (bits <= 16) v = (art_s)(int)(short)(p [0] | (p [1] << 8)) * g;
+    else v = (art_s)(int)((uint32_t) p [0] | ((uint32_t) p [1] << 8) | ((uint32_t)(int)(signed char) p [2] << 16)) * g;
     out [i] = v;
 }
 
@@ -619,7 +628,7 @@ __global__ void ingest_kernel (const unsigned char *in, float g, int bits, int b
 
 extern "C" {
 
-int arthip_biquad_order2 (Biquad *d_sections, int C, int S, float *d_buf, int frames, void *stream)
+int arthip_biquad_order2 (Biquad *d_sections, int C, int S, art_s *d_buf, int frames, void *stream)
 {
     if (frames <= 0) return 0;
     if (S == 1) hipLaunchKernelGGL (biquad_order2_lds_kernel<1>, dim3 ((C + 63) / 64), dim3 (ST_THREADS), 0, (hipStream_t) stream, d_sections, C, d_buf, frames);
@@ -628,7 +637,7 @@ int arthip_biquad_order2 (Biquad *d_sections, int C, int S, float *d_buf, int fr
     return hipGetLastError () == hipSuccess ? 0 : -1;
 }
 
-int arthip_biquad_chain (Biquad *d_sections, int C, int S, float *d_buf, int frames, int stride, void *stream)
+int arthip_biquad_chain (Biquad *d_sections, int C, int S, art_s *d_buf, int frames, int stride, void *stream)
 {
     if (S < 1 || S > MAX_CHAIN || frames <= 0) return S < 1 || S > MAX_CHAIN ? -1 : 0;
     const int sample_form = stride < 0;                  // negative stride selects the per-sample association
@@ -641,14 +650,14 @@ int arthip_biquad_chain (Biquad *d_sections, int C, int S, float *d_buf, int fra
     return hipGetLastError () == hipSuccess ? 0 : -1;
 }
 
-static int decimate_launch (const ArtDecArgs *a, const float *d_in, long in_pitch, int frames, unsigned char *d_out, long out_pitch, void *stream)
+static int decimate_launch (const ArtDecArgs *a, const art_s *d_in, long in_pitch, int frames, unsigned char *d_out, long out_pitch, void *stream)
 {
     if (frames <= 0) return 0;
     hipLaunchKernelGGL (decimate_kernel, dim3 ((a->C + 63) / 64), dim3 (64), 0, (hipStream_t) stream, *a, d_in, in_pitch, frames, d_out, out_pitch);
     return hipGetLastError () == hipSuccess ? 0 : -1;
 }
 
-int arthip_decimate (const ArtDecArgs *a, const float *d_in, int frames, unsigned char *d_out, void *stream)
+int arthip_decimate (const ArtDecArgs *a, const art_s *d_in, int frames, unsigned char *d_out, void *stream)
 {
     if (frames >= 64 && !a->shaping_on && (!a->dither_on || a->gens_next) && (DEC_SEG % 2) == 0) {
         const long tasks = (long) a->C * ((frames + DEC_SEG - 1) / DEC_SEG);
@@ -670,12 +679,12 @@ int arthip_decimate (const ArtDecArgs *a, const float *d_in, int frames, unsigne
     return decimate_launch (a, d_in, 0, frames, d_out, 0, stream);
 }
 
-int arthip_decimate_planar (const ArtDecArgs *a, const float *d_in, long in_pitch, int frames, unsigned char *d_out, long out_pitch, void *stream)
+int arthip_decimate_planar (const ArtDecArgs *a, const art_s *d_in, long in_pitch, int frames, unsigned char *d_out, long out_pitch, void *stream)
 {
     return decimate_launch (a, d_in, in_pitch, frames, d_out, out_pitch, stream);
 }
 
-int arthip_ingest (const unsigned char *d_in, float g, int bits, int bytes, int stride, float *d_out, int n, void *stream)
+int arthip_ingest (const unsigned char *d_in, art_s g, int bits, int bytes, int stride, art_s *d_out, int n, void *stream)
 {
     if (n <= 0) return 0;
     hipLaunchKernelGGL (ingest_kernel, dim3 ((n + 255) / 256), dim3 (256), 0, (hipStream_t) stream, d_in, g, bits, bytes, stride, d_out, n);

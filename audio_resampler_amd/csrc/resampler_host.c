@@ -25,12 +25,12 @@
 
 struct artamd_resampler {
     void *stream;
-    float *d_bank;
-    float *d_hist [2];                      /* ping-pong history, HIST x C interleaved */
+    art_s *d_bank;
+    art_s *d_hist [2];                      /* ping-pong history, HIST x C interleaved */
     int cur;
-    float *d_in;  size_t in_cap;            /* staging for host-pointer calls (bytes) */
-    float *d_out; size_t out_cap;
-    float *d_tmp; size_t tmp_cap;           /* planar <-> interleaved scratch */
+    art_s *d_in;  size_t in_cap;            /* staging for host-pointer calls (bytes) */
+    art_s *d_out; size_t out_cap;
+    art_s *d_tmp; size_t tmp_cap;           /* planar <-> interleaved scratch */
     ArtamdSegment *segs; int seg_cap;
     int floor_active;                       /* ring index 0 is a hard history floor (after a flush-time rewind) */
     int kernel_pref, last_kernel;
@@ -38,7 +38,7 @@ struct artamd_resampler {
     double period_ratio; int period_out, period_in;
     /* optional HIP-event timing of FIR launches */
     int timing; void **ev; int ev_count, ev_cap;
-    float *d_patch; size_t patch_cap;        /* end-point extrapolation: samples computed on the host */
+    art_s *d_patch; size_t patch_cap;        /* end-point extrapolation: samples computed on the host */
     void *d_scratch; size_t scratch_cap;     /* MFMA path: effective rows + canonical positions of one launch */
     unsigned int *d_fix; size_t fix_cap;    /* [0] = counter, [1..] = output indices handed back by the MFMA kernel */
 };
@@ -49,7 +49,7 @@ struct artamd_resampler {
 
 /* One polyphase row: windowed sinc centred (T/2 - 1 + phase) taps in, DC-normalised, rounded to
  * float from the centre outwards with the rounding error carried along. */
-static void design_row (float *row, double *work, int T, double phase, double lowpass, int use_bh)
+static void design_row (art_s *row, double *work, int T, double phase, double lowpass, int use_bh)
 {
     const int mid = T / 2;
     double dc = 0.0;
@@ -74,7 +74,7 @@ static void design_row (float *row, double *work, int T, double phase, double lo
     /* visiting order mid, mid-1, mid+1, mid-2, ..., 0 */
     for (int step = 0, k = mid; step < T; ++step, k = (k >= mid) ? T - k - 1 : T - k) {
         work [k] *= unity;
-        row [k] = (float)(work [k] - residue);
+        row [k] = (art_s)(work [k] - residue);
         residue += row [k] - work [k];
     }
 }
@@ -83,7 +83,7 @@ void artamdBuildFilterBank (int T, int F, double lowpass, int flags, artsample_t
 {
     double *work = malloc (sizeof (double) * (size_t) T);
 
-    memset (bank, 0, sizeof (float) * (size_t)(F + 1) * T);
+    memset (bank, 0, sizeof (art_s) * (size_t)(F + 1) * T);
 
     for (int f = 0; f < F; ++f)
         design_row (bank + (size_t) f * T, work, T, (double) f / F, lowpass, flags & BLACKMAN_HARRIS);
@@ -253,7 +253,7 @@ Resample *resampleInit (int numChannels, int numTaps, int numFilters, double low
     Resample *cxt = calloc (1, sizeof (Resample));
     struct artamd_resampler *hip = calloc (1, sizeof (*hip));
     const size_t bank_count = (size_t)(numFilters + 1) * numTaps;
-    const size_t hist_bytes = sizeof (float) * (size_t) HIST_FRAMES (numTaps) * numChannels;
+    const size_t hist_bytes = sizeof (art_s) * (size_t) HIST_FRAMES (numTaps) * numChannels;
 
     cxt->hip = hip;
     cxt->numChannels = numChannels;
@@ -266,20 +266,20 @@ Resample *resampleInit (int numChannels, int numTaps, int numFilters, double low
     cxt->inputIndex = numTaps;
 
     /* host copy of the bank, exposed through the reference's `filters` row-pointer table */
-    float *bank = malloc (sizeof (float) * bank_count);
+    art_s *bank = malloc (sizeof (art_s) * bank_count);
     artamdBuildFilterBank (numTaps, numFilters, lowpassRatio, flags, bank);
-    cxt->filters = malloc (sizeof (float *) * (size_t)(numFilters + 1));
+    cxt->filters = malloc (sizeof (art_s *) * (size_t)(numFilters + 1));
     for (int f = 0; f <= numFilters; ++f)
         cxt->filters [f] = bank + (size_t) f * numTaps;
 
-    hip->d_bank = arthip_malloc (sizeof (float) * bank_count);
+    hip->d_bank = arthip_malloc (sizeof (art_s) * bank_count);
     hip->d_hist [0] = arthip_malloc (hist_bytes);
     hip->d_hist [1] = arthip_malloc (hist_bytes);
     hip->seg_cap = 64;
     hip->segs = malloc (sizeof (ArtamdSegment) * hip->seg_cap);
 
     if (!hip->d_bank || !hip->d_hist [0] || !hip->d_hist [1] ||
-        arthip_h2d (hip->d_bank, bank, sizeof (float) * bank_count, NULL) ||
+        arthip_h2d (hip->d_bank, bank, sizeof (art_s) * bank_count, NULL) ||
         arthip_zero (hip->d_hist [0], hist_bytes, NULL) || arthip_zero (hip->d_hist [1], hist_bytes, NULL) ||
         arthip_sync (NULL)) {
         fprintf (stderr, "artamd: device allocation failed: %s\n", arthip_last_error ());
@@ -359,7 +359,7 @@ void resampleFree (Resample *cxt)
 void resampleReset (Resample *cxt)
 {
     struct artamd_resampler *hip = cxt->hip;
-    const size_t hist_bytes = sizeof (float) * (size_t) HIST_FRAMES (cxt->numTaps) * cxt->numChannels;
+    const size_t hist_bytes = sizeof (art_s) * (size_t) HIST_FRAMES (cxt->numTaps) * cxt->numChannels;
 
     arthip_zero (hip->d_hist [0], hist_bytes, hip->stream);
     arthip_zero (hip->d_hist [1], hist_bytes, hip->stream);
@@ -495,22 +495,22 @@ unsigned int resampleHipLastHandedBack (Resample *cxt)
  * ---------------------------------------------------------------------------------------- */
 
 /* fetch `count` frames starting at linear index `lin` of (history ++ input) into planes[c][0..count) */
-static void gather_linear (Resample *cxt, const float *d_in, long in_pitch, int lin, int count, float *planes)
+static void gather_linear (Resample *cxt, const art_s *d_in, long in_pitch, int lin, int count, art_s *planes)
 {
     struct artamd_resampler *hip = cxt->hip;
     const int C = cxt->numChannels, H = HIST_FRAMES (cxt->numTaps);
-    float *tmp = malloc (sizeof (float) * (size_t) count * C);
+    art_s *tmp = malloc (sizeof (art_s) * (size_t) count * C);
     const int from_hist = lin < H ? (H - lin < count ? H - lin : count) : 0;
 
     if (from_hist)
-        arthip_d2h (tmp, hip->d_hist [hip->cur] + (size_t) lin * C, sizeof (float) * (size_t) from_hist * C, hip->stream);
+        arthip_d2h (tmp, hip->d_hist [hip->cur] + (size_t) lin * C, sizeof (art_s) * (size_t) from_hist * C, hip->stream);
     if (count > from_hist) {
         const int first = lin + from_hist - H, n = count - from_hist;
         if (in_pitch)
             for (int c = 0; c < C; ++c)      /* planar: land directly in the plane */
-                arthip_d2h (planes + (size_t) c * count + from_hist, d_in + (size_t) c * in_pitch + first, sizeof (float) * (size_t) n, hip->stream);
+                arthip_d2h (planes + (size_t) c * count + from_hist, d_in + (size_t) c * in_pitch + first, sizeof (art_s) * (size_t) n, hip->stream);
         else
-            arthip_d2h (tmp + (size_t) from_hist * C, d_in + (size_t) first * C, sizeof (float) * (size_t) n * C, hip->stream);
+            arthip_d2h (tmp + (size_t) from_hist * C, d_in + (size_t) first * C, sizeof (art_s) * (size_t) n * C, hip->stream);
     }
     arthip_sync (hip->stream);
 
@@ -522,7 +522,7 @@ static void gather_linear (Resample *cxt, const float *d_in, long in_pitch, int 
 }
 
 /* Backward extrapolation into the silent pre-history, just before the first output of a stream. */
-static void prefill_history (Resample *cxt, const float *d_in, long in_pitch)
+static void prefill_history (Resample *cxt, const art_s *d_in, long in_pitch)
 {
     struct artamd_resampler *hip = cxt->hip;
     const int T = cxt->numTaps, C = cxt->numChannels, H = HIST_FRAMES (T), half = T / 2;
@@ -533,9 +533,9 @@ static void prefill_history (Resample *cxt, const float *d_in, long in_pitch)
     if (known < 8 || extra <= 0) return;                                /* reference resampler.c:695 / :815 */
 
     const int lin_known = T + H - cxt->inputIndex;                      /* ring index T in linear terms */
-    float *planes = malloc (sizeof (float) * (size_t) known * C);
-    float *older = malloc (sizeof (float) * (size_t) extra);
-    float *patch = malloc (sizeof (float) * (size_t) extra * C);
+    art_s *planes = malloc (sizeof (art_s) * (size_t) known * C);
+    art_s *older = malloc (sizeof (art_s) * (size_t) extra);
+    art_s *patch = malloc (sizeof (art_s) * (size_t) extra * C);
 
     gather_linear (cxt, d_in, in_pitch, lin_known, known, planes);
 
@@ -546,32 +546,32 @@ static void prefill_history (Resample *cxt, const float *d_in, long in_pitch)
     }
 
     /* ring [known, T) = linear [lin_known - extra, lin_known): inside the history buffer by construction */
-    arthip_h2d (hip->d_hist [hip->cur] + (size_t)(lin_known - extra) * C, patch, sizeof (float) * (size_t) extra * C, hip->stream);
+    arthip_h2d (hip->d_hist [hip->cur] + (size_t)(lin_known - extra) * C, patch, sizeof (art_s) * (size_t) extra * C, hip->stream);
     arthip_sync (hip->stream);
     free (planes); free (older); free (patch);
 }
 
 /* Forward extrapolation of half a window at flush time; returns a device buffer of T/2 frames x C. */
-static const float *flush_tail (Resample *cxt)
+static const art_s *flush_tail (Resample *cxt)
 {
     struct artamd_resampler *hip = cxt->hip;
     const int T = cxt->numTaps, C = cxt->numChannels, H = HIST_FRAMES (T), half = T / 2;
-    float *planes = malloc (sizeof (float) * (size_t) half * C);
-    float *work = malloc (sizeof (float) * (size_t) T);
-    float *patch = malloc (sizeof (float) * (size_t) half * C);
+    art_s *planes = malloc (sizeof (art_s) * (size_t) half * C);
+    art_s *work = malloc (sizeof (art_s) * (size_t) T);
+    art_s *patch = malloc (sizeof (art_s) * (size_t) half * C);
 
     gather_linear (cxt, NULL, 0, H - half, half, planes);
 
     for (int c = 0; c < C; ++c) {
-        memcpy (work, planes + (size_t) c * half, sizeof (float) * (size_t) half);
+        memcpy (work, planes + (size_t) c * half, sizeof (art_s) * (size_t) half);
         art_extrapolate_forward (work, half, half);
         for (int f = 0; f < half; ++f)
             patch [(size_t) f * C + c] = work [half + f];
     }
 
-    hip->d_patch = grow (hip->d_patch, &hip->patch_cap, sizeof (float) * (size_t) half * C);
+    hip->d_patch = grow (hip->d_patch, &hip->patch_cap, sizeof (art_s) * (size_t) half * C);
     if (hip->d_patch) {
-        arthip_h2d (hip->d_patch, patch, sizeof (float) * (size_t) half * C, hip->stream);
+        arthip_h2d (hip->d_patch, patch, sizeof (art_s) * (size_t) half * C, hip->stream);
         arthip_sync (hip->stream);
     }
     free (planes); free (work); free (patch);
@@ -580,8 +580,8 @@ static const float *flush_tail (Resample *cxt)
 
 /* Plan one call, enqueue the FIR launches and the history roll.  `d_in` holds the call's input on
  * the device (interleaved, or planar with `in_pitch`); `d_out` receives the output likewise. */
-static ResampleResult enqueue_call (Resample *cxt, const float *d_in, long in_pitch, int nIn,
-                                    float *d_out, long out_pitch, int cap, double ratio)
+static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pitch, int nIn,
+                                    art_s *d_out, long out_pitch, int cap, double ratio)
 {
     struct artamd_resampler *hip = cxt->hip;
     const int T = cxt->numTaps, C = cxt->numChannels, H = HIST_FRAMES (T);
@@ -609,7 +609,7 @@ static ResampleResult enqueue_call (Resample *cxt, const float *d_in, long in_pi
     }
 
     const int appended = is_flush ? T / 2 : (int) res.input_used;
-    const float *flush_in = NULL;
+    const art_s *flush_in = NULL;
 
     if (cxt->flags & EXTRAPOLATE_ENDPOINTS) {
         /* prefill: first output of the stream, produced by an ordinary call whose first output precedes any
@@ -631,12 +631,14 @@ static ResampleResult enqueue_call (Resample *cxt, const float *d_in, long in_pi
         a.C = C; a.T = T; a.F = cxt->numFilters; a.H = H;
         a.interpolate = (cxt->flags & SUBSAMPLE_INTERPOLATE) != 0;
         a.lowpass = (cxt->flags & INCLUDE_LOWPASS) != 0;
-        a.mode = (cxt->flags & RESAMPLE_STRICT_ORDER) ? ART_MODE_STRICT :
-                 (cxt->flags & EXTEND_CONVOLUTION_MATH) ? ART_MODE_PRECISE : ART_MODE_FAST;
-        if ((cxt->flags & RESAMPLE_STRICT_ORDER) && (cxt->flags & EXTEND_CONVOLUTION_MATH)) a.mode |= 4;
+        /* the double-precision build has one arithmetic: EXTEND_CONVOLUTION_MATH only matters for 4-byte samples
+         * (reference resampler.c:191) */
+        const int extend = !ART_WIDE && (cxt->flags & EXTEND_CONVOLUTION_MATH);
+        a.mode = (cxt->flags & RESAMPLE_STRICT_ORDER) ? ART_MODE_STRICT : extend ? ART_MODE_PRECISE : ART_MODE_FAST;
+        if ((cxt->flags & RESAMPLE_STRICT_ORDER) && extend) a.mode |= 4;
         a.ratio = eff_ratio;
         a.period_out = hip->period_out; a.period_in = hip->period_in;
-        if (a.period_out && a.mode == ART_MODE_FAST && hip->kernel_pref != ART_KERNEL_GENERAL) {
+        if (!ART_WIDE && a.period_out && a.mode == ART_MODE_FAST && hip->kernel_pref != ART_KERNEL_GENERAL) {
             /* [0] per-launch count, [1] running total (diagnostics), [2..] the list */
             if (sizeof (unsigned int) * ((size_t) res.output_generated + 2) > hip->fix_cap) {
                 hip->d_fix = grow (hip->d_fix, &hip->fix_cap, sizeof (unsigned int) * ((size_t) res.output_generated + 2));
@@ -709,8 +711,8 @@ ResampleResult resampleProcessAndFlushInterleavedDevice (Resample *cxt, const ar
 
 /* host-pointer call: how many input frames can this call consume at most / produce at most is known
  * only after planning, so plan on a scratch copy first to size the transfers */
-static ResampleResult host_call (Resample *cxt, const float *input, const float *const *planes, int nIn,
-                                 float *output, float *const *out_planes, int cap, double ratio)
+static ResampleResult host_call (Resample *cxt, const art_s *input, const art_s *const *planes, int nIn,
+                                 art_s *output, art_s *const *out_planes, int cap, double ratio)
 {
     struct artamd_resampler *hip = cxt->hip;
     const int C = cxt->numChannels;
@@ -724,8 +726,8 @@ static ResampleResult host_call (Resample *cxt, const float *input, const float 
 
     const size_t in_samples = (size_t) peek.input_used * C, out_samples = (size_t) peek.output_generated * C;
 
-    hip->d_in = grow (hip->d_in, &hip->in_cap, sizeof (float) * in_samples);
-    hip->d_out = grow (hip->d_out, &hip->out_cap, sizeof (float) * out_samples);
+    hip->d_in = grow (hip->d_in, &hip->in_cap, sizeof (art_s) * in_samples);
+    hip->d_out = grow (hip->d_out, &hip->out_cap, sizeof (art_s) * out_samples);
     if ((in_samples && !hip->d_in) || (out_samples && !hip->d_out)) {
         fprintf (stderr, "artamd: device allocation failed: %s\n", arthip_last_error ());
         return res;
@@ -733,17 +735,17 @@ static ResampleResult host_call (Resample *cxt, const float *input, const float 
 
     if (planes || out_planes) {
         size_t big = in_samples > out_samples ? in_samples : out_samples;
-        hip->d_tmp = grow (hip->d_tmp, &hip->tmp_cap, sizeof (float) * big);
+        hip->d_tmp = grow (hip->d_tmp, &hip->tmp_cap, sizeof (art_s) * big);
     }
 
     if (in_samples) {
         if (planes) {
             for (int c = 0; c < C; ++c)
-                arthip_h2d (hip->d_tmp + (size_t) c * peek.input_used, planes [c], sizeof (float) * peek.input_used, hip->stream);
+                arthip_h2d (hip->d_tmp + (size_t) c * peek.input_used, planes [c], sizeof (art_s) * peek.input_used, hip->stream);
             arthip_interleave (hip->d_in, hip->d_tmp, peek.input_used, (int) peek.input_used, C, hip->stream);
         }
         else
-            arthip_h2d (hip->d_in, input, sizeof (float) * in_samples, hip->stream);
+            arthip_h2d (hip->d_in, input, sizeof (art_s) * in_samples, hip->stream);
     }
 
     res = enqueue_call (cxt, hip->d_in, 0, nIn, hip->d_out, 0, cap, ratio);
@@ -752,10 +754,10 @@ static ResampleResult host_call (Resample *cxt, const float *input, const float 
         if (out_planes) {
             arthip_deinterleave (hip->d_tmp, res.output_generated, hip->d_out, (int) res.output_generated, C, hip->stream);
             for (int c = 0; c < C; ++c)
-                arthip_d2h (out_planes [c], hip->d_tmp + (size_t) c * res.output_generated, sizeof (float) * res.output_generated, hip->stream);
+                arthip_d2h (out_planes [c], hip->d_tmp + (size_t) c * res.output_generated, sizeof (art_s) * res.output_generated, hip->stream);
         }
         else
-            arthip_d2h (output, hip->d_out, sizeof (float) * (size_t) res.output_generated * C, hip->stream);
+            arthip_d2h (output, hip->d_out, sizeof (art_s) * (size_t) res.output_generated * C, hip->stream);
     }
 
     arthip_sync (hip->stream);
@@ -792,7 +794,7 @@ ResampleResult resampleProcessAndFlush (Resample *cxt, const artsample_t *const 
     if ((numInputFrames -= res.input_used) != 0 || (numOutputFrames -= res.output_generated) == 0)
         return res;
 
-    float **shifted = malloc (sizeof (float *) * (size_t) cxt->numChannels);
+    art_s **shifted = malloc (sizeof (art_s *) * (size_t) cxt->numChannels);
     for (int c = 0; c < cxt->numChannels; ++c)
         shifted [c] = output [c] + res.output_generated;
 

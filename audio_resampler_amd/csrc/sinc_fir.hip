@@ -23,7 +23,7 @@ namespace {
 
 struct Pos { int ip; int fi; double frac; };
 
-__device__ __forceinline__ float load_frame (const ArtFirArgs &a, int lin_floor, int lin, int ch)
+__device__ __forceinline__ art_s load_frame (const ArtFirArgs &a, int lin_floor, int lin, int ch)
 {
     if (lin < lin_floor || lin < 0 || ch >= a.C) return 0.0f;
     if (lin < a.H) return a.hist [(size_t) lin * a.C + ch];
@@ -96,6 +96,9 @@ __device__ __forceinline__ void wave_reduce (double (&v) [NV], int lane)
     }
 }
 
+__attribute__ ((unused)) __device__ __forceinline__ float fused (float a, float b, float c) { return __builtin_fmaf (a, b, c); }
+__attribute__ ((unused)) __device__ __forceinline__ double fused (double a, double b, double c) { return __builtin_fma (a, b, c); }
+
 constexpr int GEN_THREADS = 256;
 constexpr int GEN_MAX_TILE = 32;
 
@@ -108,8 +111,8 @@ template <int CG, bool INTERP, bool PRECISE>
 __global__ __launch_bounds__ (GEN_THREADS)
 void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile, int from_list)
 {
-    using Acc = typename std::conditional<PRECISE, double, float>::type;
-    extern __shared__ __attribute__ ((aligned (16))) float xs [];
+    using Acc = typename std::conditional<PRECISE || ART_WIDE, double, float>::type;   // 8-byte samples accumulate in double
+    extern __shared__ __attribute__ ((aligned (16))) art_s xs [];
     __shared__ int s_ip [GEN_MAX_TILE], s_fi [GEN_MAX_TILE];
     __shared__ double s_frac [GEN_MAX_TILE];
 
@@ -140,8 +143,8 @@ void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile, int from_list
 
     for (int i = wave; i < cnt; i += GEN_THREADS / 64) {
         const int ip = s_ip [i], fi = s_fi [i];
-        const float *x = xs + (size_t)(ip - half + 1 - lin_lo) * CG;
-        float result [CG];
+        const art_s *x = xs + (size_t)(ip - half + 1 - lin_lo) * CG;
+        art_s result [CG];
 
         if (!INTERP && !a.lowpass && (fi % a.F) == 0) {
             // exact sample hit in nearest-filter mode: the reference copies the sample through
@@ -149,8 +152,8 @@ void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile, int from_list
             for (int c = 0; c < CG; ++c) result [c] = x [(size_t)(half - 1 + fi / a.F) * CG + c];
         }
         else {
-            const float *h0 = a.bank + (size_t) fi * a.T;
-            const float *h1 = h0 + a.T;
+            const art_s *h0 = a.bank + (size_t) fi * a.T;
+            const art_s *h1 = h0 + a.T;
             Acc acc0 [CG], acc1 [CG];
 #pragma unroll
             for (int c = 0; c < CG; ++c) { acc0 [c] = 0; acc1 [c] = 0; }
@@ -162,18 +165,18 @@ void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile, int from_list
 #pragma unroll
                 for (int side = 0; side < 2; ++side) {
                     const int k = side ? a.T - 1 - p : p;
-                    const float c0 = h0 [k];
-                    const float c1 = INTERP ? h1 [k] : 0.0f;
+                    const art_s c0 = h0 [k];
+                    const art_s c1 = INTERP ? h1 [k] : 0.0f;
 #pragma unroll
                     for (int c = 0; c < CG; ++c) {
-                        const float v = x [(size_t) k * CG + c];
+                        const art_s v = x [(size_t) k * CG + c];
                         if (PRECISE) {
                             acc0 [c] = acc0 [c] + (Acc) c0 * (Acc) v;
                             if (INTERP) acc1 [c] = acc1 [c] + (Acc) c1 * (Acc) v;
                         }
                         else {
-                            acc0 [c] = __builtin_fmaf (c0, v, acc0 [c]);
-                            if (INTERP) acc1 [c] = __builtin_fmaf (c1, v, acc1 [c]);
+                            acc0 [c] = fused ((Acc) c0, (Acc) v, acc0 [c]);
+                            if (INTERP) acc1 [c] = fused ((Acc) c1, (Acc) v, acc1 [c]);
                         }
                     }
                 }
@@ -192,16 +195,16 @@ void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile, int from_list
             constexpr int GROUP = 64 / NV;                       // lanes holding the same reduced value
             const double mine = part [0];
             const double frac = s_frac [i];
-            float y;
+            art_s y;
             if (INTERP) {
                 // the lane group of row fi fetches row fi+1 from the neighbouring group; fp64 lerp, un-fused
                 const double s1 = __shfl_xor (mine, GROUP);
                 const double left = mine * (1.0 - frac);
                 const double right = s1 * frac;
-                y = (float)(left + right);
+                y = (art_s)(left + right);
             }
             else
-                y = (float) mine;
+                y = (art_s) mine;
 
             const int owner = INTERP ? (lane / GROUP) >> 1 : lane / GROUP;
             const bool writer = (lane % GROUP) == 0 && (!INTERP || ((lane / GROUP) & 1) == 0);
@@ -225,7 +228,7 @@ void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile, int from_list
 }
 
 // Strict kernel: one lane per output sample, taps visited in the reference's source order
-// (pairs from both ends towards the middle, float accumulator; or in order with a double accumulator),
+// (pairs from both ends towards the middle, sample-type accumulator; or in order with a double accumulator),
 // no fused operations.  Bit-identical to the reference compiled with -O2 -ffp-contract=off.
 template <bool INTERP>
 __global__ __launch_bounds__ (256)
@@ -238,9 +241,9 @@ void fir_strict_kernel (ArtFirArgs a, ArtSegTable segs, int precise)
 
     const Pos p = locate<INTERP> (a, segs, n);
     const int T = a.T, half = T / 2, w = p.ip - half + 1;
-    float y;
+    art_s y;
 
-    auto dot = [&] (const float *h) -> double {
+    auto dot = [&] (const art_s *h) -> double {
         if (precise) {
             double acc = 0.0;
             for (int k = 0; k < T; ++k) {
@@ -249,11 +252,11 @@ void fir_strict_kernel (ArtFirArgs a, ArtSegTable segs, int precise)
             }
             return acc;
         }
-        float acc = 0.0f;
+        art_s acc = 0.0f;
         for (int lo = 0, hi = T - 1; lo < hi; ++lo, --hi) {
-            float pl = h [lo] * load_frame (a, segs.lin_floor, w + lo, ch);
-            float ph = h [hi] * load_frame (a, segs.lin_floor, w + hi, ch);
-            float pair = pl + ph;
+            art_s pl = h [lo] * load_frame (a, segs.lin_floor, w + lo, ch);
+            art_s ph = h [hi] * load_frame (a, segs.lin_floor, w + hi, ch);
+            art_s pair = pl + ph;
             acc = acc + pair;
         }
         return (double) acc;
@@ -264,17 +267,18 @@ void fir_strict_kernel (ArtFirArgs a, ArtSegTable segs, int precise)
         double s1 = dot (a.bank + (size_t)(p.fi + 1) * T);
         double left = s0 * (1.0 - p.frac);
         double right = s1 * p.frac;
-        y = (float)(left + right);
+        y = (art_s)(left + right);
     }
     else if (!a.lowpass && (p.fi % a.F) == 0)
         y = load_frame (a, segs.lin_floor, p.ip + p.fi / a.F, ch);
     else
-        y = (float) dot (a.bank + (size_t) p.fi * T);
+        y = (art_s) dot (a.bank + (size_t) p.fi * T);
 
     if (a.out_pitch) a.out [(size_t) ch * a.out_pitch + n] = y;
     else a.out [(size_t) n * a.C + ch] = y;
 }
 
+#if !ART_WIDE          // the matrix-core path is single precision; 8-byte samples use the general kernel
 // ---------------------------------------------------------------------------------------------------
 // MFMA kernel for rational ratios (the headline path: 44.1k -> 48k is 160 outputs per 147 inputs).
 //
@@ -321,7 +325,6 @@ constexpr int MF_MAX_PPW = 64;            // periods per workgroup (C = 2)
 // effective row: adjacent rows differ by < 3e-3 per tap, so the row changes by < 6e-9 relative (a tenth of
 // half a float ulp).  The reference's own position arithmetic is quantised to ~1e-7 steps after 1M frames.
 constexpr double MF_PHASE_TOL = 2e-6;
-constexpr int MF_BSLOTS = (MF_KC * 32 + MF_THREADS - 1) / MF_THREADS;   // staging slots per thread at cg = 32
 
 struct MfmaGeom {
     int P, Q;                             // outputs / inputs per period
@@ -697,19 +700,20 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
         }
     }
 }
+#endif  // !ART_WIDE
 
-__global__ void roll_history_kernel (float *dst, const float *hist, const float *in, long in_pitch, int appended, int H, int C)
+__global__ void roll_history_kernel (art_s *dst, const art_s *hist, const art_s *in, long in_pitch, int appended, int H, int C)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= H * C) return;
     const int f = e / C, c = e - f * C, lin = appended + f;
-    float v = 0.0f;
+    art_s v = 0.0f;
     if (lin < H) v = hist [(size_t) lin * C + c];
     else if (in) { const int g = lin - H; v = in_pitch ? in [(size_t) c * in_pitch + g] : in [(size_t) g * C + c]; }
     dst [e] = v;
 }
 
-__global__ void interleave_kernel (float *dst, const float *src, long pitch, int frames, int C)
+__global__ void interleave_kernel (art_s *dst, const art_s *src, long pitch, int frames, int C)
 {
     const size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (size_t) frames * C) return;
@@ -717,7 +721,7 @@ __global__ void interleave_kernel (float *dst, const float *src, long pitch, int
     dst [e] = src [(size_t) c * pitch + f];
 }
 
-__global__ void deinterleave_kernel (float *dst, long pitch, const float *src, int frames, int C)
+__global__ void deinterleave_kernel (art_s *dst, long pitch, const art_s *src, int frames, int C)
 {
     const size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (size_t) frames * C) return;
@@ -730,7 +734,7 @@ int launch_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st
 {
     // tile size: as many consecutive outputs as keep the staged span within the LDS budget
     const int lds_budget = 64 * 1024;
-    const int max_span = lds_budget / (4 * CG);
+    const int max_span = lds_budget / ((int) sizeof (art_s) * CG);
     int tile = (int) floor ((max_span - a.T - 3) * a.ratio);
     if (tile > GEN_MAX_TILE) tile = GEN_MAX_TILE;
     // small calls: prefer many small tiles (each wave walks its tile's outputs serially, so latency ~ tile/4
@@ -739,7 +743,7 @@ int launch_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st
     while (tile > 4 && (total_outputs + tile - 1) / tile < 1024u) tile >>= 1;
     if (tile < 1 || from_list) tile = 1;
     long span = a.T + (long) ceil (tile / a.ratio) + 3;
-    size_t lds = (size_t) span * CG * 4;
+    size_t lds = (size_t) span * CG * sizeof (art_s);
     if (lds > 160 * 1024 - 1024) return -1;                 // absurd ratio/taps combination
     const unsigned int total = a.n_end - a.n_begin;
     dim3 grid (from_list ? 512u : (total + tile - 1) / tile, (a.C + CG - 1) / CG);
@@ -781,6 +785,7 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
         return hipGetLastError () == hipSuccess ? ART_KERNEL_GENERAL : -1;
     }
 
+#if !ART_WIDE
     // MFMA path: exact rational ratio, default numeric mode, interleaved buffers, no history floor — and enough
     // work.  A workgroup of the MFMA kernel walks all K chunks of its tile serially (~50-90 us floor), while the
     // general kernel spreads even a small call over many workgroups; measured crossover (tools/bench_crossover.py,
@@ -842,21 +847,27 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
         return hipGetLastError () == hipSuccess ? ART_KERNEL_MFMA : -1;
     }
 
+#else
+    (void) kernel_pref;
+#endif
+
+#if !ART_WIDE
 general_path:
+#endif
     if (a->ev_start) arthip_event_record (a->ev_start, stream);
     if (run_general (*a, *segs, st, 0)) return -1;
     if (a->ev_stop) arthip_event_record (a->ev_stop, stream);
     return hipGetLastError () == hipSuccess ? ART_KERNEL_GENERAL : -1;
 }
 
-int arthip_roll_history (float *new_hist, const float *hist, const float *in, long in_pitch, int appended, int H, int C, void *stream)
+int arthip_roll_history (art_s *new_hist, const art_s *hist, const art_s *in, long in_pitch, int appended, int H, int C, void *stream)
 {
     const int total = H * C;
     hipLaunchKernelGGL (roll_history_kernel, dim3 ((total + 255) / 256), dim3 (256), 0, (hipStream_t) stream, new_hist, hist, in, in_pitch, appended, H, C);
     return hipGetLastError () == hipSuccess ? 0 : -1;
 }
 
-int arthip_interleave (float *dst, const float *src, long pitch, int frames, int C, void *stream)
+int arthip_interleave (art_s *dst, const art_s *src, long pitch, int frames, int C, void *stream)
 {
     const size_t total = (size_t) frames * C;
     if (!total) return 0;
@@ -864,7 +875,7 @@ int arthip_interleave (float *dst, const float *src, long pitch, int frames, int
     return hipGetLastError () == hipSuccess ? 0 : -1;
 }
 
-int arthip_deinterleave (float *dst, long pitch, const float *src, int frames, int C, void *stream)
+int arthip_deinterleave (art_s *dst, long pitch, const art_s *src, int frames, int C, void *stream)
 {
     const size_t total = (size_t) frames * C;
     if (!total) return 0;

@@ -15,7 +15,11 @@
 
 #ifndef ARTSAMPLE_T_DEFINED
 #define ARTSAMPLE_T_DEFINED
+#if defined(PATH_WIDTH) && (PATH_WIDTH==64)
+typedef double artsample_t;
+#else
 typedef float artsample_t;
+#endif
 #endif
 
 /* transfer function (a0 + a1 z^-1 + ... + a4 z^-4) / (1 + b1 z^-1 + ... + b4 z^-4) */

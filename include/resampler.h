@@ -18,12 +18,14 @@
 
 #include <stdint.h>
 
-#if defined(PATH_WIDTH) && (PATH_WIDTH==64)
-#error "the MI355X build implements the 32-bit float sample path only (SURVEY.md 8(f) rank 3)"
-#endif
+/* PATH_WIDTH=64 selects the double-precision sample path (reference resampler.h:22-26); link libartamd64.so then */
 #ifndef ARTSAMPLE_T_DEFINED
 #define ARTSAMPLE_T_DEFINED
+#if defined(PATH_WIDTH) && (PATH_WIDTH==64)
+typedef double artsample_t;             /* one audio sample */
+#else
 typedef float artsample_t;              /* one audio sample */
+#endif
 #endif
 
 /* Behaviour flags for the `flags` argument of the init calls.  Values are ABI (identical to the reference). */

@@ -25,7 +25,7 @@
  * Filter bank  (reference resampler.c:1090-1133 init_filter, :149-168 bank assembly)
  * ---------------------------------------------------------------------------------------- */
 
-static void build_phase_row (float *row, double *scratch, int taps, double phase, double lowpass, int blackman_harris)
+static void build_phase_row (ora_s *row, double *scratch, int taps, double phase, double lowpass, int blackman_harris)
 {
     const int half = taps / 2;
     double total = 0.0;
@@ -49,7 +49,7 @@ static void build_phase_row (float *row, double *scratch, int taps, double phase
         total += v;
     }
 
-    /* unity DC gain, then round to float walking centre-outwards carrying the rounding error
+    /* unity DC gain, then round to the sample type walking centre-outwards carrying the rounding error
      * (resampler.c:1126-1132): visit half, half-1, half+1, half-2, ... 0 */
     const double norm = 1.0 / total;
     double carried = 0.0;
@@ -57,15 +57,15 @@ static void build_phase_row (float *row, double *scratch, int taps, double phase
 
     while (j < taps) {
         scratch [j] *= norm;
-        row [j] = (float)(scratch [j] - carried);
+        row [j] = (ora_s)(scratch [j] - carried);
         carried += row [j] - scratch [j];
         j = (j >= half) ? taps - j - 1 : taps - j;
     }
 }
 
-static float *build_bank (int taps, int filters, double lowpass, int flags)
+static ora_s *build_bank (int taps, int filters, double lowpass, int flags)
 {
-    float *bank = calloc ((size_t)(filters + 1) * taps, sizeof (float));
+    ora_s *bank = calloc ((size_t)(filters + 1) * taps, sizeof (ora_s));
     double *scratch = malloc (sizeof (double) * taps);
 
     for (int f = 0; f < filters; ++f)
@@ -112,7 +112,7 @@ OraResampler *ora_resample_init (int channels, int taps, int filters, double low
      * (resampler.c:667-672) keeps only `taps` samples while windows still reach up to taps/2 further
      * back, so the reference reads before buffers[c][0] (heap UB; zeros for ch>=1 with glibc, garbage
      * for ch 0).  The oracle and the product define those pre-history samples as silence. */
-    r->ring_store = calloc ((size_t) channels * (r->ring_len + taps), sizeof (float));
+    r->ring_store = calloc ((size_t) channels * (r->ring_len + taps), sizeof (ora_s));
     r->ring = r->ring_store + taps;
     r->read_pos = taps / 2;
     r->write_pos = taps;
@@ -172,7 +172,7 @@ void ora_resample_free (OraResampler *r)
 
 void ora_resample_reset (OraResampler *r)
 {
-    memset (r->ring_store, 0, sizeof (float) * (size_t) r->channels * (r->ring_len + r->taps));
+    memset (r->ring_store, 0, sizeof (ora_s) * (size_t) r->channels * (r->ring_len + r->taps));
     r->read_pos = r->taps / 2;
     r->write_pos = r->taps;
     if (r->flags & ORA_EXTRAPOLATE) r->flags |= ORA_PREFILL;
@@ -235,10 +235,10 @@ unsigned ora_resample_expected_output (const OraResampler *r, int n_in, double r
  * Dot products  (resampler.c:1033-1057)
  * ---------------------------------------------------------------------------------------- */
 
-/* float accumulator, pairs taken from both ends towards the middle (resampler.c:1033-1044) */
-double ora_dot_outside_in (const float *h, const float *x, int taps)
+/* sample-type accumulator, pairs taken from both ends towards the middle (resampler.c:1033-1044) */
+double ora_dot_outside_in (const ora_s *h, const ora_s *x, int taps)
 {
-    float acc = 0.0f;
+    ora_s acc = 0.0f;
 
     for (int lo = 0, hi = taps - 1; lo < hi; ++lo, --hi)
         acc += (h [lo] * x [lo]) + (h [hi] * x [hi]);
@@ -247,7 +247,7 @@ double ora_dot_outside_in (const float *h, const float *x, int taps)
 }
 
 /* double accumulator, taps in order (resampler.c:1049-1057) */
-double ora_dot_precise (const float *h, const float *x, int taps)
+double ora_dot_precise (const ora_s *h, const ora_s *x, int taps)
 {
     double acc = 0.0;
 
@@ -258,16 +258,17 @@ double ora_dot_precise (const float *h, const float *x, int taps)
 }
 
 /* one output value at fractional ring position `pos` (resampler.c:1135-1181) */
-static double evaluate_at (const OraResampler *r, const float *ring, double pos)
+static double evaluate_at (const OraResampler *r, const ora_s *ring, double pos)
 {
     const int T = r->taps, F = r->filters;
     const double whole = floor (pos);
-    double (*dot)(const float *, const float *, int) = (r->flags & ORA_PRECISE) ? ora_dot_precise : ora_dot_outside_in;
+    /* "extended math" exists for 4-byte samples only (resampler.c:191) */
+    double (*dot)(const ora_s *, const ora_s *, int) = (sizeof (ora_s) == 4 && (r->flags & ORA_PRECISE)) ? ora_dot_precise : ora_dot_outside_in;
 
     if (r->flags & ORA_INTERPOLATE) {
         double frac = (pos - whole) * F;
         int fi = (int) floor (frac);
-        const float *win = ring + (int) whole - T / 2 + 1;
+        const ora_s *win = ring + (int) whole - T / 2 + 1;
 
         frac -= fi;
         return (dot (r->bank + (size_t) fi * T, win, T) * (1.0 - frac)) +
@@ -275,7 +276,7 @@ static double evaluate_at (const OraResampler *r, const float *ring, double pos)
     }
     else {
         int fi = (int) floor ((pos - whole) * F + 0.5);
-        const float *centre = ring + (int) whole;
+        const ora_s *centre = ring + (int) whole;
 
         if (!(r->flags & ORA_LOWPASS) && !(fi % F))     /* exact sample hit: pass it through */
             return centre [fi / F];
@@ -312,7 +313,7 @@ static void refl_to_lpc (const double *k, double *lpc)
     }
 }
 
-static void lpc_fit (const float *v, int n, float *co)
+static void lpc_fit (const ora_s *v, int n, float *co)
 {
     int ne = n - LPC_N, loops = 0, changes = 0;
     double vrms = 0.0, drms = 0.0, err, step = 3.0 / (1 << 4);
@@ -369,10 +370,10 @@ static void lpc_fit (const float *v, int n, float *co)
     else if (vrms <= err) for (int i = 0; i < LPC_N; ++i) co [i] = 0.0f;
 }
 
-static void lpc_forward (float *v, int n, int extra)
+static void lpc_forward (ora_s *v, int n, int extra)
 {
     float co [LPC_N];
-    memset (v + n, 0, sizeof (float) * extra);
+    memset (v + n, 0, sizeof (ora_s) * extra);
     lpc_fit (v, n, co);
     for (int i = 0; i < extra; ++i) {
         double z = 0.0;
@@ -381,9 +382,9 @@ static void lpc_forward (float *v, int n, int extra)
     }
 }
 
-static void lpc_reverse (float *past_end, int n, int extra)      /* past_end[-1] is the newest known sample */
+static void lpc_reverse (ora_s *past_end, int n, int extra)      /* past_end[-1] is the newest known sample */
 {
-    float *r = calloc (n + extra, sizeof (float));
+    ora_s *r = calloc (n + extra, sizeof (ora_s));
     for (int i = 0; i < n; ++i) r [i] = past_end [-1 - i];
     lpc_forward (r, n, extra);
     for (int i = n; i < n + extra; ++i) past_end [-1 - i] = r [i];
@@ -397,19 +398,19 @@ static void lpc_reverse (float *past_end, int n, int extra)      /* past_end[-1]
 
 typedef struct {
     OraResampler *r;
-    float *ring;
-    const float *in; int in_stride, n_in;
-    float *out; int out_stride, out_cap;
+    ora_s *ring;
+    const ora_s *in; int in_stride, n_in;
+    ora_s *out; int out_stride, out_cap;
     double ratio;
     /* results */
     double read_pos; int write_pos, flags;
     OraResult res;
 } ChannelRun;
 
-static void ring_rewind (const OraResampler *r, float *ring, double *pos, int *wp)
+static void ring_rewind (const OraResampler *r, ora_s *ring, double *pos, int *wp)
 {
     const int keep = r->taps, drop = r->ring_len - r->taps;
-    memmove (ring, ring + drop, sizeof (float) * keep);
+    memmove (ring, ring + drop, sizeof (ora_s) * keep);
     *pos -= drop;
     *wp -= drop;
 }
@@ -422,15 +423,15 @@ static void *run_channel (void *arg)
     double pos = r->read_pos, step = 0.0;
     int wp = r->write_pos, flags = r->flags;
     int n_in = c->n_in, cap = c->out_cap;
-    const float *in = c->in;
-    float *out = c->out;
+    const ora_s *in = c->in;
+    ora_s *out = c->out;
     unsigned used = 0, made = 0;
 
     if (n_in < 0) {                                     /* flush: append half a window of silence */
         if (r->ring_len - wp < half)
             ring_rewind (r, c->ring, &pos, &wp);
 
-        memset (c->ring + wp, 0, sizeof (float) * (r->ring_len - wp));
+        memset (c->ring + wp, 0, sizeof (ora_s) * (r->ring_len - wp));
         if (flags & ORA_EXTRAPOLATE)                    /* resampler.c:677-680 */
             lpc_forward (c->ring + wp - half, half, half);
         flags |= ORA_FLUSHED;
@@ -456,7 +457,7 @@ static void *run_channel (void *arg)
                     lpc_reverse (c->ring + wp, known, r->taps - known);
                 flags &= ~ORA_PREFILL;
             }
-            *out = (float) evaluate_at (r, c->ring, pos + step);
+            *out = (ora_s) evaluate_at (r, c->ring, pos + step);
             out += c->out_stride;
             step = (double)(++made) / c->ratio;         /* division, not accumulation (resampler.c:526) */
             cap--;
@@ -473,8 +474,8 @@ static void *run_channel (void *arg)
     return NULL;
 }
 
-static OraResult run_all (OraResampler *r, const float *const *in, int in_stride, int n_in,
-                          float *const *out, int out_stride, int out_cap, double ratio, int threads)
+static OraResult run_all (OraResampler *r, const ora_s *const *in, int in_stride, int n_in,
+                          ora_s *const *out, int out_stride, int out_cap, double ratio, int threads)
 {
     const int C = r->channels;
     ChannelRun *runs = calloc (C, sizeof (ChannelRun));
@@ -511,24 +512,24 @@ static OraResult run_all (OraResampler *r, const float *const *in, int in_stride
     return res;
 }
 
-OraResult ora_resample_interleaved (OraResampler *r, const float *in, int n_in, float *out, int out_cap, double ratio, int threads)
+OraResult ora_resample_interleaved (OraResampler *r, const ora_s *in, int n_in, ora_s *out, int out_cap, double ratio, int threads)
 {
     const int C = r->channels;
-    const float **ip = malloc (sizeof (float *) * C);
-    float **op = malloc (sizeof (float *) * C);
+    const ora_s **ip = malloc (sizeof (ora_s *) * C);
+    ora_s **op = malloc (sizeof (ora_s *) * C);
     for (int c = 0; c < C; ++c) { ip [c] = in ? in + c : NULL; op [c] = out + c; }
     OraResult res = run_all (r, in ? ip : NULL, C, n_in, op, C, out_cap, ratio, threads);
     free (ip); free (op);
     return res;
 }
 
-OraResult ora_resample_planar (OraResampler *r, const float *const *in, int n_in, float *const *out, int out_cap, double ratio, int threads)
+OraResult ora_resample_planar (OraResampler *r, const ora_s *const *in, int n_in, ora_s *const *out, int out_cap, double ratio, int threads)
 {
     return run_all (r, in, 1, n_in, out, 1, out_cap, ratio, threads);
 }
 
 /* process then flush into the tail (resampler.c:741-758) */
-OraResult ora_resample_interleaved_flush (OraResampler *r, const float *in, int n_in, float *out, int out_cap, double ratio, int threads)
+OraResult ora_resample_interleaved_flush (OraResampler *r, const ora_s *in, int n_in, ora_s *out, int out_cap, double ratio, int threads)
 {
     OraResult res = ora_resample_interleaved (r, in, n_in, out, out_cap, ratio, threads);
 
@@ -551,11 +552,11 @@ void ora_biquad_lowpass (OraBiquadCoeffs *c, double freq)
     double norm = 1.0 / (1.0 + K / Q + K * K);
 
     memset (c, 0, sizeof (*c));
-    c->a0 = (float)(K * K * norm);
-    c->a1 = (float)(2 * c->a0);           /* uses the already-rounded a0 (biquad.c:26) */
+    c->a0 = (ora_s)(K * K * norm);
+    c->a1 = (ora_s)(2 * c->a0);           /* uses the already-rounded a0 (biquad.c:26) */
     c->a2 = c->a0;
-    c->b1 = (float)(2.0 * (K * K - 1.0) * norm);
-    c->b2 = (float)((1.0 - K / Q + K * K) * norm);
+    c->b1 = (ora_s)(2.0 * (K * K - 1.0) * norm);
+    c->b2 = (ora_s)((1.0 - K / Q + K * K) * norm);
 }
 
 void ora_biquad_highpass (OraBiquadCoeffs *c, double freq)
@@ -564,18 +565,18 @@ void ora_biquad_highpass (OraBiquadCoeffs *c, double freq)
     double norm = 1.0 / (1.0 + K / Q + K * K);
 
     memset (c, 0, sizeof (*c));
-    c->a0 = (float) norm;
-    c->a1 = (float)(-2.0 * norm);
+    c->a0 = (ora_s) norm;
+    c->a1 = (ora_s)(-2.0 * norm);
     c->a2 = c->a0;
-    c->b1 = (float)(2.0 * (K * K - 1.0) * norm);
-    c->b2 = (float)((1.0 - K / Q + K * K) * norm);
+    c->b1 = (ora_s)(2.0 * (K * K - 1.0) * norm);
+    c->b2 = (ora_s)((1.0 - K / Q + K * K) * norm);
 }
 
 void ora_biquad_init (OraBiquad *f, const OraBiquadCoeffs *c, double gain)
 {
     memset (f, 0, sizeof (*f));
-    f->a [0] = (float)(c->a0 * gain); f->a [1] = (float)(c->a1 * gain); f->a [2] = (float)(c->a2 * gain);
-    f->a [3] = (float)(c->a3 * gain); f->a [4] = (float)(c->a4 * gain);
+    f->a [0] = (ora_s)(c->a0 * gain); f->a [1] = (ora_s)(c->a1 * gain); f->a [2] = (ora_s)(c->a2 * gain);
+    f->a [3] = (ora_s)(c->a3 * gain); f->a [4] = (ora_s)(c->a4 * gain);
     f->b [1] = c->b1; f->b [2] = c->b2; f->b [3] = c->b3; f->b [4] = c->b4;
 
     f->order = (c->a4 != 0.0f || c->b4 != 0.0f) ? 4 :
@@ -584,9 +585,9 @@ void ora_biquad_init (OraBiquad *f, const OraBiquadCoeffs *c, double gain)
 }
 
 /* per-sample form: highest order term first (biquad.c:78-102) */
-float ora_biquad_sample (OraBiquad *f, float in)
+ora_s ora_biquad_sample (OraBiquad *f, ora_s in)
 {
-    float acc = in * f->a [0];
+    ora_s acc = in * f->a [0];
     int i = f->index & 3;
 
     for (int k = f->order; k >= 1; --k)
@@ -600,12 +601,12 @@ float ora_biquad_sample (OraBiquad *f, float in)
 }
 
 /* buffer form: lowest order term first, strictly left to right (biquad.c:106-163) */
-void ora_biquad_buffer (OraBiquad *f, float *buf, int n, int stride)
+void ora_biquad_buffer (OraBiquad *f, ora_s *buf, int n, int stride)
 {
     int i = f->index;
 
     while (n-- > 0) {
-        float acc = *buf * f->a [0];
+        ora_s acc = *buf * f->a [0];
 
         for (int k = 1; k <= f->order; ++k) {
             acc = acc + (f->x [(i - k + 1) & 3] * f->a [k]);
@@ -632,8 +633,8 @@ static void shaper_from_ntf (OraBiquad *f, double a1, double a2, double a3, doub
 {
     OraBiquadCoeffs c;
     memset (&c, 0, sizeof (c));
-    c.a0 = (float)(b1 - a1); c.a1 = (float)(b2 - a2); c.a2 = (float)(b3 - a3); c.a3 = (float)(b4 - a4);
-    c.b1 = (float) b1; c.b2 = (float) b2; c.b3 = (float) b3; c.b4 = (float) b4;
+    c.a0 = (ora_s)(b1 - a1); c.a1 = (ora_s)(b2 - a2); c.a2 = (ora_s)(b3 - a3); c.a3 = (ora_s)(b4 - a4);
+    c.b1 = (ora_s) b1; c.b2 = (ora_s) b2; c.b3 = (ora_s) b3; c.b4 = (ora_s) b4;
     ora_biquad_init (f, &c, 1.0);
 }
 
@@ -641,7 +642,7 @@ OraDecimator *ora_decimate_init (int channels, int bits, int bytes, double gain,
 {
     OraDecimator *d = calloc (1, sizeof (*d));
     d->channels = channels; d->bits = bits; d->bytes = bytes; d->gain = gain; d->flags = flags;
-    d->feedback = calloc (channels, sizeof (float));
+    d->feedback = calloc (channels, sizeof (ora_s));
 
     if (flags & ORA_DITHER_ANY) {
         /* seeds = consecutive bytes of (state >> 24), three LCG steps per byte (decimator.c:40-52) */
@@ -693,21 +694,21 @@ static double tpdf_value (uint32_t *gen, int type)
     return (((first >> 1) + (r >> 1)) / 2147483648.0) - 1.0;
 }
 
-static int decimate_one (OraDecimator *d, int ch, float in, unsigned char *out)
+static int decimate_one (OraDecimator *d, int ch, ora_s in, unsigned char *out)
 {
-    const float scale = (float)((1 << d->bits) / 2.0 * d->gain);
+    const ora_s scale = (ora_s)((1 << d->bits) / 2.0 * d->gain);
     const int pad = d->bytes - ((d->bits + 7) / 8);
     const int32_t hi = (1 << (d->bits - 1)) - 1, lo = ~hi;
     const int shift = (24 - d->bits) % 8;
     int clipped = 0;
 
-    float dither = (d->flags & ORA_DITHER_ANY) ? (float) tpdf_value (d->gens + ch, d->dither_type) : 0.0f;
-    float code = (in * scale) - d->feedback [ch];
-    float dithered = code + dither;
+    ora_s dither = (d->flags & ORA_DITHER_ANY) ? (ora_s) tpdf_value (d->gens + ch, d->dither_type) : 0.0f;
+    ora_s code = (in * scale) - d->feedback [ch];
+    ora_s dithered = code + dither;
     int32_t q = (int32_t) floor ((double) dithered + 0.5);
 
     if (d->flags & ORA_SHAPE_ANY)
-        d->feedback [ch] = ora_biquad_sample (d->shapers + ch, (float) q - code);
+        d->feedback [ch] = ora_biquad_sample (d->shapers + ch, (ora_s) q - code);
 
     if (q > hi) { q = hi; clipped = 1; }
     else if (q < lo) { q = lo; clipped = 1; }
@@ -720,7 +721,7 @@ static int decimate_one (OraDecimator *d, int ch, float in, unsigned char *out)
     return clipped;
 }
 
-int ora_decimate_interleaved (OraDecimator *d, const float *in, int frames, unsigned char *out)
+int ora_decimate_interleaved (OraDecimator *d, const ora_s *in, int frames, unsigned char *out)
 {
     int clips = 0;
     for (int i = 0; i < frames; ++i)
@@ -729,7 +730,7 @@ int ora_decimate_interleaved (OraDecimator *d, const float *in, int frames, unsi
     return clips;
 }
 
-int ora_decimate_planar (OraDecimator *d, const float *const *in, int frames, unsigned char *const *out)
+int ora_decimate_planar (OraDecimator *d, const ora_s *const *in, int frames, unsigned char *const *out)
 {
     int clips = 0;
     for (int i = 0; i < frames; ++i)
@@ -738,22 +739,22 @@ int ora_decimate_planar (OraDecimator *d, const float *const *in, int frames, un
     return clips;
 }
 
-void ora_float_integers_le (const unsigned char *in, double gain, int bits, int bytes, int stride, float *out, int n)
+void ora_float_integers_le (const unsigned char *in, double gain, int bits, int bytes, int stride, ora_s *out, int n)
 {
     const int width = (bits + 7) / 8;
     const size_t hop = (size_t) stride * bytes;
     in += bytes - width;
 
     if (bits <= 8) {
-        float g = (float)(gain / 128.0);
+        ora_s g = (ora_s)(gain / 128.0);
         for (int i = 0; i < n; ++i, in += hop) out [i] = ((int) in [0] - 128) * g;
     }
     else if (bits <= 16) {
-        float g = (float)(gain / 32768.0);
+        ora_s g = (ora_s)(gain / 32768.0);
         for (int i = 0; i < n; ++i, in += hop) out [i] = (int16_t)(in [0] | (in [1] << 8)) * g;
     }
     else if (bits <= 24) {
-        float g = (float)(gain / 8388608.0);
+        ora_s g = (ora_s)(gain / 8388608.0);
         for (int i = 0; i < n; ++i, in += hop) {
             int32_t v = (int32_t)((uint32_t) in [0] | ((uint32_t) in [1] << 8) | ((uint32_t)(int32_t)(signed char) in [2] << 16));
             out [i] = v * g;
@@ -765,26 +766,26 @@ void ora_float_integers_le (const unsigned char *in, double gain, int bits, int 
  * artest's synthetic input and checksums  (artest.c:744-798, :90-104, :587-588)
  * ---------------------------------------------------------------------------------------- */
 
-uint64_t ora_noise_fill (float *dst, long count, uint64_t s)
+uint64_t ora_noise_fill (ora_s *dst, long count, uint64_t s)
 {
     while (count-- > 0) {
         s = ((s << 4) - s) ^ 1; s = ((s << 4) - s) ^ 1; s = ((s << 4) - s) ^ 1;
-        *dst++ = (float)((int32_t)(s >> 32) / 4294967296.0);
+        *dst++ = (ora_s)((int32_t)(s >> 32) / 4294967296.0);
     }
     return s;
 }
 
-void ora_fade_in (float *data, int count)
+void ora_fade_in (ora_s *data, int count)
 {
     int zeros = count / 4, ramp = count - zeros;
     for (int i = 0; i < zeros; ++i) *data++ = 0.0f;
-    for (int i = 0; i < ramp; ++i, ++data) *data = (float)(*data * ((cos ((ramp - i) * M_PI / ramp) + 1.0) / 2.0));
+    for (int i = 0; i < ramp; ++i, ++data) *data = (ora_s)(*data * ((cos ((ramp - i) * M_PI / ramp) + 1.0) / 2.0));
 }
 
-void ora_fade_out (float *data, int count)
+void ora_fade_out (ora_s *data, int count)
 {
     int zeros = count / 4, ramp = count - zeros;
-    for (int i = 0; i < ramp; ++i, ++data) *data = (float)(*data * ((cos (i * M_PI / ramp) + 1.0) / 2.0));
+    for (int i = 0; i < ramp; ++i, ++data) *data = (ora_s)(*data * ((cos (i * M_PI / ramp) + 1.0) / 2.0));
     for (int i = 0; i < zeros; ++i) *data++ = 0.0f;
 }
 

@@ -15,6 +15,14 @@
 
 #include <stdint.h>
 
+/* sample type: float, or double when built with -DORA_WIDE (the reference's PATH_WIDTH=64 builds, resampler.h:22-26;
+ * _build/liboracle64_*.so) */
+#ifdef ORA_WIDE
+typedef double ora_s;
+#else
+typedef float ora_s;
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -47,9 +55,9 @@ typedef struct { unsigned int used, generated; } OraResult;
 typedef struct OraResampler {
     int channels, taps, filters, ring_len, write_pos, flags;
     double read_pos, fixed_ratio, lowpass_ratio;
-    float *bank;            /* (filters+1) rows x taps, contiguous */
-    float *ring;            /* channel c at ring + c*(ring_len+taps); each preceded by `taps` guard zeros */
-    float *ring_store;
+    ora_s *bank;            /* (filters+1) rows x taps, contiguous */
+    ora_s *ring;            /* channel c at ring + c*(ring_len+taps); each preceded by `taps` guard zeros */
+    ora_s *ring_store;
 } OraResampler;
 
 OraResampler *ora_resample_init (int channels, int taps, int filters, double lowpass_ratio, int flags);
@@ -63,41 +71,41 @@ unsigned ora_resample_expected_output (const OraResampler *r, int n_in, double r
 
 /* n_in < 0 => flush (input may be NULL).  threads > 1 => one pthread per channel
  * (the reference's workers.c model: last channel on the caller, join per call). */
-OraResult ora_resample_interleaved (OraResampler *r, const float *in, int n_in, float *out, int out_cap, double ratio, int threads);
-OraResult ora_resample_planar (OraResampler *r, const float *const *in, int n_in, float *const *out, int out_cap, double ratio, int threads);
-OraResult ora_resample_interleaved_flush (OraResampler *r, const float *in, int n_in, float *out, int out_cap, double ratio, int threads);
+OraResult ora_resample_interleaved (OraResampler *r, const ora_s *in, int n_in, ora_s *out, int out_cap, double ratio, int threads);
+OraResult ora_resample_planar (OraResampler *r, const ora_s *const *in, int n_in, ora_s *const *out, int out_cap, double ratio, int threads);
+OraResult ora_resample_interleaved_flush (OraResampler *r, const ora_s *in, int n_in, ora_s *out, int out_cap, double ratio, int threads);
 
 /* plain dot products, exposed for unit tests */
-double ora_dot_outside_in (const float *h, const float *x, int taps);
-double ora_dot_precise (const float *h, const float *x, int taps);
+double ora_dot_outside_in (const ora_s *h, const ora_s *x, int taps);
+double ora_dot_precise (const ora_s *h, const ora_s *x, int taps);
 
 /* ---- biquad (biquad.c) ---- */
-typedef struct { float a0, a1, a2, a3, a4, b1, b2, b3, b4; } OraBiquadCoeffs;      /* 36 bytes */
-typedef struct { float a[5], b[5], x[4], y[4]; int order, index; } OraBiquad;      /* 80 bytes */
+typedef struct { ora_s a0, a1, a2, a3, a4, b1, b2, b3, b4; } OraBiquadCoeffs;      /* 36 bytes (72 wide) */
+typedef struct { ora_s a[5], b[5], x[4], y[4]; int order, index; } OraBiquad;      /* 80 bytes (152 wide) */
 void ora_biquad_lowpass (OraBiquadCoeffs *c, double freq);
 void ora_biquad_highpass (OraBiquadCoeffs *c, double freq);
 void ora_biquad_init (OraBiquad *f, const OraBiquadCoeffs *c, double gain);
-float ora_biquad_sample (OraBiquad *f, float in);
-void ora_biquad_buffer (OraBiquad *f, float *buf, int n, int stride);
+ora_s ora_biquad_sample (OraBiquad *f, ora_s in);
+void ora_biquad_buffer (OraBiquad *f, ora_s *buf, int n, int stride);
 
 /* ---- decimator (decimator.c) ---- */
 typedef struct OraDecimator {
     int channels, bits, bytes, dither_type, flags;
     double gain;
-    float *feedback;
+    ora_s *feedback;
     uint32_t *gens;
     OraBiquad *shapers;
 } OraDecimator;
 OraDecimator *ora_decimate_init (int channels, int bits, int bytes, double gain, int rate, int flags);
 void ora_decimate_free (OraDecimator *d);
-int ora_decimate_interleaved (OraDecimator *d, const float *in, int frames, unsigned char *out);
-int ora_decimate_planar (OraDecimator *d, const float *const *in, int frames, unsigned char *const *out);
-void ora_float_integers_le (const unsigned char *in, double gain, int bits, int bytes, int stride, float *out, int n);
+int ora_decimate_interleaved (OraDecimator *d, const ora_s *in, int frames, unsigned char *out);
+int ora_decimate_planar (OraDecimator *d, const ora_s *const *in, int frames, unsigned char *const *out);
+void ora_float_integers_le (const unsigned char *in, double gain, int bits, int bytes, int stride, ora_s *out, int n);
 
 /* ---- artest's synthetic workload (artest.c:744-798) ---- */
-uint64_t ora_noise_fill (float *dst, long count, uint64_t state);   /* returns next state; seed 0x3141592653589793 */
-void ora_fade_in (float *data, int count);
-void ora_fade_out (float *data, int count);
+uint64_t ora_noise_fill (ora_s *dst, long count, uint64_t state);   /* returns next state; seed 0x3141592653589793 */
+void ora_fade_in (ora_s *data, int count);
+void ora_fade_out (ora_s *data, int count);
 uint64_t ora_checksum_words (uint64_t c, const void *words, long nwords);   /* c = c*3 + u32, artest.c:97 */
 uint64_t ora_checksum_bytes (uint64_t c, const unsigned char *bytes, long nbytes); /* artest.c:587-588 */
 

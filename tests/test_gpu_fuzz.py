@@ -54,7 +54,7 @@ def random_session(seed):
     return ctor, adv, calls, ch, total
 
 
-def play(cls, session, extra=0, **kw):
+def play(cls, session, extra=0, noise_fn=noise, **kw):
     ctor, adv, calls, ch, total = session
     args, ckw = list(ctor["args"]), dict(ctor["kw"])
     if "flags" in ckw:
@@ -63,7 +63,7 @@ def play(cls, session, extra=0, **kw):
         args[4] |= extra
     r = cls(*args, **ckw, **kw)
     r.advance(adv)
-    x, _ = noise(total * ch, state=0x9E3779B97F4A7C15 | 1)
+    x, _ = noise_fn(total * ch, state=0x9E3779B97F4A7C15 | 1)
     x = x.reshape(-1, ch)
     pos, ys, trace = 0, [], []
     for c in calls:
