@@ -9,6 +9,7 @@
 // wave.  Compiled with -ffp-contract=off: every multiply and add rounds separately, as in the
 // reference.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "art_internal.h"
 
 namespace {
@@ -380,6 +381,280 @@ void biquad_order2_lds_kernel (Biquad *sections, int C, art_s *buf, int frames)
     }
 }
 
+// ---- order-2 cascade, feed-forward split + section pipeline -----------------------------------------
+// A lone wave issues one instruction every ~4 cycles whatever the number of active lanes, so with 8 channels
+// the serial lanes are issue- and latency-bound: what counts is instructions (and dependent operations) per
+// sample in the recurrence.  Of the nine operations of a section only five depend on earlier outputs; the rest is
+// feed-forward and is done for a whole chunk at once by helper waves (same operations, same order, same
+// roundings):
+//
+//     helpers       u[n]  = (x[n]*a0) + (x[n-1]*a1)          p[n] = x[n-2]*a2
+//     serial lane   y[n]  = ((u[n] - (b1*y[n-1])) + p[n]) - (b2*y[n-2])
+//
+// u/p/y live in LDS per channel (time-contiguous: one ds_read_b128 feeds four samples, fetched one block of
+// eight samples ahead of the recurrence; row pitch = 4 mod 32 words keeps the channels of a wave on different
+// banks).  The workgroup is a four-stage pipeline over chunks, one barrier per step `it`, all stages of a step
+// running concurrently on different waves (different SIMDs of the CU):
+//
+//     wave 2      feed-forward 1 of chunk it+1 (inputs fetched from HBM one step earlier) | fetch chunk it+2
+//     wave 3      store chunk it-3 | feed-forward 2 of chunk it-1
+//     wave 0      section 1 of chunk it
+//     wave 1      section 2 of chunk it-2
+//
+// The first chunk takes the remainder, every later chunk has the same length (a multiple of 4).
+constexpr int FF_CAP = ART_WIDE ? 1536 : 3072;      // samples per LDS array (12 KiB); 9 arrays
+constexpr int FF_HELPERS = 64;                     // threads per helper role (one wave each)
+constexpr int FF_RUN = 48;                         // frames per helper lane and chunk (upper bound)
+
+// Raw buffer accesses with hardware bounds checking (word 3 = 0x00020000: raw, 32-bit): an out-of-range load
+// returns 0 and an out-of-range store is dropped, so the helper loops carry no per-element predicates.
+typedef unsigned int ffu2 __attribute__ ((ext_vector_type (2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ff_rsrc (const void *base, size_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc (const_cast<void *> (base), 0, (int) (bytes > 0x7fffffffu ? 0x7fffffffu : bytes), 0x00020000);
+}
+__attribute__ ((unused)) __device__ __forceinline__ float ff_load (__amdgpu_buffer_rsrc_t r, int off, float) { return __uint_as_float (__builtin_amdgcn_raw_buffer_load_b32 (r, off, 0, 0)); }
+__attribute__ ((unused)) __device__ __forceinline__ double ff_load (__amdgpu_buffer_rsrc_t r, int off, double)
+{
+    const ffu2 v = __builtin_amdgcn_raw_buffer_load_b64 (r, off, 0, 0);
+    return __hiloint2double ((int) v.y, (int) v.x);
+}
+__attribute__ ((unused)) __device__ __forceinline__ void ff_store (__amdgpu_buffer_rsrc_t r, int off, float v) { __builtin_amdgcn_raw_buffer_store_b32 (__float_as_uint (v), r, off, 0, 0); }
+__attribute__ ((unused)) __device__ __forceinline__ void ff_store (__amdgpu_buffer_rsrc_t r, int off, double v)
+{
+    ffu2 w; w.x = (unsigned int) __double2loint (v); w.y = (unsigned int) __double2hiint (v);
+    __builtin_amdgcn_raw_buffer_store_b64 (w, r, off, 0, 0);
+}
+
+__device__ __forceinline__ void ff_serial (art_s *row, const art_s *prow, int len, art_s b1, art_s b2, art_s &y1, art_s &y2)
+{
+    typedef art_s vec4 __attribute__ ((ext_vector_type (4)));
+    auto four = [&] (const vec4 u, const vec4 p) -> vec4 {
+        vec4 y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const art_s m = b1 * y1;
+            const art_s t2 = u [j] - m;
+            const art_s t3 = t2 + p [j];
+            const art_s q = b2 * y2;
+            const art_s v = t3 - q;
+            y [j] = v; y2 = y1; y1 = v;
+        }
+        return y;
+    };
+    // blocks of eight samples, two register sets: the reads of the next block are issued before the recurrence of
+    // the current one starts (sched_barrier keeps the compiler from sinking them), so LDS latency never sits on
+    // the serial path.  The look-ahead may read up to one block past `len` (inside the LDS allocation, unused).
+    const int nblk = len >> 3;
+    if (nblk > 0) {
+        vec4 ua0 = *(const vec4 *)(row), ua1 = *(const vec4 *)(row + 4), pa0 = *(const vec4 *)(prow), pa1 = *(const vec4 *)(prow + 4);
+        int blk = 0;
+        for (; blk + 2 <= nblk; blk += 2) {
+            art_s *r = row + 8 * blk; const art_s *pr = prow + 8 * blk;
+            const vec4 ub0 = *(const vec4 *)(r + 8), ub1 = *(const vec4 *)(r + 12), pb0 = *(const vec4 *)(pr + 8), pb1 = *(const vec4 *)(pr + 12);
+            __builtin_amdgcn_sched_barrier (0);
+            const vec4 ya0 = four (ua0, pa0), ya1 = four (ua1, pa1);
+            *(vec4 *)(r) = ya0; *(vec4 *)(r + 4) = ya1;
+            __builtin_amdgcn_sched_barrier (0);
+            ua0 = *(const vec4 *)(r + 16); ua1 = *(const vec4 *)(r + 20); pa0 = *(const vec4 *)(pr + 16); pa1 = *(const vec4 *)(pr + 20);
+            __builtin_amdgcn_sched_barrier (0);
+            const vec4 yb0 = four (ub0, pb0), yb1 = four (ub1, pb1);
+            *(vec4 *)(r + 8) = yb0; *(vec4 *)(r + 12) = yb1;
+            __builtin_amdgcn_sched_barrier (0);
+        }
+        if (blk < nblk) {
+            const vec4 ya0 = four (ua0, pa0), ya1 = four (ua1, pa1);
+            *(vec4 *)(row + 8 * blk) = ya0; *(vec4 *)(row + 8 * blk + 4) = ya1;
+        }
+    }
+    int f = 8 * nblk;
+    for (; f < len; ++f) {
+        const art_s m = b1 * y1;
+        const art_s t2 = row [f] - m;
+        const art_s t3 = t2 + prow [f];
+        const art_s q = b2 * y2;
+        const art_s v = t3 - q;
+        row [f] = v; y2 = y1; y1 = v;
+    }
+}
+
+template <int S>                                   // S = 1 or 2 order-2 sections per channel
+__global__ __launch_bounds__ (ST_THREADS)
+void biquad_order2_ff_kernel (Biquad *sections, int C, art_s *buf, int frames)
+{
+    extern __shared__ __attribute__ ((aligned (32))) unsigned char ff_lds [];
+    art_s *const A1 = (art_s *) ff_lds;            // [3][FF_CAP]  u1 -> y1, by chunk % 3
+    art_s *const B1 = A1 + 3 * FF_CAP;             // [2][FF_CAP]  p1, by chunk parity
+    art_s *const A2 = B1 + 2 * FF_CAP;             // [2][FF_CAP]  u2 -> y2
+    art_s *const B2 = A2 + 2 * FF_CAP;             // [2][FF_CAP]  p2
+    __shared__ art_s ffc [2][64][3];               // a0, a1, a2 per section and channel
+    __shared__ art_s xtail [2][64][2];             // the two inputs preceding a chunk, by chunk parity: [0] nearest
+    __shared__ art_s mtail [3][64][2];             // the two section-1 outputs preceding a chunk (chunk % 3)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c0 = blockIdx.x * 64, Cg = min (64, C - c0);
+
+    // Chunk geometry.  A helper lane owns `run` consecutive frames of one channel (hc) in every chunk, `runs` lanes
+    // per channel; a chunk is exactly runs*run frames (run a multiple of 4), the first chunk takes the remainder.
+    int pitch = FF_CAP / Cg;
+    pitch = pitch >= 36 ? ((pitch - 4) / 32) * 32 + 4 : pitch & ~3;
+    const int runs = FF_HELPERS / Cg;
+    const int hc = lane % Cg, hr = lane / Cg;
+    int run = min (FF_RUN, ((pitch >= 36 ? pitch - 4 : pitch) / runs) & ~3);
+    {   // no more chunk than the call has frames (short calls: several short chunks keep all four stages busy)
+        const int want = (((frames + 3) / 4 + runs - 1) / runs + 3) & ~3;
+        run = max (4, min (run, want));
+    }
+    const int len = runs * run;                                     // every chunk but the first
+    const int nchunks = (frames + len - 1) / len;
+    const int len0 = frames - (nchunks - 1) * len;                  // 1 .. len
+    auto chunk_start = [&] (int k) { return k == 0 ? 0 : len0 + (k - 1) * len; };
+    auto chunk_len = [&] (int k) { return k == 0 ? len0 : len; };
+    const int f0 = hr * run;
+
+    // per-lane recurrence state: wave 0 owns section 1, wave 1 section 2
+    art_s b1 = 0, b2 = 0, y1 = 0, y2 = 0;
+    art_s xt [4] = { 0, 0, 0, 0 };                 // the call's last four inputs (section 1's x history afterwards)
+    if (tid < Cg) {
+        const Biquad &f1 = sections [(size_t)(c0 + tid) * S];
+        ffc [0][tid][0] = f1.a [0]; ffc [0][tid][1] = f1.a [1]; ffc [0][tid][2] = f1.a [2];
+        xtail [0][tid][0] = f1.x [f1.index & 3]; xtail [0][tid][1] = f1.x [(f1.index - 1) & 3];
+        b1 = f1.b [1]; b2 = f1.b [2]; y1 = f1.y [f1.index & 3]; y2 = f1.y [(f1.index - 1) & 3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xt [k] = buf [(size_t)(frames - 1 - k) * C + c0 + tid];     // frames >= 4 (launcher)
+        if (S == 2) {
+            const Biquad &f2 = sections [(size_t)(c0 + tid) * S + 1];
+            ffc [1][tid][0] = f2.a [0]; ffc [1][tid][1] = f2.a [1]; ffc [1][tid][2] = f2.a [2];
+            mtail [0][tid][0] = f2.x [f2.index & 3]; mtail [0][tid][1] = f2.x [(f2.index - 1) & 3];
+        }
+    }
+    else if (S == 2 && wave == 1 && lane < Cg) {
+        const Biquad &f2 = sections [(size_t)(c0 + lane) * S + 1];
+        b1 = f2.b [1]; b2 = f2.b [2]; y1 = f2.y [f2.index & 3]; y2 = f2.y [(f2.index - 1) & 3];
+    }
+    __syncthreads ();
+
+    const int store_lag = S == 2 ? 3 : 1;          // chunk k leaves the last section in step k + store_lag - 1
+    const int esz = (int) sizeof (art_s);
+    art_s xr [FF_RUN + 2];                         // wave 2: its run of the next chunk's inputs (+ the two before it)
+    art_s xl0 = 0, xl1 = 0;                        //         and that chunk's last two inputs (hr == 0 lanes)
+    auto fetch = [&] (int k) {
+        if (wave != 2 || hr >= runs || k >= nchunks) return;
+        const int L = chunk_len (k);
+        const __amdgpu_buffer_rsrc_t rs = ff_rsrc (buf + (size_t) chunk_start (k) * C + c0, ((size_t) L * C - c0) * esz);
+        const int base = ((f0 - 2) * C + hc) * esz;              // negative offsets wrap out of range: read as 0
+#pragma unroll
+        for (int j = 0; j < FF_RUN + 2; ++j) {
+            if (j >= run + 2) break;
+            xr [j] = ff_load (rs, base + j * C * esz, art_s ());
+        }
+        xl0 = ff_load (rs, ((L - 1) * C + hc) * esz, art_s ());
+        xl1 = ff_load (rs, ((L - 2) * C + hc) * esz, art_s ());
+    };
+    fetch (0);
+
+    for (int it = -1; it < nchunks + store_lag; ++it) {
+        // Wave 2 only ever has loads in flight and wave 3 only stores, so neither waits for the other's memory
+        // latency; the same (channel, frame) always belongs to the same lane, so wave 3 may store a buffer and
+        // refill it without a barrier in between.
+        if (wave == 2) {
+            if (hr < runs) {
+                if (it + 1 < nchunks) {                    // section 1's feed-forward part of chunk it+1, from the
+                    const int k = it + 1, L = chunk_len (k), par = k & 1;      // inputs fetched during the previous step
+                    art_s *ud = A1 + (k % 3) * FF_CAP + hc * pitch + f0, *pd = B1 + par * FF_CAP + hc * pitch + f0;
+                    // the two frames before the chunk may already hold outputs (in-place): they come from xtail
+                    if (hr == 0) {
+                        xr [0] = xtail [par][hc][1]; xr [1] = xtail [par][hc][0];
+                        xtail [par ^ 1][hc][0] = xl0; xtail [par ^ 1][hc][1] = L >= 2 ? xl1 : xr [1];
+                    }
+                    const art_s a0 = ffc [0][hc][0], a1 = ffc [0][hc][1], a2 = ffc [0][hc][2];
+#pragma unroll
+                    for (int j = 0; j < FF_RUN; ++j) {     // frames past a short first chunk land in row slack
+                        if (j >= run) break;
+                        const art_s p0 = xr [j + 2] * a0, p1 = xr [j + 1] * a1;
+                        ud [j] = p0 + p1;
+                        pd [j] = xr [j] * a2;
+                    }
+                }
+                fetch (it + 2);                            // in flight across the barrier
+            }
+        }
+        else if (wave == 3) {
+            if (hr < runs) {
+                {   // store the chunk that left the last section
+                    const int k = it - store_lag;
+                    if (k >= 0) {
+                        const int L = chunk_len (k);
+                        const art_s *src = (S == 2 ? A2 + (k & 1) * FF_CAP : A1 + (k % 3) * FF_CAP) + hc * pitch + f0;
+                        const __amdgpu_buffer_rsrc_t rs = ff_rsrc (buf + (size_t) chunk_start (k) * C + c0, ((size_t) L * C - c0) * esz);
+                        const int base = (f0 * C + hc) * esz;
+                        art_s v [FF_RUN];
+#pragma unroll
+                        for (int j = 0; j < FF_RUN; ++j) { if (j >= run) break; v [j] = src [j]; }
+#pragma unroll
+                        for (int j = 0; j < FF_RUN; ++j) { if (j >= run) break; ff_store (rs, base + j * C * esz, v [j]); }
+                    }
+                }
+                if (S == 2 && it >= 1 && it <= nchunks) {  // section 2's feed-forward part from section 1's outputs
+                    const int k = it - 1;
+                    const art_s *row = A1 + (k % 3) * FF_CAP + hc * pitch + f0;
+                    art_s *ud = A2 + (k & 1) * FF_CAP + hc * pitch + f0, *pd = B2 + (k & 1) * FF_CAP + hc * pitch + f0;
+                    art_s x [FF_RUN + 2];
+#pragma unroll
+                    for (int j = 0; j < FF_RUN + 2; ++j) {
+                        if (j >= run + 2) break;
+                        x [j] = row [hr == 0 && j < 2 ? 0 : j - 2];
+                    }
+                    if (hr == 0) { x [0] = mtail [k % 3][hc][1]; x [1] = mtail [k % 3][hc][0]; }
+                    const art_s a0 = ffc [1][hc][0], a1 = ffc [1][hc][1], a2 = ffc [1][hc][2];
+#pragma unroll
+                    for (int j = 0; j < FF_RUN; ++j) {
+                        if (j >= run) break;
+                        const art_s p0 = x [j + 2] * a0, p1 = x [j + 1] * a1;
+                        ud [j] = p0 + p1;
+                        pd [j] = x [j] * a2;
+                    }
+                }
+            }
+        }
+        else if (wave == 0) {
+            if (lane < Cg && it >= 0 && it < nchunks) {
+                ff_serial (A1 + (it % 3) * FF_CAP + lane * pitch, B1 + (it & 1) * FF_CAP + lane * pitch, chunk_len (it), b1, b2, y1, y2);
+                if (S == 2) { mtail [(it + 1) % 3][lane][0] = y1; mtail [(it + 1) % 3][lane][1] = y2; }
+            }
+        }
+        else if (S == 2) {
+            const int k = it - 2;
+            if (lane < Cg && k >= 0 && k < nchunks)
+                ff_serial (A2 + (k & 1) * FF_CAP + lane * pitch, B2 + (k & 1) * FF_CAP + lane * pitch, chunk_len (k), b1, b2, y1, y2);
+        }
+        // LDS-only barrier: wave 2's global loads (consumed next step) and wave 3's stores stay in flight across it;
+        // no thread reads global memory another thread of this launch wrote
+        asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    __syncthreads ();
+
+    // ---- state write-back: the four most recent inputs / outputs of each section ----------------------
+    if (tid < Cg) {
+        // the last chunk (>= 4 frames whenever frames >= 4) is still in LDS as section outputs
+        const int kl = nchunks - 1, L = chunk_len (kl);
+        const art_s *r1 = A1 + (kl % 3) * FF_CAP + tid * pitch + L, *r2 = A2 + (kl & 1) * FF_CAP + tid * pitch + L;
+        Biquad &f1 = sections [(size_t)(c0 + tid) * S];
+        {
+            const int i = f1.index + frames;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { f1.x [(i - k) & 3] = xt [k]; f1.y [(i - k) & 3] = r1 [-1 - k]; }
+            f1.index = i;
+        }
+        if (S == 2) {
+            Biquad &f2 = sections [(size_t)(c0 + tid) * S + 1];
+            const int i = f2.index + frames;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { f2.x [(i - k) & 3] = r1 [-1 - k]; f2.y [(i - k) & 3] = r2 [-1 - k]; }
+            f2.index = i;
+        }
+    }
+}
+
 // error-feedback filter with a compile-time order (per-sample association, reference biquad.c:83-95):
 //     acc = in*a0;  for k = ORDER..1:  acc += (x_k*a_k) - (b_k*y_k)
 // x_k / y_k for k >= 2 do not depend on the newest output, so those terms are formed ahead of the chain.
@@ -631,8 +906,20 @@ extern "C" {
 int arthip_biquad_order2 (Biquad *d_sections, int C, int S, art_s *d_buf, int frames, void *stream)
 {
     if (frames <= 0) return 0;
-    if (S == 1) hipLaunchKernelGGL (biquad_order2_lds_kernel<1>, dim3 ((C + 63) / 64), dim3 (ST_THREADS), 0, (hipStream_t) stream, d_sections, C, d_buf, frames);
-    else if (S == 2) hipLaunchKernelGGL (biquad_order2_lds_kernel<2>, dim3 ((C + 63) / 64), dim3 (ST_THREADS), 0, (hipStream_t) stream, d_sections, C, d_buf, frames);
+    static const bool legacy = getenv ("ARTAMD_BIQUAD_LEGACY") != nullptr;       // ablation: the single-lane-does-everything form
+    if (legacy && S == 1) hipLaunchKernelGGL (biquad_order2_lds_kernel<1>, dim3 ((C + 63) / 64), dim3 (ST_THREADS), 0, (hipStream_t) stream, d_sections, C, d_buf, frames);
+    else if (legacy && S == 2) hipLaunchKernelGGL (biquad_order2_lds_kernel<2>, dim3 ((C + 63) / 64), dim3 (ST_THREADS), 0, (hipStream_t) stream, d_sections, C, d_buf, frames);
+    else if (S == 1 || S == 2) {
+        const size_t lds = (size_t) 9 * FF_CAP * sizeof (art_s) + 256;           // 108 KiB of the CU's 160 (+ look-ahead slack)
+        static bool once = false;
+        if (!once) {
+            (void) hipFuncSetAttribute ((const void *) biquad_order2_ff_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            (void) hipFuncSetAttribute ((const void *) biquad_order2_ff_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            once = true;
+        }
+        if (S == 1) hipLaunchKernelGGL (biquad_order2_ff_kernel<1>, dim3 ((C + 63) / 64), dim3 (ST_THREADS), lds, (hipStream_t) stream, d_sections, C, d_buf, frames);
+        else hipLaunchKernelGGL (biquad_order2_ff_kernel<2>, dim3 ((C + 63) / 64), dim3 (ST_THREADS), lds, (hipStream_t) stream, d_sections, C, d_buf, frames);
+    }
     else return -1;
     return hipGetLastError () == hipSuccess ? 0 : -1;
 }

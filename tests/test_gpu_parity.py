@@ -328,3 +328,46 @@ def test_decimator_planar_device_and_ingest():
         o = np.zeros(50, np.float32)
         L.floatIntegersLE(raw.ctypes.data_as(u8p), 0.75, bits, nbytes, 2, o.ctypes.data_as(f32p), 50)
         assert np.array_equal(o.view(np.uint32), z[f"ingest/{bits}_{nbytes}"].view(np.uint32))
+
+
+@pytest.mark.parametrize("ch,nsec", [(1, 1), (1, 2), (2, 2), (3, 1), (5, 2), (8, 1), (43, 2), (64, 2), (70, 2)])
+def test_biquad_bank_pipeline_geometries_bit_exact(ch, nsec):
+    """the feed-forward / four-stage biquad kernel over channel counts (lane mappings, several workgroups) and call
+    lengths (one chunk, remainders of 1..3 frames, many chunks), state carried across calls — against the oracle"""
+    torch = pytest.importorskip("torch")
+    from _oracle import load_oracle, Biquad as OBiquad, BiquadCoeffs as OCoeffs
+    L, OL = A.lib(), load_oracle()
+    lengths = [64, 65, 67, 352, 353, 1000, 4099, 20000, 3]       # the last call (3 frames) takes the generic kernel
+    total = sum(lengths)
+    x, _ = noise(total * ch, state=0xC0FFEE1234567 | 1)
+    x = x.reshape(total, ch)
+    co, oc = A.BiquadCoefficients(), OCoeffs()
+    secs = (A.Biquad * (ch * nsec))()
+    osecs = [[OBiquad() for _ in range(nsec)] for _ in range(ch)]
+    for k in range(ch):
+        for s in range(nsec):
+            f = 0.05 + 0.4 * ((k * 7 + s * 3) % 11) / 11.0
+            (L.biquad_lowpass if (k + s) % 3 else L.biquad_highpass)(C.byref(co), f)
+            (OL.ora_biquad_lowpass if (k + s) % 3 else OL.ora_biquad_highpass)(C.byref(oc), f)
+            L.biquad_init(C.byref(secs[k * nsec + s]), C.byref(co), 0.9)
+            OL.ora_biquad_init(C.byref(osecs[k][s]), C.byref(oc), 0.9)
+    bank = A.BiquadBank(secs, ch, nsec)
+    want = x.copy()
+    d = torch.from_numpy(x.copy()).cuda()
+    pos = 0
+    for n in lengths:
+        bank.apply_device(d[pos:pos + n], n)
+        view = want[pos:pos + n]
+        for k in range(ch):
+            for s in range(nsec):
+                OL.ora_biquad_buffer(C.byref(osecs[k][s]), C.cast(view.ctypes.data + 4 * k, f32p), n, ch)
+        pos += n
+    torch.cuda.synchronize()
+    got = d.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), int(np.argmax((got != want).any(axis=1)))
+    state = bank.read()
+    for k in range(ch):
+        for s in range(nsec):
+            a, b = state[k * nsec + s], osecs[k][s]
+            hist = lambda q, arr: [arr[(q.index - i) & 3] for i in range(4)]
+            assert hist(a, a.x) == hist(b, b.x) and hist(a, a.y) == hist(b, b.y), (k, s)
