@@ -638,7 +638,7 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
         if ((cxt->flags & RESAMPLE_STRICT_ORDER) && extend) a.mode |= 4;
         a.ratio = eff_ratio;
         a.period_out = hip->period_out; a.period_in = hip->period_in;
-        if (!ART_WIDE && a.period_out && a.mode == ART_MODE_FAST && hip->kernel_pref != ART_KERNEL_GENERAL) {
+        if (a.period_out && a.mode == ART_MODE_FAST && hip->kernel_pref != ART_KERNEL_GENERAL) {
             /* [0] per-launch count, [1] running total (diagnostics), [2..] the list */
             if (sizeof (unsigned int) * ((size_t) res.output_generated + 2) > hip->fix_cap) {
                 hip->d_fix = grow (hip->d_fix, &hip->fix_cap, sizeof (unsigned int) * ((size_t) res.output_generated + 2));

@@ -73,8 +73,10 @@ def check_against_golden(name, y, tr, flag_mask=0xffffffff):
 
 class HipWide(W.Resampler):
     def __init__(self, channels, taps, filters, lowpass_ratio=0.0, flags=A.BLACKMAN_HARRIS | A.SUBSAMPLE_INTERPOLATE,
-                 fixed=None, extra=0):
+                 fixed=None, extra=0, kernel=0):
         super().__init__(channels, taps, filters, lowpass_ratio, flags | extra, fixed)
+        if kernel:
+            self.set_kernel(kernel)          # 2 = force the fp64 matrix-core kernel wherever the ratio is rational
 
 
 def decimate_input(ch=2, frames=6000):
@@ -201,15 +203,16 @@ def within_tolerance(y, truth):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kernel", [0, 2])
 @pytest.mark.parametrize("name", G.NAMES)
-def test_wide_default_mode_within_tolerance_of_reference_order(name):
-    y, tr = replay(G.make(HipWide, name), name)
+def test_wide_default_mode_within_tolerance_of_reference_order(name, kernel):
+    y, tr = replay(G.make(HipWide, name, kernel=kernel), name)
     yo, tro = replay(G.make(O.OracleResampler, name), name)
     assert np.array_equal(tr[:, :4], tro[:, :4])
     ok, worst = within_tolerance(y, yo)
     assert ok, worst
     # and the extended-math flag changes nothing in this build
-    y2, _ = replay(G.make(HipWide, name, extra_flags=A.EXTEND_CONVOLUTION_MATH), name)
+    y2, _ = replay(G.make(HipWide, name, extra_flags=A.EXTEND_CONVOLUTION_MATH, kernel=kernel), name)
     assert np.array_equal(bits(y), bits(y2))
 
 
@@ -224,10 +227,11 @@ def test_wide_random_session_strict_bit_exact(seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kernel", [0, 2])
 @pytest.mark.parametrize("seed", range(40, 80))
-def test_wide_random_session_default_mode_within_tolerance(seed):
+def test_wide_random_session_default_mode_within_tolerance(seed, kernel):
     s = random_session(seed)
-    y, tr = play(HipWide, s, noise_fn=O.noise)
+    y, tr = play(HipWide, s, noise_fn=O.noise, kernel=kernel)
     yo, tro = play(O.OracleResampler, s, noise_fn=O.noise)
     assert tr == tro
     ok, worst = within_tolerance(y, yo)
@@ -261,7 +265,8 @@ def test_wide_planar_and_device_entry_points_equal_interleaved():
 
 @pytest.mark.gpu
 def test_wide_headline_shape_block_default_mode_vs_oracle():
-    # 8 channels, 988 x 988 interpolating, 44.1k -> 48k: the headline configuration with double samples (general kernel)
+    # 8 channels, 988 x 988 interpolating, 44.1k -> 48k: the headline configuration with double samples; this much work
+    # takes the fp64 matrix-core kernel by itself
     torch = pytest.importorskip("torch")
     ch, T, n = 8, 988, 16384
     ratio = 48000 / 44100
@@ -274,8 +279,39 @@ def test_wide_headline_shape_block_default_mode_vs_oracle():
     o.advance(T / 2)
     _, g, y = h.process(x, cap, ratio)
     _, go, yo = o.process(x, cap, ratio, threads=8)
-    assert g == go and h.last_kernel() == 1
+    assert g == go and h.last_kernel() == 2
     ok, worst = within_tolerance(y, yo)
+    assert ok, worst
+
+
+from test_gpu_fuzz import EDGE_CASES  # noqa: E402
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", EDGE_CASES, ids=lambda c: f"c{c[0]}_t{c[1]}_f{c[2]}_{c[3]}to{c[4]}{'_fixed' if c[5] else ''}")
+@pytest.mark.parametrize("kernel", [0, 2])
+def test_wide_edge_geometries(case, kernel):
+    ch, T, F, src, dst, fixed, flags = case
+    ratio = dst / src
+    n1, n2 = 20 * T + 77, 9 * T + 5
+    x, _ = O.noise((n1 + n2) * ch, state=0xDEADBEEFCAFEF00D | 1)
+    x = x.reshape(-1, ch)
+    kw = dict(flags=flags, fixed=(float(src), float(dst), 0)) if fixed else {}
+    args = (ch, T, F) if fixed else (ch, T, F, 0.0, flags)
+    h, o = HipWide(*args, **kw, kernel=kernel), O.OracleResampler(*args, **kw)
+    for r in (h, o):
+        r.advance(T / 2)
+    cap = int(n1 * ratio) + 64
+    for blk, n in ((x[:n1], n1), (x[n1:], n2)):
+        uh, gh, yh = h.process(blk, cap, ratio)
+        uo, go, yo = o.process(blk, cap, ratio, threads=8)
+        assert (uh, gh) == (uo, go) and h.state()[:2] == o.state()[:2]
+        ok, worst = within_tolerance(yh, yo)
+        assert ok, worst
+    _, gh, yh = h.process(None, cap, ratio, flush=True)
+    _, go, yo = o.process(None, cap, ratio, flush=True)
+    assert gh == go
+    ok, worst = within_tolerance(yh, yo)
     assert ok, worst
 
 
