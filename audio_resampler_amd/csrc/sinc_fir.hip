@@ -495,10 +495,12 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
     constexpr int PPW_C = CG ? (MF_COLS / CG > MF_MAX_PPW ? MF_MAX_PPW : MF_COLS / CG) : 1;
     constexpr int NB = CG ? (PPW_C * VPP) / MF_THREADS : 1;
 
-    float ra [MT * 4];
-    float rb [NB * VEC];
+    // two register stages: a loader commits chunk c+1 from one stage while the loads of chunk c+2 are still in
+    // flight in the other, so a load has two chunk periods to land (the L2/HBM latency is longer than one)
+    float ra0 [MT * 4], ra1 [MT * 4];
+    float rb0 [NB * VEC], rb1 [NB * VEC];
 
-    auto fetch = [&] (int chunk) {
+    auto fetch = [&] (int chunk, float (&ra) [MT * 4], float (&rb) [NB * VEC]) {
         const int k0 = chunk * MF_KC;
 #pragma unroll
         for (int m = 0; m < MT; ++m)                        // past ktot / past the last row: out of range => 0
@@ -521,7 +523,7 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
         }
     };
 
-    auto commit = [&] (int chunk, int buf) {
+    auto commit = [&] (int chunk, int buf, float (&ra) [MT * 4], float (&rb) [NB * VEC]) {
         float *As = As_ [buf], *Bs = Bs_ [buf];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -650,15 +652,21 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
         // two separate loops (disjoint live ranges => registers = max of the two roles, not the sum);
         // both execute exactly nchunks + 1 barriers
         if (loader) {
-            fetch (0); commit (0, 0); fetch (1);
+            fetch (0, ra0, rb0); fetch (1, ra1, rb1);
+            commit (0, 0, ra0, rb0); fetch (2, ra0, rb0);
             __syncthreads ();
-            for (int chunk = 0; chunk < nchunks; ++chunk) {
+            int chunk = 0;
 #ifndef ABL_NOLOAD
-                commit (chunk + 1, (chunk & 1) ^ 1);         // past-the-end chunks: loads return 0 / LDS unread
-                fetch (chunk + 2);
-#endif
+            for (; chunk + 2 <= nchunks; chunk += 2) {       // past-the-end chunks: loads return 0 / LDS unread
+                commit (chunk + 1, 1, ra1, rb1); fetch (chunk + 3, ra1, rb1);
+                __syncthreads ();
+                commit (chunk + 2, 0, ra0, rb0); fetch (chunk + 4, ra0, rb0);
                 __syncthreads ();
             }
+            if (chunk < nchunks) { commit (chunk + 1, 1, ra1, rb1); __syncthreads (); }
+#else
+            for (; chunk < nchunks; ++chunk) __syncthreads ();
+#endif
             return;
         }
         __syncthreads ();
@@ -668,12 +676,12 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
         }
     }
     else {
-        fetch (0);
+        fetch (0, ra0, rb0);
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             __syncthreads ();                                // previous chunk fully consumed
-            commit (chunk, 0);
+            commit (chunk, 0, ra0, rb0);
             __syncthreads ();
-            if (chunk + 1 < nchunks) fetch (chunk + 1);      // global loads fly while the matrix cores work
+            if (chunk + 1 < nchunks) fetch (chunk + 1, ra0, rb0);      // global loads fly while the matrix cores work
             matrix_chunk (chunk, 0);
         }
     }
