@@ -26,6 +26,7 @@ enum { ART_MODE_FAST = 0,        /* f32 FMA accumulation, any order (default) */
        ART_MODE_STRICT = 2 };    /* reference C source order, un-fused (RESAMPLE_STRICT_ORDER) */
 
 enum { ART_KERNEL_AUTO = 0, ART_KERNEL_GENERAL = 1, ART_KERNEL_MFMA = 2 };
+#define ART_FIR_ROLLED 0x100             /* arthip_fir: the history roll rode along with this launch */
 
 typedef struct {
     int count;
@@ -41,7 +42,9 @@ typedef struct {
     const art_s *in;                     /* device, new input frames */
     long in_pitch;                       /* 0: interleaved [frame][C]; else planar, channel c at in + c*in_pitch */
     art_s *out;
-    long out_pitch;                      /* 0: interleaved; else planar */
+    long out_pitch;
+    art_s *roll_dst;                     /* when set: the launch that evaluates the fix list also rolls the history */
+    int roll_appended;                   /*   (frames appended by this call) into roll_dst; arthip_fir then returns k | ART_FIR_ROLLED */                      /* 0: interleaved; else planar */
     int in_frames;                       /* frames valid at `in` (reads beyond return 0) */
     int C, T, F, H;
     int interpolate, lowpass;            /* SUBSAMPLE_INTERPOLATE / INCLUDE_LOWPASS in effect */

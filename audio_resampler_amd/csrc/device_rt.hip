@@ -45,7 +45,13 @@ int arthip_d2d (void *d, const void *s, size_t n, void *st) { return n ? fail (h
 int arthip_zero (void *d, size_t n, void *st) { return n ? fail (hipMemsetAsync (d, 0, n, (hipStream_t) st), "memset") : 0; }
 int arthip_sync (void *st) { return fail (hipStreamSynchronize ((hipStream_t) st), "sync"); }
 
-void *arthip_event_create (void) { hipEvent_t e = nullptr; return fail (hipEventCreate (&e), "hipEventCreate") ? nullptr : (void *) e; }
+void *arthip_event_create (void)
+{
+    // timing events: no system-scope fence when they fire (nothing on the host reads device memory off them), which
+    // keeps the dispatch gap an event costs on the stream to a few microseconds
+    hipEvent_t e = nullptr;
+    return fail (hipEventCreateWithFlags (&e, hipEventDisableSystemFence), "hipEventCreate") ? nullptr : (void *) e;
+}
 void arthip_event_destroy (void *e) { if (e) (void) hipEventDestroy ((hipEvent_t) e); }
 int arthip_event_record (void *e, void *st) { return fail (hipEventRecord ((hipEvent_t) e, (hipStream_t) st), "hipEventRecord"); }
 float arthip_event_elapsed_ms (void *a, void *b)

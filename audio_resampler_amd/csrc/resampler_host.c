@@ -610,6 +610,7 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
 
     const int appended = is_flush ? T / 2 : (int) res.input_used;
     const art_s *flush_in = NULL;
+    int rolled = 0;
 
     if (cxt->flags & EXTRAPOLATE_ENDPOINTS) {
         /* prefill: first output of the stream, produced by an ordinary call whose first output precedes any
@@ -664,7 +665,11 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
             if (a.n_end > a.n_begin) {
                 a.ev_start = hip->timing ? timing_event (hip) : NULL;
                 a.ev_stop = hip->timing ? timing_event (hip) : NULL;
+                /* the last FIR launch of the call may take the history roll along (one launch less on the stream) */
+                a.roll_dst = (s1 == nseg && appended > 0) ? hip->d_hist [hip->cur ^ 1] : NULL;
+                a.roll_appended = appended;
                 int k = arthip_fir (&a, &tab, hip->kernel_pref, hip->stream);
+                if (k >= 0 && (k & ART_FIR_ROLLED)) { rolled = 1; k &= ~ART_FIR_ROLLED; }
                 if (k < 0) { fprintf (stderr, "artamd: FIR launch failed: %s\n", arthip_last_error ()); res.input_used = res.output_generated = 0; return res; }
                 hip->last_kernel = k;
             }
@@ -672,7 +677,8 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
     }
 
     if (appended > 0) {
-        arthip_roll_history (hip->d_hist [hip->cur ^ 1], hip->d_hist [hip->cur], is_flush ? flush_in : d_in, is_flush ? 0 : in_pitch, appended, H, C, hip->stream);
+        if (!rolled)
+            arthip_roll_history (hip->d_hist [hip->cur ^ 1], hip->d_hist [hip->cur], is_flush ? flush_in : d_in, is_flush ? 0 : in_pitch, appended, H, C, hip->stream);
         hip->cur ^= 1;
     }
 

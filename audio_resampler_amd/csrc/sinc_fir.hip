@@ -101,6 +101,7 @@ __attribute__ ((unused)) __device__ __forceinline__ double fused (double a, doub
 
 constexpr int GEN_THREADS = 256;
 constexpr int GEN_MAX_TILE = 32;
+constexpr unsigned int GEN_LIST_BLOCKS = 512;   // workgroups walking the fix list in list mode
 
 // General kernel: one workgroup per tile of consecutive output frames; the tile's input span is
 // staged once in LDS (coalesced frame-major reads), then each wave evaluates whole output frames:
@@ -120,8 +121,23 @@ void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile, int from_list
     const int ch0 = blockIdx.y * CG;
     const int half = a.T / 2;
     const unsigned int list_len = from_list ? min (*a.fix_count, a.fix_cap) : 1u;
+    // list mode: blocks [0, GEN_LIST_BLOCKS) walk the fix list; any further blocks (x only, y == 0) roll the history
+    // for the next call (reads hist ++ in, writes the other history buffer: independent of everything else in flight)
+    const unsigned int walkers = from_list ? GEN_LIST_BLOCKS : gridDim.x;
+    if (from_list && blockIdx.x >= GEN_LIST_BLOCKS) {
+        if (blockIdx.y) return;
+        const int e = (int)(blockIdx.x - GEN_LIST_BLOCKS) * GEN_THREADS + tid;
+        if (e < a.H * a.C) {
+            const int f = e / a.C, c = e - f * a.C, lin = a.roll_appended + f;
+            art_s v = 0;
+            if (lin < a.H) v = a.hist [(size_t) lin * a.C + c];
+            else if (a.in) { const int gi = lin - a.H; v = a.in_pitch ? a.in [(size_t) c * a.in_pitch + gi] : a.in [(size_t) gi * a.C + c]; }
+            a.roll_dst [e] = v;
+        }
+        return;
+    }
 
-  for (unsigned int item = blockIdx.x; item < (from_list ? list_len : gridDim.x); item += gridDim.x) {
+  for (unsigned int item = blockIdx.x; item < (from_list ? list_len : gridDim.x); item += walkers) {
     const unsigned int n0 = from_list ? a.fix_list [item] : a.n_begin + item * (unsigned int) tile;
     const int cnt = from_list ? 1 : (int) min ((unsigned int) tile, a.n_end - n0);
 
@@ -495,10 +511,8 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
     constexpr int PPW_C = CG ? (MF_COLS / CG > MF_MAX_PPW ? MF_MAX_PPW : MF_COLS / CG) : 1;
     constexpr int NB = CG ? (PPW_C * VPP) / MF_THREADS : 1;
 
-    // two register stages: a loader commits chunk c+1 from one stage while the loads of chunk c+2 are still in
-    // flight in the other, so a load has two chunk periods to land (the L2/HBM latency is longer than one)
-    float ra0 [MT * 4], ra1 [MT * 4];
-    float rb0 [NB * VEC], rb1 [NB * VEC];
+    float ra0 [MT * 4];
+    float rb0 [NB * VEC];
 
     auto fetch = [&] (int chunk, float (&ra) [MT * 4], float (&rb) [NB * VEC]) {
         const int k0 = chunk * MF_KC;
@@ -652,21 +666,18 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
         // two separate loops (disjoint live ranges => registers = max of the two roles, not the sum);
         // both execute exactly nchunks + 1 barriers
         if (loader) {
-            fetch (0, ra0, rb0); fetch (1, ra1, rb1);
-            commit (0, 0, ra0, rb0); fetch (2, ra0, rb0);
+            // one register stage.  (A second stage in flight — commit chunk c+1 while c+2 lands — measured +3.5 % on
+            // the headline but miscomputed the first period of MONO streams with T >= 380 for a reason not understood;
+            // left out until it is.)
+            fetch (0, ra0, rb0); commit (0, 0, ra0, rb0); fetch (1, ra0, rb0);
             __syncthreads ();
-            int chunk = 0;
+            for (int chunk = 0; chunk < nchunks; ++chunk) {
 #ifndef ABL_NOLOAD
-            for (; chunk + 2 <= nchunks; chunk += 2) {       // past-the-end chunks: loads return 0 / LDS unread
-                commit (chunk + 1, 1, ra1, rb1); fetch (chunk + 3, ra1, rb1);
-                __syncthreads ();
-                commit (chunk + 2, 0, ra0, rb0); fetch (chunk + 4, ra0, rb0);
+                commit (chunk + 1, (chunk & 1) ^ 1, ra0, rb0);       // past-the-end chunks: loads return 0 / LDS unread
+                fetch (chunk + 2, ra0, rb0);
+#endif
                 __syncthreads ();
             }
-            if (chunk < nchunks) { commit (chunk + 1, 1, ra1, rb1); __syncthreads (); }
-#else
-            for (; chunk < nchunks; ++chunk) __syncthreads ();
-#endif
             return;
         }
         __syncthreads ();
@@ -999,7 +1010,8 @@ int launch_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st
     size_t lds = (size_t) span * CG * sizeof (art_s);
     if (lds > 160 * 1024 - 1024) return -1;                 // absurd ratio/taps combination
     const unsigned int total = a.n_end - a.n_begin;
-    dim3 grid (from_list ? 512u : (total + tile - 1) / tile, (a.C + CG - 1) / CG);
+    const unsigned int roll_blocks = (from_list && a.roll_dst) ? (unsigned int)((a.H * a.C + GEN_THREADS - 1) / GEN_THREADS) : 0u;
+    dim3 grid (from_list ? GEN_LIST_BLOCKS + roll_blocks : (total + tile - 1) / tile, (a.C + CG - 1) / CG);
     const bool precise = (a.mode & 3) == ART_MODE_PRECISE;
 
 #define GO(I, P) do { auto k = fir_general_kernel<CG, I, P>; \
@@ -1096,8 +1108,8 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
 #undef MF_GO
         if (a->ev_stop) arthip_event_record (a->ev_stop, stream);
         if (hipGetLastError () != hipSuccess) return -1;
-        if (run_general (*a, *segs, st, 1)) return -1;          // outputs handed back (usually none)
-        return hipGetLastError () == hipSuccess ? ART_KERNEL_MFMA : -1;
+        if (run_general (*a, *segs, st, 1)) return -1;          // outputs handed back (usually none) + the history roll
+        return hipGetLastError () == hipSuccess ? (ART_KERNEL_MFMA | (a->roll_dst ? ART_FIR_ROLLED : 0)) : -1;
     }
 
 #else
@@ -1142,8 +1154,8 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
 #undef MW_GO
                 if (a->ev_stop) arthip_event_record (a->ev_stop, stream);
                 if (hipGetLastError () != hipSuccess) return -1;
-                if (run_general (*a, *segs, st, 1)) return -1;          // outputs handed back
-                return hipGetLastError () == hipSuccess ? ART_KERNEL_MFMA : -1;
+                if (run_general (*a, *segs, st, 1)) return -1;          // outputs handed back + the history roll
+                return hipGetLastError () == hipSuccess ? (ART_KERNEL_MFMA | (a->roll_dst ? ART_FIR_ROLLED : 0)) : -1;
             }
         }
     }
