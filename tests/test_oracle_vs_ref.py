@@ -78,10 +78,12 @@ def test_threads_and_dry_runs_match_reference():
 def test_reference_flush_out_of_bounds_is_confined_to_the_tail():
     """`artest -4 -e -l -c8 -n2 -s96000 -d44100`: the reference's flush reads before buffers[c][0]
     (resampler.c:667-672 keeps `taps` samples, windows reach taps/2 further back).  Everything
-    before the flush tail is bit-identical; the tail differs by < 1e-9."""
+    before the flush tail is bit-identical.  What the reference reads there is whatever the heap holds (zeros give
+    a deviation below 1e-9, but values like 1e27 have been seen): the size of the tail deviation is not asserted."""
     mk = lambda cls: run_artest(lambda: artest_backend(cls, 4, 8, 96000, 44100, exact=True, lowpass=True), 8, 988,
                                 96000, 44100, 2, ratio_arg=0.0, collect=True)["y"]
     a, b = mk(OracleResampler), mk(RefResampler)
     tail = int(988 / 2 * 44100 / 96000) + 2
     assert np.array_equal(a[:-tail].view(np.uint32), b[:-tail].view(np.uint32))
-    assert np.abs(a[-tail:] - b[-tail:]).max() < 1e-9
+    # channels other than the first read the tail of the previous channel's ring (defined data): they agree closely
+    assert np.isfinite(a[-tail:]).all()
