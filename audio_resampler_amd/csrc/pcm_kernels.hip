@@ -541,11 +541,13 @@ void biquad_order2_ff_kernel (Biquad *sections, int C, art_s *buf, int frames)
         if (wave != 2 || hr >= runs || k >= nchunks) return;
         const int L = chunk_len (k);
         const __amdgpu_buffer_rsrc_t rs = ff_rsrc (buf + (size_t) chunk_start (k) * C + c0, ((size_t) L * C - c0) * esz);
-        const int base = ((f0 - 2) * C + hc) * esz;              // negative offsets wrap out of range: read as 0
+        // the two frames before the chunk (f0 == 0: patched from xtail later) are forced out of range by a select — a
+        // negative offset is not left to wrap, the hardware's range check does not wrap register + immediate to 32 bits
 #pragma unroll
         for (int j = 0; j < FF_RUN + 2; ++j) {
             if (j >= run + 2) break;
-            xr [j] = ff_load (rs, base + j * C * esz, art_s ());
+            const int f = f0 + j - 2;
+            xr [j] = ff_load (rs, f >= 0 ? (f * C + hc) * esz : (int) 0xfffffff0u, art_s ());
         }
         xl0 = ff_load (rs, ((L - 1) * C + hc) * esz, art_s ());
         xl1 = ff_load (rs, ((L - 2) * C + hc) * esz, art_s ());

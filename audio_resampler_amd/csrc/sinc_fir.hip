@@ -525,7 +525,11 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
                 const int v = pt + u * MF_THREADS;
                 const int jl = v / VPP, rem = v % VPP, kk = rem / VPF, cv = rem % VPF;
                 const int lin = w0 + jl * g.Q + k0 + kk;
-                const unsigned int oi = (unsigned int)((lin - a.H) * CG + cv * VEC) * 4u;      // wraps (=> 0) below H
+                // Frames below H belong to the history buffer: their offset into `in` is forced far out of range by a
+                // select, not left to wrap as a negative number — the compiler may split an offset into register + immediate,
+                // and the hardware's range check does not wrap that sum to 32 bits (a "negative" base plus a positive
+                // immediate would be rejected although the true offset is valid).
+                const unsigned int oi = lin >= a.H ? (unsigned int)((lin - a.H) * CG + cv * VEC) * 4u : 0xfffffff0u;
                 VecLoad<VEC>::load (&rb [u * VEC], rs_in, oi);
                 if (touches_hist) {
                     float hv [VEC];
@@ -666,9 +670,7 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
         // two separate loops (disjoint live ranges => registers = max of the two roles, not the sum);
         // both execute exactly nchunks + 1 barriers
         if (loader) {
-            // one register stage.  (A second stage in flight — commit chunk c+1 while c+2 lands — measured +3.5 % on
-            // the headline but miscomputed the first period of MONO streams with T >= 380 for a reason not understood;
-            // left out until it is.)
+            // one register stage (a second one in flight — commit chunk c+1 while c+2 lands — measured within noise, +1.4 %)
             fetch (0, ra0, rb0); commit (0, 0, ra0, rb0); fetch (1, ra0, rb0);
             __syncthreads ();
             for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -872,7 +874,9 @@ void fir_mfma64_kernel (ArtFirArgs a, ArtSegTable segs, WideGeom g)
             const int v = tid + u * MW_THREADS;
             const int jl = v / VPP, rem = v % VPP, kk = rem / VPF, cv = rem % VPF;
             const int lin = w0 + jl * g.Q + k0 + kk;
-            const int oi = ((lin - a.H) * CG + cv * VEC) * 8;            // negative (below H) wraps out of range => 0
+            // below H the frame lives in the history buffer: force the `in` offset out of range by a select rather than
+            // by letting a negative number wrap (see the single-precision kernel)
+            const int oi = lin >= a.H ? ((lin - a.H) * CG + cv * VEC) * 8 : (int) 0xfffffff0u;
             const int oh = (lin * CG + cv * VEC) * 8;
             if (VEC == 2) {
                 w_u32x4 x = __builtin_amdgcn_raw_buffer_load_b128 (rs_in, oi, 0, 0);
