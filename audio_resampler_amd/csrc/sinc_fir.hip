@@ -533,7 +533,7 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
                 VecLoad<VEC>::load (&rb [u * VEC], rs_in, oi);
                 if (touches_hist) {
                     float hv [VEC];
-                    VecLoad<VEC>::load (hv, rs_hist, (unsigned int)(lin * CG + cv * VEC) * 4u);
+                    VecLoad<VEC>::load (hv, rs_hist, (lin >= 0 && lin < a.H) ? (unsigned int)(lin * CG + cv * VEC) * 4u : 0xfffffff0u);
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) rb [u * VEC + e] = __uint_as_float (__float_as_uint (rb [u * VEC + e]) | __float_as_uint (hv [e]));
                 }
@@ -877,7 +877,7 @@ void fir_mfma64_kernel (ArtFirArgs a, ArtSegTable segs, WideGeom g)
             // below H the frame lives in the history buffer: force the `in` offset out of range by a select rather than
             // by letting a negative number wrap (see the single-precision kernel)
             const int oi = lin >= a.H ? ((lin - a.H) * CG + cv * VEC) * 8 : (int) 0xfffffff0u;
-            const int oh = (lin * CG + cv * VEC) * 8;
+            const int oh = (lin >= 0 && lin < a.H) ? (lin * CG + cv * VEC) * 8 : (int) 0xfffffff0u;
             if (VEC == 2) {
                 w_u32x4 x = __builtin_amdgcn_raw_buffer_load_b128 (rs_in, oi, 0, 0);
                 if (touches_hist) { const w_u32x4 h = __builtin_amdgcn_raw_buffer_load_b128 (rs_hist, oh, 0, 0); x |= h; }
@@ -1055,15 +1055,25 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
     }
 
 #if !ART_WIDE
-    // MFMA path: exact rational ratio, default numeric mode, interleaved buffers, no history floor — and enough
-    // work.  A workgroup of the MFMA kernel walks all K chunks of its tile serially (~50-90 us floor), while the
-    // general kernel spreads even a small call over many workgroups; measured crossover (tools/bench_crossover.py,
-    // C in {2,8}, T in {380,988}) is at outputs x channels x taps of roughly 1.2e8.
+    // MFMA path: exact rational ratio, default numeric mode, interleaved buffers, no history floor — and enough work
+    // to beat the general kernel.  Measured on MI355X (tools/bench_small_taps.py, tools/bench_crossover.py): the
+    // general kernel costs ~7 us + k_C ns per output frame almost independently of the tap count (k = 0.2 / 0.45 / 1.0 /
+    // 3.2 ns for 1 / 2 / 4 / 8 channels: it is bound by per-output work, not by taps), while a call through the MFMA
+    // path has a floor of ~14 us + 1.4 us per 32-tap chunk (prepare launch + one workgroup walking its K chunks
+    // serially) and is faster than the general kernel on everything larger.  For channel counts without a compiled
+    // column group the older rule stays: outputs x channels x taps of at least 1.2e8.
     const unsigned int total = a->n_end - a->n_begin;
-    const double work = (double) total * a->C * a->T;
+    bool enough;
+    if (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32) {
+        const double k_ns = a->C == 1 ? 0.2 : a->C == 2 ? 0.45 : a->C == 4 ? 1.0 : 0.4 * a->C;
+        const double chunks = (a->T + 63) / 32;
+        enough = total * k_ns >= 7000.0 + 1400.0 * chunks;
+    }
+    else
+        enough = (double) total * a->C * a->T >= 1.2e8;
     const bool mfma_ok = a->mode == ART_MODE_FAST && a->period_out > 0 && a->fix_list && a->scratch && a->in_pitch == 0 && a->out_pitch == 0 &&
                          segs->lin_floor == INT_MIN && kernel_pref != ART_KERNEL_GENERAL &&
-                         (work >= 1.2e8 || kernel_pref >= ART_KERNEL_MFMA) && total >= (unsigned int) a->period_out;
+                         (enough || kernel_pref >= ART_KERNEL_MFMA) && total >= (unsigned int) a->period_out;
 
     if (mfma_ok) {
         MfmaGeom g;
