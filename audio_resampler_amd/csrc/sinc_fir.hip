@@ -74,26 +74,34 @@ __device__ __forceinline__ Pos locate (const ArtFirArgs &a, const ArtSegTable &s
 // Halving butterfly: at every level half of the values change hands, so NV values cost
 // NV-1 (+ 6 - log2 NV) shuffle-adds instead of 6*NV.  On return lane L holds the complete sum of
 // value (L >> (6 - log2 NV)) in v[0].
+// (Levels are unrolled at compile time — with a run-time count of live values the register array is indexed
+// dynamically and every exchange turns into a chain of compares and selects over the whole array: 1,400 VALU
+// instructions per output for 16 values instead of ~80.)
+template <int N, int M>                            // N live values, lane mask M
+__device__ __forceinline__ void reduce_level (double *v, int lane)
+{
+    if constexpr (M >= 1) {
+        if constexpr (N > 1) {
+            const bool upper = (lane & M) != 0;
+#pragma unroll
+            for (int j = 0; j < N / 2; ++j) {
+                const double keep = upper ? v [j + N / 2] : v [j];
+                const double send = upper ? v [j] : v [j + N / 2];
+                v [j] = keep + __shfl_xor (send, M);
+            }
+            reduce_level<N / 2, M / 2> (v, lane);
+        }
+        else {
+            v [0] = v [0] + __shfl_xor (v [0], M);
+            reduce_level<1, M / 2> (v, lane);
+        }
+    }
+}
+
 template <int NV>
 __device__ __forceinline__ void wave_reduce (double (&v) [NV], int lane)
 {
-    int n = NV;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        if (n > 1) {
-            const bool upper = (lane & m) != 0;
-#pragma unroll
-            for (int j = 0; j < NV / 2; ++j)
-                if (j < n / 2) {
-                    const double keep = upper ? v [j + n / 2] : v [j];
-                    const double send = upper ? v [j] : v [j + n / 2];
-                    v [j] = keep + __shfl_xor (send, m);
-                }
-            n >>= 1;
-        }
-        else
-            v [0] = v [0] + __shfl_xor (v [0], m);
-    }
+    reduce_level<NV, 32> (v, lane);
 }
 
 __attribute__ ((unused)) __device__ __forceinline__ float fused (float a, float b, float c) { return __builtin_fmaf (a, b, c); }
@@ -1056,18 +1064,20 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
 
 #if !ART_WIDE
     // MFMA path: exact rational ratio, default numeric mode, interleaved buffers, no history floor — and enough work
-    // to beat the general kernel.  Measured on MI355X (tools/bench_small_taps.py, tools/bench_crossover.py): the
-    // general kernel costs ~7 us + k_C ns per output frame almost independently of the tap count (k = 0.2 / 0.45 / 1.0 /
-    // 3.2 ns for 1 / 2 / 4 / 8 channels: it is bound by per-output work, not by taps), while a call through the MFMA
-    // path has a floor of ~14 us + 1.4 us per 32-tap chunk (prepare launch + one workgroup walking its K chunks
-    // serially) and is faster than the general kernel on everything larger.  For channel counts without a compiled
-    // column group the older rule stays: outputs x channels x taps of at least 1.2e8.
+    // to beat the general kernel.  Cost models fitted to MI355X measurements (tools/bench_small_taps.py,
+    // profiles/r1_small_calls.txt), n = output frames of the launch:
+    //     general   ~ 8 us + n * k,    k = (0.2 + 0.04 C) + 0.00007 C T  ns per frame
+    //     MFMA      ~ max (floor, work-bound),   floor = 14 us + 1.4 us per 32-tap chunk  (+ 6 us, and 2.1 us per chunk
+    //                                             for C = 2: with <= 2 channels a workgroup replays 64 periods of positions)
+    // The MFMA path is taken when the general kernel would take longer than the floor.  For channel counts without a
+    // compiled column group the older rule stays: outputs x channels x taps of at least 1.2e8.
     const unsigned int total = a->n_end - a->n_begin;
     bool enough;
     if (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32) {
-        const double k_ns = a->C == 1 ? 0.2 : a->C == 2 ? 0.45 : a->C == 4 ? 1.0 : 0.4 * a->C;
+        const double k_ns = (0.2 + 0.04 * a->C) + 0.00007 * a->C * a->T;
         const double chunks = (a->T + 63) / 32;
-        enough = total * k_ns >= 7000.0 + 1400.0 * chunks;
+        const double floor_ns = 14000.0 + 1400.0 * chunks + (a->C <= 2 ? 6000.0 : 0.0) + (a->C == 2 ? 700.0 * chunks : 0.0);
+        enough = total * k_ns >= floor_ns - 8000.0;
     }
     else
         enough = (double) total * a->C * a->T >= 1.2e8;

@@ -81,16 +81,16 @@ def test_mfma_kernel_within_one_ulp_fullscale_of_precise(name):
 
 
 def test_mfma_kernel_is_the_one_running_the_headline_config():
-    ch, T = 8, 988
-    x, _ = noise(ch * 40000)
+    ch, T, blk = 8, 988, 60000          # 65k output frames per call: beyond the measured general/MFMA crossover (~47k)
+    x, _ = noise(ch * 2 * blk)
     x = x.reshape(-1, ch)
     r = HipResampler(ch, T, T, 0.0, BH | INTERP)
     o = OracleResampler(ch, T, T, 0.0, BH | INTERP | PRECISE)
     for b in (r, o):
         b.advance(T / 2)
     for k in range(2):
-        u, g, y = r.process(x[k * 20000:(k + 1) * 20000], 23000, 48000 / 44100)
-        uo, go, yo = o.process(x[k * 20000:(k + 1) * 20000], 23000, 48000 / 44100)
+        u, g, y = r.process(x[k * blk:(k + 1) * blk], 66000, 48000 / 44100)
+        uo, go, yo = o.process(x[k * blk:(k + 1) * blk], 66000, 48000 / 44100, threads=8)
         assert (u, g) == (uo, go)
         assert r.last_kernel() == 2
         ok, worst, rms = tolerance_ok(y, yo)
