@@ -127,6 +127,16 @@ def _bind(width):
         "decimateProcessInterleavedLEDevice": (None, [DP, ptr, C.c_int, ptr]),
         "decimateHipClipped": (C.c_long, [DP]),
         "floatIntegersLEDevice": (None, [ptr, C.c_double, C.c_int, C.c_int, C.c_int, ptr, C.c_int, ptr]),
+        # stretch.h
+        "stretchInit": (ptr, [C.c_int, C.c_int, C.c_int, C.c_int]),
+        "stretchGetOutputCapacity": (C.c_int, [ptr, C.c_int, C.c_double]),
+        "stretchProcess": (C.c_int, [ptr, f32p, C.c_int, f32p, C.c_double]),
+        "stretchFlush": (C.c_int, [ptr, f32p]),
+        "stretchReset": (None, [ptr]),
+        "stretchFree": (None, [ptr]),
+        "stretchHipSetStream": (None, [ptr, ptr]),
+        "stretchProcessDevice": (C.c_int, [ptr, ptr, C.c_int, ptr, C.c_double]),
+        "stretchFlushDevice": (C.c_int, [ptr, ptr]),
     }
 
     _state = {"lib": None}

@@ -107,6 +107,18 @@ int arthip_decimate_planar (const ArtDecArgs *a, const art_s *d_in, long in_pitc
 int arthip_biquad_chain (Biquad *d_sections, int C, int S, art_s *d_buf, int frames, int stride, void *stream);
 /* every section has order 2, S = 1 or 2, interleaved frames: hand-scheduled kernel */
 int arthip_biquad_order2 (Biquad *d_sections, int C, int S, art_s *d_buf, int frames, void *stream);
+/* ---- time stretcher (stretch_kernels.hip) ---- */
+typedef struct {
+    art_s *ring [2][2];                  /* [stage][ping-pong] input rings, `room` values each */
+    art_s *between;                      /* hand-over buffer stage 1 -> stage 2 (cascaded pair) */
+    art_s *total, *score;                /* search scratch: longest + 4 values each */
+    void *state;                         /* device: { int mark, fill, cur, pad; double drift; } per stage */
+    int channels, room, lo, hi, quick, paired;
+} ArtStretchArgs;
+/* one stretchProcess (flush == 0) or stretchFlush (flush != 0) call; *d_result receives the frames written */
+int arthip_stretch_call (const ArtStretchArgs *h, const art_s *d_in, int frames, art_s *d_out, double ratio, int flush,
+                         int *d_result, void *stream);
+
 int arthip_ingest (const unsigned char *d_in, art_s gain_factor, int bits, int bytes, int stride, art_s *d_out, int n, void *stream);
 
 #ifdef __cplusplus

@@ -1,0 +1,222 @@
+/* stretch_host.c — host side of the time stretcher: the reference's stretch.h API (reference stretch.c:50-143,
+ * :335-373 for init / reset / capacity / flush / free; the per-call state machine itself runs on the device,
+ * stretch_kernels.hip).  No CPU path: without a HIP device stretchInit fails loudly. */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "art_internal.h"
+#include "stretch.h"
+
+typedef struct { int mark, fill, cur, pad; double drift; } DevState;   /* must match stretch_kernels.hip */
+
+struct artamd_stretch {
+    ArtStretchArgs args;
+    art_s *d_in, *d_out; size_t in_cap, out_cap;      /* staging for host-pointer calls (bytes) */
+    int *d_result;
+    void *stream;
+    int blocks;                                        /* ring size in longest periods: 3, or 4 in fast mode */
+};
+
+static void *regrow (void *dev, size_t *cap, size_t need)
+{
+    if (need <= *cap) return dev;
+    arthip_free (dev);
+    dev = arthip_malloc (need + need / 2 + 4096);
+    *cap = dev ? need + need / 2 + 4096 : 0;
+    return dev;
+}
+
+static int push_state (Stretch *cxt)                   /* host mirrors -> device state (init / reset) */
+{
+    DevState st [2];
+    memset (st, 0, sizeof (st));
+    st [0].mark = cxt->tail; st [0].fill = cxt->head; st [0].drift = cxt->outsamples_error;
+    if (cxt->next) { st [1].mark = cxt->next->tail; st [1].fill = cxt->next->head; st [1].drift = cxt->next->outsamples_error; }
+    return arthip_h2d (cxt->hip->args.state, st, sizeof (st), cxt->hip->stream) || arthip_sync (cxt->hip->stream);
+}
+
+static void pull_state (Stretch *cxt)                  /* device state -> host mirrors (after every call) */
+{
+    DevState st [2];
+    if (arthip_d2h (st, cxt->hip->args.state, sizeof (st), cxt->hip->stream) || arthip_sync (cxt->hip->stream)) return;
+    cxt->tail = st [0].mark; cxt->head = st [0].fill; cxt->outsamples_error = st [0].drift;
+    if (cxt->next) { cxt->next->tail = st [1].mark; cxt->next->head = st [1].fill; cxt->next->outsamples_error = st [1].drift; }
+}
+
+static Stretch *make_stage (int shortest, int longest, int channels, int fast)
+{
+    Stretch *s = calloc (1, sizeof (*s));
+    if (!s) return NULL;
+    s->num_chans = channels;
+    s->inbuff_samples = longest * channels * (fast ? 4 : 3);
+    s->head = s->tail = s->longest = longest * channels;
+    s->shortest = shortest * channels;
+    s->fast_mode = fast;
+    return s;
+}
+
+Stretch *stretchInit (int shortest_period, int longest_period, int num_channels, int flags)
+{
+    const int fast = (flags & STRETCH_FAST_FLAG) != 0, dual = (flags & STRETCH_DUAL_FLAG) != 0;
+
+    if (fast) {
+        longest_period = (longest_period + 1) & ~1;
+        shortest_period &= ~1;
+    }
+
+    if (longest_period <= shortest_period || shortest_period < MIN_PERIOD || longest_period > MAX_PERIOD) {
+        fprintf (stderr, "stretchInit(): invalid periods!\n");
+        return NULL;
+    }
+
+    if (num_channels < 1 || num_channels > 2) {
+        fprintf (stderr, "stretchInit(): mono or stereo only!\n");
+        return NULL;
+    }
+
+    if (artamdDeviceCount () <= 0) {
+        fprintf (stderr, "artamd: stretchInit needs a HIP device (no CPU path): %s\n", arthip_last_error ());
+        return NULL;
+    }
+
+    Stretch *cxt = make_stage (shortest_period, longest_period, num_channels, fast);
+    struct artamd_stretch *hip = calloc (1, sizeof (*hip));
+    if (!cxt || !hip) { free (cxt); free (hip); fprintf (stderr, "stretchInit(): out of memory!\n"); return NULL; }
+    cxt->hip = hip;
+    if (dual && !(cxt->next = make_stage (shortest_period, longest_period, num_channels, fast))) { stretchFree (cxt); return NULL; }
+
+    ArtStretchArgs *a = &hip->args;
+    const size_t ring_bytes = sizeof (art_s) * (size_t) cxt->inbuff_samples;
+    int failed = 0;
+    hip->blocks = fast ? 4 : 3;
+    a->channels = num_channels; a->room = cxt->inbuff_samples; a->lo = cxt->shortest; a->hi = cxt->longest;
+    a->quick = fast; a->paired = dual;
+    for (int s = 0; s < (dual ? 2 : 1); ++s)
+        for (int b = 0; b < 2; ++b) {
+            a->ring [s][b] = arthip_malloc (ring_bytes);
+            failed |= !a->ring [s][b] || arthip_zero (a->ring [s][b], ring_bytes, NULL);
+        }
+    if (dual) { a->between = arthip_malloc (ring_bytes); failed |= !a->between; }
+    a->total = arthip_malloc (sizeof (art_s) * (MAX_PERIOD + 8));
+    a->score = arthip_malloc (sizeof (art_s) * (MAX_PERIOD + 8));
+    a->state = arthip_malloc (2 * sizeof (DevState));
+    hip->d_result = arthip_malloc (sizeof (int));
+    failed |= !a->total || !a->score || !a->state || !hip->d_result;
+
+    if (failed || push_state (cxt)) {
+        fprintf (stderr, "artamd: stretchInit: device allocation failed: %s\n", arthip_last_error ());
+        stretchFree (cxt);
+        return NULL;
+    }
+
+    return cxt;
+}
+
+void stretchFree (Stretch *cxt)
+{
+    if (!cxt) return;
+    if (cxt->hip) {
+        ArtStretchArgs *a = &cxt->hip->args;
+        for (int s = 0; s < 2; ++s) for (int b = 0; b < 2; ++b) arthip_free (a->ring [s][b]);
+        arthip_free (a->between); arthip_free (a->total); arthip_free (a->score); arthip_free (a->state);
+        arthip_free (cxt->hip->d_result); arthip_free (cxt->hip->d_in); arthip_free (cxt->hip->d_out);
+        free (cxt->hip);
+    }
+    free (cxt->next);
+    free (cxt);
+}
+
+void stretchReset (Stretch *cxt)
+{
+    ArtStretchArgs *a = &cxt->hip->args;
+    /* the reference keeps outsamples_error across a reset (stretch.c:102-110) — so do we */
+    for (Stretch *s = cxt; s; s = s->next) s->head = s->tail = s->longest;
+    for (int s = 0; s < (a->paired ? 2 : 1); ++s)
+        arthip_zero (a->ring [s][0], sizeof (art_s) * (size_t) cxt->longest, cxt->hip->stream);
+    push_state (cxt);                                   /* ring 0 current again */
+}
+
+int stretchGetOutputCapacity (Stretch *cxt, int max_num_samples, double max_ratio)
+{
+    int frames = max_num_samples;
+
+    for (Stretch *s = cxt; s; s = s->next) {            /* stage by stage, as the reference recurses (stretch.c:117-143) */
+        double here = max_ratio, rest = 1.0;
+        if (s->next) {
+            if (here < 0.5) { rest = here / 0.5; here = 0.5; }
+            else if (here > 2.0) { rest = here / 2.0; here = 2.0; }
+        }
+        frames = (int) ceil (frames * ceil (here * 2.0) / 2.0) + (s->longest / s->num_chans) * (s->fast_mode ? 4 : 3);
+        max_ratio = rest;
+    }
+
+    return frames;
+}
+
+void stretchHipSetStream (Stretch *cxt, void *hipStream) { cxt->hip->stream = hipStream; }
+
+static int device_call (Stretch *cxt, const art_s *d_in, int frames, art_s *d_out, double ratio, int flush)
+{
+    struct artamd_stretch *hip = cxt->hip;
+    int made = 0;
+
+    if (arthip_stretch_call (&hip->args, d_in, frames, d_out, ratio, flush, hip->d_result, hip->stream) ||
+        arthip_d2h (&made, hip->d_result, sizeof (int), hip->stream) || arthip_sync (hip->stream)) {
+        fprintf (stderr, "artamd: stretch launch failed: %s\n", arthip_last_error ());
+        return 0;
+    }
+
+    pull_state (cxt);
+    return made;
+}
+
+int stretchProcessDevice (Stretch *cxt, const artsample_t *d_samples, int num_samples, artsample_t *d_output, double ratio)
+{
+    return num_samples > 0 ? device_call (cxt, d_samples, num_samples, d_output, ratio, 0) : 0;
+}
+
+int stretchFlushDevice (Stretch *cxt, artsample_t *d_output)
+{
+    return device_call (cxt, NULL, 0, d_output, 1.0, 1);
+}
+
+/* frames a call can emit at most: what is buffered plus what comes in, at the largest stage ratios, plus slack */
+static size_t worst_case_frames (Stretch *cxt, int num_samples)
+{
+    size_t frames = (size_t) num_samples + (size_t) cxt->inbuff_samples / cxt->num_chans;
+    for (Stretch *s = cxt; s; s = s->next)
+        frames = frames * 2 + (size_t)(s->inbuff_samples / s->num_chans) * 2;
+    return frames;
+}
+
+int stretchProcess (Stretch *cxt, const artsample_t *samples, int num_samples, artsample_t *output, double ratio)
+{
+    struct artamd_stretch *hip = cxt->hip;
+    const int C = cxt->num_chans;
+
+    if (num_samples <= 0) return 0;
+    hip->d_in = regrow (hip->d_in, &hip->in_cap, sizeof (art_s) * (size_t) num_samples * C);
+    hip->d_out = regrow (hip->d_out, &hip->out_cap, sizeof (art_s) * worst_case_frames (cxt, num_samples) * C);
+    if (!hip->d_in || !hip->d_out || arthip_h2d (hip->d_in, samples, sizeof (art_s) * (size_t) num_samples * C, hip->stream)) {
+        fprintf (stderr, "artamd: stretchProcess: %s\n", arthip_last_error ());
+        return 0;
+    }
+
+    const int made = device_call (cxt, hip->d_in, num_samples, hip->d_out, ratio, 0);
+    if (made > 0) { arthip_d2h (output, hip->d_out, sizeof (art_s) * (size_t) made * C, hip->stream); arthip_sync (hip->stream); }
+    return made;
+}
+
+int stretchFlush (Stretch *cxt, artsample_t *output)
+{
+    struct artamd_stretch *hip = cxt->hip;
+    const int C = cxt->num_chans;
+
+    hip->d_out = regrow (hip->d_out, &hip->out_cap, sizeof (art_s) * worst_case_frames (cxt, 0) * C);
+    if (!hip->d_out) return 0;
+    const int made = device_call (cxt, NULL, 0, hip->d_out, 1.0, 1);
+    if (made > 0) { arthip_d2h (output, hip->d_out, sizeof (art_s) * (size_t) made * C, hip->stream); arthip_sync (hip->stream); }
+    return made;
+}

@@ -14,6 +14,7 @@
 #include "resampler.h"
 #include "biquad.h"
 #include "decimator.h"
+#include "stretch.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -84,6 +85,13 @@ void decimateProcessInterleavedLEDevice (Decimate *cxt, const artsample_t *d_inp
 long decimateHipClipped (Decimate *cxt);             /* synchronises; total clipped since init */
 void floatIntegersLEDevice (const unsigned char *d_input, double inputGain, int inputBits, int inputBytes, int inputStride,
                             artsample_t *d_output, int numSamples, void *hipStream);
+
+/* ---- time stretcher, device pointers (stretch.h) ---- */
+void stretchHipSetStream (Stretch *cxt, void *hipStream);
+/* as stretchProcess / stretchFlush with `samples` / `output` in device memory; both wait for the call to finish (the frame
+ * count is the return value).  d_output must hold stretchGetOutputCapacity() frames. */
+int stretchProcessDevice (Stretch *cxt, const artsample_t *d_samples, int num_samples, artsample_t *d_output, double ratio);
+int stretchFlushDevice (Stretch *cxt, artsample_t *d_output);
 
 #ifdef __cplusplus
 }

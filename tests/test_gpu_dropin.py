@@ -1,7 +1,9 @@
 """GPU: the reference's OWN test program — compiled from its own artest.c against its own headers, linked
 against libartamd.so instead of resampler.c/biquad.c/decimator.c (oracle/Makefile target `dropin`) — must
 print the same statistics as when it is linked against the reference's own DSP sources.
-The binary only exists where /root/reference was available at build time (it travels to the GPU box)."""
+The binary only exists where /root/reference was available at build time (it travels to the GPU box).
+Likewise the reference's ART command-line tool: art.c ALONE, every DSP entry point (resampler.h, biquad.h, decimator.h,
+stretch.h) resolved by the library."""
 import os
 import re
 import subprocess
@@ -85,6 +87,9 @@ def _write_wav(path, rate, channels, seconds, bits=16):
     ("-3 -r44100 -p", 96000, 2),             # downsample with auto low-pass + cascaded biquad pre-filter (BASELINE configs[2] shape)
     ("-2 -r48000 -o24 -d1 -n2", 44100, 1),   # 24-bit out, flat dither, 2nd-order shaping
     ("-3 -r32000 -x -o8", 48000, 2),         # no extrapolation, 8-bit output
+    ("-2 --tempo=1.25", 44100, 2),           # time stretch only (stretch.h from the library too: art_amd is art.c alone)
+    ("-3 -r48000 --pitch=-300", 44100, 1),   # pitch shift: stretch, then resample by the inverse
+    ("-2 --tempo=0.3 -o24", 44100, 2),       # below 0.5: the cascaded (dual) stretcher
 ])
 def test_art_cli_on_hip_library_writes_the_same_file_as_reference_art(tmp_path, opts, rate_in, chans):
     src = str(tmp_path / "in.wav")

@@ -446,7 +446,8 @@ def test_reference_artest64_binary_on_the_hip_library_matches_reference_checksum
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not (os.path.exists(ART64_AMD) and os.path.exists(ART64_REF)), reason="oracle/_ref/art64_* not built")
-@pytest.mark.parametrize("opts,rate_in,chans", [("-4 -r48000", 44100, 2), ("-3 -r44100 -p", 96000, 2), ("-2 -r48000 -o24 -d1 -n2", 44100, 1)])
+@pytest.mark.parametrize("opts,rate_in,chans", [("-4 -r48000", 44100, 2), ("-3 -r44100 -p", 96000, 2), ("-2 -r48000 -o24 -d1 -n2", 44100, 1),
+                                                 ("-2 -r48000 --tempo=0.8 --pitch=200", 44100, 2)])     # time stretcher from libartamd64.so
 def test_art64_cli_on_hip_library_writes_the_same_file_as_reference_art64(tmp_path, opts, rate_in, chans):
     from test_gpu_dropin import _write_wav
     src = str(tmp_path / "in.wav")
