@@ -90,10 +90,13 @@ __device__ int pick_period (const StretchStage &S, Scratch &L, const art_s *x)
     art_s miss_of [3]; int cand_of [3]; int ncand = 0;
     if (wave < ST_WG / 64 - 1) {
         for (int p = p0 + tid; p <= p1; p += ST_WG - 64) {
+            // "miss += fabs (d)" adds in double and rounds back to the sample type.  With both operands sample-type
+            // values that equals the plain sample-type addition (double rounding is innocuous for + when the wide format
+            // has >= 2p + 2 bits: 53 >= 50).
             art_s miss = 0;
             for (int i = p - 1; i >= 0; --i) {
                 const art_s d = m [i] - m [i + p];
-                miss = add_abs (miss, fabs ((double) d));
+                miss = miss + (d < (art_s) 0 ? -d : d);
             }
             miss_of [ncand] = miss; cand_of [ncand] = p; ++ncand;       // <= 3 candidates per thread (2377 / 960)
         }

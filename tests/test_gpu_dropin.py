@@ -114,6 +114,9 @@ def test_art_cli_on_hip_library_writes_the_same_file_as_reference_art(tmp_path, 
     ("-4 -r48000", 44100, 2), ("-3 -r44100 -p", 96000, 2), ("-2 -r48000 -o24 -d1 -n2", 44100, 1), ("-3 -r32000 -x -o8", 48000, 2),
     ("-1 -r48000", 44100, 3),            # 48 filters < 160 phases: interpolation stays on; 3 channels => extensible header
     ("-3 -r96000 -p -o24", 44100, 2),    # upsampling with the biquad POST-filter
+    ("-2 --tempo=1.25", 44100, 2),       # device-resident time stretcher, no resampling
+    ("-3 -r48000 --pitch=-300", 44100, 1),
+    ("-2 --tempo=0.3 -o24", 44100, 2),   # cascaded stretcher
 ])
 def test_device_resident_art_tool_writes_the_same_file_as_reference_art(tmp_path, opts, rate_in, chans):
     import sys

@@ -4,7 +4,7 @@
 The counterpart of the reference's ART command line (reference art.c:96-1155) built on the
 device-pointer entry points of libartamd.so: the PCM bytes of a block are uploaded once, then
 
-    floatIntegersLEDevice -> [biquadBank x2, pre-filter] -> resampleProcessInterleavedDevice
+    floatIntegersLEDevice -> [stretchProcessDevice] -> [biquadBank x2, pre-filter] -> resampleProcessInterleavedDevice
                           -> [biquadBank x2, post-filter] -> decimateProcessInterleavedLEDevice
 
 run back to back on one HIP stream and only the packed output bytes come back.  Block size, flag choices, the
@@ -12,7 +12,10 @@ position advance and the output-length rule follow ART (art.c:717, 808-830, 849-
 ARTAMD_STRICT=1 the output file is byte-identical to the reference tool's (tests/test_gpu_dropin.py).
 
 usage: art_gpu.py [-1|-2|-3|-4] [-r<Hz>] [-g<dB>] [-l<Hz>] [-f<n>] [-t<n>] [-o<bits>] [-d<0|1|2>] [-n<0..3>]
-                  [-a] [-b] [-h] [-e] [-p] [-x] [-y] [-q] in.wav out.wav
+                  [-a] [-b] [-h] [-e] [-p] [-x] [-y] [-q] [--tempo=<ratio>] [--pitch=<cents>] in.wav out.wav
+
+--tempo / --pitch put the time stretcher (stretchProcessDevice, mono or stereo) between ingest and resampler, as ART does
+(art.c:769-797, 1002-1007).
 """
 import ctypes as C
 import math
@@ -83,9 +86,15 @@ def main(argv):
     dither, shaping = A.DITHER_HIGHPASS, A.SHAPING_ATH_CURVE
     bh = hann = allpass = extended = prepost = overwrite = quiet = False
     extrapolate = True
+    pitch_ratio = tempo_ratio = 1.0
     files = []
     for arg in argv:
-        if arg.startswith("-") and len(arg) > 1:
+        if arg.startswith("--"):
+            key, _, val = arg[2:].partition("=")
+            if key.startswith("pitch"): pitch_ratio = 2.0 ** (float(val) / 1200.0)
+            elif key.startswith("tempo"): tempo_ratio = float(val)
+            else: raise SystemExit(f"unknown option {arg} !")
+        elif arg.startswith("-") and len(arg) > 1:
             o, v = arg[1], arg[2:]
             num = lambda: float(v[:-1]) * 1000 if v[-1:] in "kK" else float(v)
             if o in PRESETS: taps, filters = PRESETS[o]
@@ -123,6 +132,22 @@ def main(argv):
     ratio = rate_out / rate_in
     stream = torch.cuda.current_stream().cuda_stream
 
+    # ---- time stretcher (art.c:769-797): pitch is a stretch followed by resampling with the inverse ratio
+    stretch_ratio, st, stretch_cap = 1.0, None, BLOCK
+    if pitch_ratio != 1.0 or tempo_ratio != 1.0:
+        stretch_ratio = pitch_ratio / tempo_ratio
+        ratio /= pitch_ratio
+        if stretch_ratio != 1.0:
+            if ch > 2:
+                raise SystemExit(f"error: audio stretch only works with mono or stereo, not {ch}-channel")
+            if not 0.25 <= stretch_ratio <= 4.0:
+                raise SystemExit(f"error: audio stretch requires excessive ratio {stretch_ratio:g}")
+            st = L.stretchInit(rate_in // 350, rate_in // 50, ch, 2 if (stretch_ratio < 0.5 or stretch_ratio > 2.0) else 0)
+            if not st:
+                raise SystemExit("stretchInit failed")
+            L.stretchHipSetStream(st, stream)
+            stretch_cap = L.stretchGetOutputCapacity(st, BLOCK, stretch_ratio)
+
     # ---- contexts (art.c:808-890)
     rs = None
     if filters and (ratio != 1.0 or lowpass or phase != 0.0):
@@ -132,7 +157,7 @@ def main(argv):
         if allpass: flags &= ~A.INCLUDE_LOWPASS
         if extrapolate: flags |= A.EXTRAPOLATE_ENDPOINTS
         if extended: flags |= A.EXTEND_CONVOLUTION_MATH
-        rs = A.Resampler(ch, taps, filters, flags=flags, fixed=(float(rate_in), float(rate_out), lowpass))
+        rs = A.Resampler(ch, taps, filters, flags=flags, fixed=(rate_in * pitch_ratio, float(rate_out), lowpass))
         rs.set_stream(stream)
         rs.advance(taps / 2.0 + phase)
     pre = post = None
@@ -151,10 +176,11 @@ def main(argv):
         dec = A.Decimator(ch, outbits, out_bytes, 1.0, rate_out, dither | shaping)
         dec.set_stream(stream)
 
-    cap = int(math.floor((BLOCK + taps // 2) * ratio + 100.0))
-    target = int(math.floor(frames_in * ratio + 0.5))
+    cap = int(math.floor((stretch_cap + taps // 2) * ratio + 100.0))
+    target = int(math.floor(frames_in * stretch_ratio * ratio + 0.5))
     d_raw = torch.empty(BLOCK * ch * in_bytes, dtype=torch.uint8, device="cuda")
     d_in = torch.empty(BLOCK, ch, dtype=torch.float32, device="cuda")
+    d_st = torch.empty(stretch_cap, ch, dtype=torch.float32, device="cuda") if st else None
     d_out = torch.empty(cap, ch, dtype=torch.float32, device="cuda")
     d_pcm = torch.empty(cap * ch * out_bytes, dtype=torch.uint8, device="cuda")
     import numpy as np
@@ -173,17 +199,27 @@ def main(argv):
             else:
                 L.floatIntegersLEDevice(d_raw.data_ptr(), gain, inbits, in_bytes, 1, d_in.data_ptr(), n * ch, stream)
             pos += n
-            if pre is not None:
-                pre.apply_device(d_in, n)
+        src = d_in
+        if st:                                  # stretch (or drain the stretcher once the file is exhausted)
+            n = L.stretchProcessDevice(st, d_in.data_ptr(), n, d_st.data_ptr(), stretch_ratio) if n > 0 else \
+                L.stretchFlushDevice(st, d_st.data_ptr())
+            src = d_st
+        if n > 0 and pre is not None:
+            pre.apply_device(src, n)
         if rs is not None:
-            _, made = rs.process_device(d_in if n > 0 else None, n if n > 0 else -1, d_out, cap, ratio)
+            _, made = rs.process_device(src if n > 0 else None, n if n > 0 else -1, d_out, cap, ratio)
             if made == cap:
                 raise SystemExit("fatal error: outputbuffer too small!")
             buf = d_out
         else:
-            made, buf = n, d_in
+            made, buf = max(n, 0), src
         if n <= 0 and made == 0:
-            break
+            if not st or produced >= target:
+                break
+            # the stretcher can come up short of the rounded target: pad with silence (art.c:1036-1047)
+            made = min(target - produced, cap)
+            buf = d_out
+            d_out[:made].zero_()
         if post is not None and made:
             post.apply_device(buf, made)
         made = min(made, target - produced)
@@ -194,6 +230,8 @@ def main(argv):
             out_chunks.append(buf[:made].contiguous().cpu().numpy().tobytes())
         produced += made
 
+    if st:
+        L.stretchFree(st)
     body = b"".join(out_chunks)
     with open(dst, "wb") as f:
         f.write(wav_header(outbits, ch, produced, rate_out, mask))
