@@ -106,7 +106,7 @@ int arthip_decimate (const ArtDecArgs *a, const art_s *d_in, int frames, unsigne
 int arthip_decimate_planar (const ArtDecArgs *a, const art_s *d_in, long in_pitch, int frames, unsigned char *d_out, long out_pitch, void *stream);
 int arthip_biquad_chain (Biquad *d_sections, int C, int S, art_s *d_buf, int frames, int stride, void *stream);
 /* every section has order 2, S = 1 or 2, interleaved frames: hand-scheduled kernel */
-int arthip_biquad_order2 (Biquad *d_sections, int C, int S, art_s *d_buf, int frames, void *stream);
+int arthip_biquad_order2 (Biquad *d_sections, int C, int S, art_s *d_buf, int frames, int stride, void *stream);   /* stride >= C: values between frames */
 /* ---- time stretcher (stretch_kernels.hip) ---- */
 typedef struct {
     art_s *ring [2][2];                  /* [stage][ping-pong] input rings, `room` values each */

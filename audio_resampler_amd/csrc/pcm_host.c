@@ -96,7 +96,12 @@ static void biquad_run_host (Biquad *f, art_s *buffer, int n, int stride, int sa
     }
     arthip_h2d (scratch_buf, buffer, span * sizeof (art_s), NULL);
     arthip_h2d (scratch_state, f, sizeof (Biquad), NULL);
-    arthip_biquad_chain (scratch_state, 1, 1, scratch_buf, n, sample_form ? -stride : stride, NULL);
+    /* second-order section over a long strided run (ART's -p filters, art.c:1011-1016): the feed-forward / pipelined
+     * kernel with one channel; everything else: the generic one-lane kernel */
+    if (!sample_form && f->order == 2 && n >= 64)
+        arthip_biquad_order2 (scratch_state, 1, 1, scratch_buf, n, stride, NULL);
+    else
+        arthip_biquad_chain (scratch_state, 1, 1, scratch_buf, n, sample_form ? -stride : stride, NULL);
     arthip_d2h (buffer, scratch_buf, span * sizeof (art_s), NULL);
     arthip_d2h (f, scratch_state, sizeof (Biquad), NULL);
     arthip_sync (NULL);
@@ -145,7 +150,7 @@ void biquadBankSetStream (BiquadBank *b, void *stream) { b->stream = stream; }
 void biquadBankApplyInterleavedDevice (BiquadBank *b, artsample_t *d_buffer, int numFrames)
 {
     if (b->all_order2 && numFrames >= 64)
-        arthip_biquad_order2 (b->d_sections, b->C, b->S, d_buffer, numFrames, b->stream);
+        arthip_biquad_order2 (b->d_sections, b->C, b->S, d_buffer, numFrames, b->C, b->stream);
     else
         arthip_biquad_chain (b->d_sections, b->C, b->S, d_buffer, numFrames, b->C, b->stream);
 }

@@ -480,7 +480,7 @@ __device__ __forceinline__ void ff_serial (art_s *row, const art_s *prow, int le
 
 template <int S>                                   // S = 1 or 2 order-2 sections per channel
 __global__ __launch_bounds__ (ST_THREADS)
-void biquad_order2_ff_kernel (Biquad *sections, int C, art_s *buf, int frames)
+void biquad_order2_ff_kernel (Biquad *sections, int C, int stride, art_s *buf, int frames)   // stride: values between frames (>= C)
 {
     extern __shared__ __attribute__ ((aligned (32))) unsigned char ff_lds [];
     art_s *const A1 = (art_s *) ff_lds;            // [3][FF_CAP]  u1 -> y1, by chunk % 3
@@ -520,7 +520,7 @@ void biquad_order2_ff_kernel (Biquad *sections, int C, art_s *buf, int frames)
         xtail [0][tid][0] = f1.x [f1.index & 3]; xtail [0][tid][1] = f1.x [(f1.index - 1) & 3];
         b1 = f1.b [1]; b2 = f1.b [2]; y1 = f1.y [f1.index & 3]; y2 = f1.y [(f1.index - 1) & 3];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) xt [k] = buf [(size_t)(frames - 1 - k) * C + c0 + tid];     // frames >= 4 (launcher)
+        for (int k = 0; k < 4; ++k) xt [k] = buf [(size_t)(frames - 1 - k) * stride + c0 + tid];     // frames >= 4 (launcher)
         if (S == 2) {
             const Biquad &f2 = sections [(size_t)(c0 + tid) * S + 1];
             ffc [1][tid][0] = f2.a [0]; ffc [1][tid][1] = f2.a [1]; ffc [1][tid][2] = f2.a [2];
@@ -540,17 +540,17 @@ void biquad_order2_ff_kernel (Biquad *sections, int C, art_s *buf, int frames)
     auto fetch = [&] (int k) {
         if (wave != 2 || hr >= runs || k >= nchunks) return;
         const int L = chunk_len (k);
-        const __amdgpu_buffer_rsrc_t rs = ff_rsrc (buf + (size_t) chunk_start (k) * C + c0, ((size_t) L * C - c0) * esz);
+        const __amdgpu_buffer_rsrc_t rs = ff_rsrc (buf + (size_t) chunk_start (k) * stride + c0, ((size_t) L * stride - c0) * esz);
         // the two frames before the chunk (f0 == 0: patched from xtail later) are forced out of range by a select — a
         // negative offset is not left to wrap, the hardware's range check does not wrap register + immediate to 32 bits
 #pragma unroll
         for (int j = 0; j < FF_RUN + 2; ++j) {
             if (j >= run + 2) break;
             const int f = f0 + j - 2;
-            xr [j] = ff_load (rs, f >= 0 ? (f * C + hc) * esz : (int) 0xfffffff0u, art_s ());
+            xr [j] = ff_load (rs, f >= 0 ? (f * stride + hc) * esz : (int) 0xfffffff0u, art_s ());
         }
-        xl0 = ff_load (rs, ((L - 1) * C + hc) * esz, art_s ());
-        xl1 = ff_load (rs, ((L - 2) * C + hc) * esz, art_s ());
+        xl0 = ff_load (rs, ((L - 1) * stride + hc) * esz, art_s ());
+        xl1 = ff_load (rs, L >= 2 ? ((L - 2) * stride + hc) * esz : (int) 0xfffffff0u, art_s ());
     };
     fetch (0);
 
@@ -587,13 +587,13 @@ void biquad_order2_ff_kernel (Biquad *sections, int C, art_s *buf, int frames)
                     if (k >= 0) {
                         const int L = chunk_len (k);
                         const art_s *src = (S == 2 ? A2 + (k & 1) * FF_CAP : A1 + (k % 3) * FF_CAP) + hc * pitch + f0;
-                        const __amdgpu_buffer_rsrc_t rs = ff_rsrc (buf + (size_t) chunk_start (k) * C + c0, ((size_t) L * C - c0) * esz);
-                        const int base = (f0 * C + hc) * esz;
+                        const __amdgpu_buffer_rsrc_t rs = ff_rsrc (buf + (size_t) chunk_start (k) * stride + c0, ((size_t) L * stride - c0) * esz);
+                        const int base = (f0 * stride + hc) * esz;
                         art_s v [FF_RUN];
 #pragma unroll
                         for (int j = 0; j < FF_RUN; ++j) { if (j >= run) break; v [j] = src [j]; }
 #pragma unroll
-                        for (int j = 0; j < FF_RUN; ++j) { if (j >= run) break; ff_store (rs, base + j * C * esz, v [j]); }
+                        for (int j = 0; j < FF_RUN; ++j) { if (j >= run) break; ff_store (rs, base + j * stride * esz, v [j]); }
                     }
                 }
                 if (S == 2 && it >= 1 && it <= nchunks) {  // section 2's feed-forward part from section 1's outputs
@@ -905,10 +905,11 @@ __global__ void ingest_kernel (const unsigned char *in, art_s g, int bits, int b
 
 extern "C" {
 
-int arthip_biquad_order2 (Biquad *d_sections, int C, int S, art_s *d_buf, int frames, void *stream)
+int arthip_biquad_order2 (Biquad *d_sections, int C, int S, art_s *d_buf, int frames, int stride, void *stream)
 {
     if (frames <= 0) return 0;
-    static const bool legacy = getenv ("ARTAMD_BIQUAD_LEGACY") != nullptr;       // ablation: the single-lane-does-everything form
+    static const bool legacy_env = getenv ("ARTAMD_BIQUAD_LEGACY") != nullptr;
+    const bool legacy = legacy_env && stride == C;       // ablation: the single-lane-does-everything form
     if (legacy && S == 1) hipLaunchKernelGGL (biquad_order2_lds_kernel<1>, dim3 ((C + 63) / 64), dim3 (ST_THREADS), 0, (hipStream_t) stream, d_sections, C, d_buf, frames);
     else if (legacy && S == 2) hipLaunchKernelGGL (biquad_order2_lds_kernel<2>, dim3 ((C + 63) / 64), dim3 (ST_THREADS), 0, (hipStream_t) stream, d_sections, C, d_buf, frames);
     else if (S == 1 || S == 2) {
@@ -919,8 +920,8 @@ int arthip_biquad_order2 (Biquad *d_sections, int C, int S, art_s *d_buf, int fr
             (void) hipFuncSetAttribute ((const void *) biquad_order2_ff_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             once = true;
         }
-        if (S == 1) hipLaunchKernelGGL (biquad_order2_ff_kernel<1>, dim3 ((C + 63) / 64), dim3 (ST_THREADS), lds, (hipStream_t) stream, d_sections, C, d_buf, frames);
-        else hipLaunchKernelGGL (biquad_order2_ff_kernel<2>, dim3 ((C + 63) / 64), dim3 (ST_THREADS), lds, (hipStream_t) stream, d_sections, C, d_buf, frames);
+        if (S == 1) hipLaunchKernelGGL (biquad_order2_ff_kernel<1>, dim3 ((C + 63) / 64), dim3 (ST_THREADS), lds, (hipStream_t) stream, d_sections, C, stride, d_buf, frames);
+        else hipLaunchKernelGGL (biquad_order2_ff_kernel<2>, dim3 ((C + 63) / 64), dim3 (ST_THREADS), lds, (hipStream_t) stream, d_sections, C, stride, d_buf, frames);
     }
     else return -1;
     return hipGetLastError () == hipSuccess ? 0 : -1;
