@@ -480,7 +480,7 @@ __device__ __forceinline__ void ff_serial (art_s *row, const art_s *prow, int le
 
 template <int S>                                   // S = 1 or 2 order-2 sections per channel
 __global__ __launch_bounds__ (ST_THREADS)
-void biquad_order2_ff_kernel (Biquad *sections, int C, int stride, art_s *buf, int frames)   // stride: values between frames (>= C)
+void biquad_order2_ff_kernel (Biquad *sections, int C, int stride, art_s *buf, int frames, int cpw)   // stride: values between frames (>= C); cpw: channels per workgroup (<= 64)
 {
     extern __shared__ __attribute__ ((aligned (32))) unsigned char ff_lds [];
     art_s *const A1 = (art_s *) ff_lds;            // [3][FF_CAP]  u1 -> y1, by chunk % 3
@@ -491,7 +491,7 @@ void biquad_order2_ff_kernel (Biquad *sections, int C, int stride, art_s *buf, i
     __shared__ art_s xtail [2][64][2];             // the two inputs preceding a chunk, by chunk parity: [0] nearest
     __shared__ art_s mtail [3][64][2];             // the two section-1 outputs preceding a chunk (chunk % 3)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c0 = blockIdx.x * 64, Cg = min (64, C - c0);
+    const int c0 = blockIdx.x * cpw, Cg = min (cpw, C - c0);
 
     // Chunk geometry.  A helper lane owns `run` consecutive frames of one channel (hc) in every chunk, `runs` lanes
     // per channel; a chunk is exactly runs*run frames (run a multiple of 4), the first chunk takes the remainder.
@@ -724,13 +724,13 @@ constexpr int DEC_SEG = 32;                        // consecutive samples of one
 
 template <int ORDER, bool DITHER>                  // ORDER 0 = no noise shaping
 __global__ __launch_bounds__ (ST_THREADS)
-void decimate_lds_kernel (ArtDecArgs a, const art_s *in, int frames, unsigned char *out)
+void decimate_lds_kernel (ArtDecArgs a, const art_s *in, int frames, unsigned char *out, int cpw)     // cpw: channels per workgroup (<= 64)
 {
     __shared__ __attribute__ ((aligned (16))) art_s tile [DEC_CHUNK];          // input, then the rounded code values
     __shared__ __attribute__ ((aligned (16))) art_s dth [DITHER ? DEC_CHUNK : 1];
     __shared__ uint32_t s_gen [64], s_next [64];   // generator state at the start of this / the next chunk
     const int tid = threadIdx.x;
-    const int c0 = blockIdx.x * 64, Cg = min (64, a.C - c0);
+    const int c0 = blockIdx.x * cpw, Cg = min (cpw, a.C - c0);
     const int chunk_frames = (DEC_CHUNK / Cg) & ~1;                            // even: chunk boundaries keep generator parity
 
     art_s fb = 0.0f; SectionRegs sh; unsigned long long clips = 0;
@@ -903,6 +903,16 @@ __global__ void ingest_kernel (const unsigned char *in, art_s g, int bits, int b
 
 } // namespace
 
+// The serial stages are latency-bound per lane, so a workgroup gains nothing from more channels — but its LDS chunk (and
+// with it the work per barrier) shrinks in proportion.  Many-channel calls are therefore spread over MORE workgroups of
+// 8 channels (one per CU and beyond) rather than packed 64 to a workgroup; only beyond 512 workgroups do the groups grow.
+static int channels_per_workgroup (int C)
+{
+    int cpw = 8;
+    while (cpw < 64 && (C + cpw - 1) / cpw > 512) cpw += 8;
+    return cpw;
+}
+
 extern "C" {
 
 int arthip_biquad_order2 (Biquad *d_sections, int C, int S, art_s *d_buf, int frames, int stride, void *stream)
@@ -920,8 +930,10 @@ int arthip_biquad_order2 (Biquad *d_sections, int C, int S, art_s *d_buf, int fr
             (void) hipFuncSetAttribute ((const void *) biquad_order2_ff_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             once = true;
         }
-        if (S == 1) hipLaunchKernelGGL (biquad_order2_ff_kernel<1>, dim3 ((C + 63) / 64), dim3 (ST_THREADS), lds, (hipStream_t) stream, d_sections, C, stride, d_buf, frames);
-        else hipLaunchKernelGGL (biquad_order2_ff_kernel<2>, dim3 ((C + 63) / 64), dim3 (ST_THREADS), lds, (hipStream_t) stream, d_sections, C, stride, d_buf, frames);
+        const int cpw = channels_per_workgroup (C);
+        const dim3 grid ((C + cpw - 1) / cpw);
+        if (S == 1) hipLaunchKernelGGL (biquad_order2_ff_kernel<1>, grid, dim3 (ST_THREADS), lds, (hipStream_t) stream, d_sections, C, stride, d_buf, frames, cpw);
+        else hipLaunchKernelGGL (biquad_order2_ff_kernel<2>, grid, dim3 (ST_THREADS), lds, (hipStream_t) stream, d_sections, C, stride, d_buf, frames, cpw);
     }
     else return -1;
     return hipGetLastError () == hipSuccess ? 0 : -1;
@@ -957,11 +969,12 @@ int arthip_decimate (const ArtDecArgs *a, const art_s *d_in, int frames, unsigne
         return hipGetLastError () == hipSuccess ? 1 : -1;      // 1: generator state now lives in gens_next
     }
     if (frames >= 64) {
-        const dim3 grid ((a->C + 63) / 64), block (ST_THREADS);
+        const int cpw = channels_per_workgroup (a->C);
+        const dim3 grid ((a->C + cpw - 1) / cpw), block (ST_THREADS);
         hipStream_t st = (hipStream_t) stream;
         const int order = a->shaping_on ? a->shaping_order : 0;
-#define DEC_GO(O) do { if (a->dither_on) hipLaunchKernelGGL ((decimate_lds_kernel<O, true>), grid, block, 0, st, *a, d_in, frames, d_out); \
-                       else hipLaunchKernelGGL ((decimate_lds_kernel<O, false>), grid, block, 0, st, *a, d_in, frames, d_out); } while (0)
+#define DEC_GO(O) do { if (a->dither_on) hipLaunchKernelGGL ((decimate_lds_kernel<O, true>), grid, block, 0, st, *a, d_in, frames, d_out, cpw); \
+                       else hipLaunchKernelGGL ((decimate_lds_kernel<O, false>), grid, block, 0, st, *a, d_in, frames, d_out, cpw); } while (0)
         switch (order) { case 0: DEC_GO (0); break; case 1: DEC_GO (1); break; case 2: DEC_GO (2); break; case 3: DEC_GO (3); break; default: DEC_GO (4); }
 #undef DEC_GO
         return hipGetLastError () == hipSuccess ? 0 : -1;
