@@ -129,12 +129,13 @@ void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile, int from_list
     const int ch0 = blockIdx.y * CG;
     const int half = a.T / 2;
     const unsigned int list_len = from_list ? min (*a.fix_count, a.fix_cap) : 1u;
-    // list mode: blocks [0, GEN_LIST_BLOCKS) walk the fix list; any further blocks (x only, y == 0) roll the history
-    // for the next call (reads hist ++ in, writes the other history buffer: independent of everything else in flight)
-    const unsigned int walkers = from_list ? GEN_LIST_BLOCKS : gridDim.x;
-    if (from_list && blockIdx.x >= GEN_LIST_BLOCKS) {
+    // Blocks [0, workers) evaluate outputs (list mode: GEN_LIST_BLOCKS walkers of the fix list; else one tile each); any
+    // further blocks (x only, y == 0) roll the history for the next call (reads hist ++ in, writes the OTHER history
+    // buffer: independent of everything else in flight) — one launch less per call.
+    const unsigned int workers = from_list ? GEN_LIST_BLOCKS : (a.n_end - a.n_begin + (unsigned int) tile - 1) / (unsigned int) tile;
+    if (blockIdx.x >= workers) {
         if (blockIdx.y) return;
-        const int e = (int)(blockIdx.x - GEN_LIST_BLOCKS) * GEN_THREADS + tid;
+        const int e = (int)(blockIdx.x - workers) * GEN_THREADS + tid;
         if (e < a.H * a.C) {
             const int f = e / a.C, c = e - f * a.C, lin = a.roll_appended + f;
             art_s v = 0;
@@ -144,8 +145,7 @@ void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile, int from_list
         }
         return;
     }
-
-  for (unsigned int item = blockIdx.x; item < (from_list ? list_len : gridDim.x); item += walkers) {
+  for (unsigned int item = blockIdx.x; item < (from_list ? list_len : workers); item += workers) {
     const unsigned int n0 = from_list ? a.fix_list [item] : a.n_begin + item * (unsigned int) tile;
     const int cnt = from_list ? 1 : (int) min ((unsigned int) tile, a.n_end - n0);
 
@@ -1022,8 +1022,8 @@ int launch_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st
     size_t lds = (size_t) span * CG * sizeof (art_s);
     if (lds > 160 * 1024 - 1024) return -1;                 // absurd ratio/taps combination
     const unsigned int total = a.n_end - a.n_begin;
-    const unsigned int roll_blocks = (from_list && a.roll_dst) ? (unsigned int)((a.H * a.C + GEN_THREADS - 1) / GEN_THREADS) : 0u;
-    dim3 grid (from_list ? GEN_LIST_BLOCKS + roll_blocks : (total + tile - 1) / tile, (a.C + CG - 1) / CG);
+    const unsigned int roll_blocks = a.roll_dst ? (unsigned int)((a.H * a.C + GEN_THREADS - 1) / GEN_THREADS) : 0u;
+    dim3 grid ((from_list ? GEN_LIST_BLOCKS : (total + tile - 1) / tile) + roll_blocks, (a.C + CG - 1) / CG);
     const bool precise = (a.mode & 3) == ART_MODE_PRECISE;
 
 #define GO(I, P) do { auto k = fir_general_kernel<CG, I, P>; \
@@ -1066,7 +1066,7 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
     // MFMA path: exact rational ratio, default numeric mode, interleaved buffers, no history floor — and enough work
     // to beat the general kernel.  Cost models fitted to MI355X measurements (tools/bench_small_taps.py,
     // profiles/r1_small_calls.txt), n = output frames of the launch:
-    //     general   ~ 8 us + n * k,    k = (0.2 + 0.04 C) + 0.00007 C T  ns per frame
+    //     general   ~ 5 us + n * k,    k = (0.2 + 0.04 C) + 0.00007 C T  ns per frame
     //     MFMA      ~ max (floor, work-bound),   floor = 14 us + 1.4 us per 32-tap chunk  (+ 6 us, and 2.1 us per chunk
     //                                             for C = 2: with <= 2 channels a workgroup replays 64 periods of positions)
     // The MFMA path is taken when the general kernel would take longer than the floor.  For channel counts without a
@@ -1077,7 +1077,7 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
         const double k_ns = (0.2 + 0.04 * a->C) + 0.00007 * a->C * a->T;
         const double chunks = (a->T + 63) / 32;
         const double floor_ns = 14000.0 + 1400.0 * chunks + (a->C <= 2 ? 6000.0 : 0.0) + (a->C == 2 ? 700.0 * chunks : 0.0);
-        enough = total * k_ns >= floor_ns - 8000.0;
+        enough = total * k_ns >= floor_ns - 5000.0;
     }
     else
         enough = (double) total * a->C * a->T >= 1.2e8;
@@ -1191,7 +1191,7 @@ general_path:
     if (a->ev_start) arthip_event_record (a->ev_start, stream);
     if (run_general (*a, *segs, st, 0)) return -1;
     if (a->ev_stop) arthip_event_record (a->ev_stop, stream);
-    return hipGetLastError () == hipSuccess ? ART_KERNEL_GENERAL : -1;
+    return hipGetLastError () == hipSuccess ? (ART_KERNEL_GENERAL | (a->roll_dst ? ART_FIR_ROLLED : 0)) : -1;
 }
 
 int arthip_roll_history (art_s *new_hist, const art_s *hist, const art_s *in, long in_pitch, int appended, int H, int C, void *stream)
