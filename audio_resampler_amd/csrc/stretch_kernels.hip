@@ -36,6 +36,7 @@ struct StretchState { int mark, fill, cur; int pad; double drift; };   // per st
 
 struct Scratch {                                   // LDS
     art_s mono [ST_MONO_MAX];
+    double addend [2400 + 8];                      // what the numerator chain adds, formed in parallel ahead of it
     art_s red_q [ST_WG / 64]; int red_p [ST_WG / 64];
     int any, pick;
     art_s *score;                                  // device memory: quick mode, quotient per decimated period
@@ -73,16 +74,38 @@ __device__ int pick_period (const StretchStage &S, Scratch &L, const art_s *x)
     const art_s *m = L.mono;
     const int p0 = QUICK ? S.lo / (C * 2) : S.lo / C;
     const int p1 = QUICK ? S.hi / (C * 2) : S.hi / C;                   // inclusive
-    // ---- numerators: one rounding chain over the candidates (last wave, lane 0), concurrent with the misses
+    // ---- numerators: one rounding chain over the candidates.  Its addends (|a| + |b| in double) are formed by all
+    // threads first; the chain itself (last wave, lane 0, concurrent with the misses) then reads them eight at a time, so
+    // no LDS latency sits between two of its steps.
+    // addend [j], j < p0: builds total (p0);  addend [p], p0 <= p < p1: takes total (p) to total (p + 1)
+    for (int j = tid; j < p1; j += ST_WG)
+        L.addend [j] = j < p0 ? fabs ((double) m [j]) + fabs ((double) m [j + p0])
+                              : fabs ((double) m [2 * j]) + fabs ((double) m [2 * j + 1]);
+    __syncthreads ();
     if (wave == ST_WG / 64 - 1) {
         if (lane == 0) {
             art_s total = 0;
-            for (int i = 0; i < p0; ++i) total = add_abs (total, fabs ((double) m [i]) + fabs ((double) m [i + p0]));
-            for (int p = p0; ; ++p) {
-                L.total [p - p0] = total;
-                if (p == p1) break;
-                total = add_abs (total, fabs ((double) m [2 * p]) + fabs ((double) m [2 * p + 1]));
+            int j = 0;
+            for (; j + 8 <= p0; j += 8) {
+                double a [8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a [u] = L.addend [j + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) total = add_abs (total, a [u]);
             }
+            for (; j < p0; ++j) total = add_abs (total, L.addend [j]);
+            // total is now total (p0); addend [p0 + k] takes total (p0 + k) to total (p0 + k + 1)
+            const int steps = p1 - p0;
+            int k = 0;
+            for (; k + 8 <= steps; k += 8) {
+                double a [8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a [u] = L.addend [p0 + k + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { L.total [k + u] = total; total = add_abs (total, a [u]); }
+            }
+            for (; k < steps; ++k) { L.total [k] = total; total = add_abs (total, L.addend [p0 + k]); }
+            L.total [steps] = total;
         }
     }
     // ---- misses: one lane per candidate, the reference's descending order
@@ -94,7 +117,15 @@ __device__ int pick_period (const StretchStage &S, Scratch &L, const art_s *x)
             // values that equals the plain sample-type addition (double rounding is innocuous for + when the wide format
             // has >= 2p + 2 bits: 53 >= 50).
             art_s miss = 0;
-            for (int i = p - 1; i >= 0; --i) {
+            int i = p - 1;
+            for (; i >= 7; i -= 8) {               // eight elements per trip: the sixteen LDS reads are issued together
+                art_s d [8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) d [u] = m [i - u] - m [i - u + p];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) miss = miss + (d [u] < (art_s) 0 ? -d [u] : d [u]);
+            }
+            for (; i >= 0; --i) {
                 const art_s d = m [i] - m [i + p];
                 miss = miss + (d < (art_s) 0 ? -d : d);
             }
