@@ -358,7 +358,10 @@ _bound = {}
 
 def binding(width=32):
     if width not in _bound:
-        _bound[width] = _bind(width)
+        ns = _bind(width)
+        # the flag values (resampler.h / decimator.h) are the same for both builds
+        vars(ns).update({k: v for k, v in globals().items() if k.isupper() and isinstance(v, int)})
+        _bound[width] = ns
     return _bound[width]
 
 

@@ -1138,16 +1138,20 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
 
 #else
     // fp64 matrix-core path: exact rational ratio, interleaved buffers, the stream's channel count one of the
-    // compiled column groups, no history floor — and enough work (same crossover rule as the float build)
+    // compiled column groups, no history floor — and enough work: cost models as in the float build, fitted to this
+    // build (tools/bench_small_taps.py --wide): general ~ 5 us + n (0.2 + 0.05 C + 0.00021 C T) ns, fp64 MFMA floor
+    // ~ 15 us + 4.1 us per 32-tap chunk
     {
         const unsigned int total = a->n_end - a->n_begin;
-        const double work = (double) total * a->C * a->T;
+        const double k_ns = (0.2 + 0.05 * a->C) + 0.00021 * a->C * a->T;
+        const double floor_ns = 15000.0 + 4100.0 * ((a->T + 63) / 32);
+        const bool enough = total * k_ns >= floor_ns - 5000.0;
         const bool small = (size_t) a->in_frames * a->C * 8 < 0x7fff0000ull && (size_t) a->H * a->C * 8 < 0x7fff0000ull &&
                            ((uintptr_t) a->in % 16) == 0 && ((uintptr_t) a->hist % 16) == 0;
         const int cgt = (small && (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32)) ? a->C : 0;
         const bool ok = a->mode == ART_MODE_FAST && a->period_out > 0 && a->fix_list && a->scratch && a->in_pitch == 0 && a->out_pitch == 0 &&
                         segs->lin_floor == INT_MIN && kernel_pref != ART_KERNEL_GENERAL && cgt != 0 &&
-                        (work >= 1.2e8 || kernel_pref >= ART_KERNEL_MFMA) && total >= (unsigned int) a->period_out;
+                        (enough || kernel_pref >= ART_KERNEL_MFMA) && total >= (unsigned int) a->period_out;
         if (ok) {
             WideGeom g;
             g.P = a->period_out; g.Q = a->period_in;

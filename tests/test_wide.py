@@ -277,7 +277,7 @@ def test_wide_headline_shape_block_default_mode_vs_oracle():
     # 8 channels, 988 x 988 interpolating, 44.1k -> 48k: the headline configuration with double samples; this much work
     # takes the fp64 matrix-core kernel by itself
     torch = pytest.importorskip("torch")
-    ch, T, n = 8, 988, 16384
+    ch, T, n = 8, 988, 65536        # 71k output frames: beyond the general / fp64-MFMA crossover (~62k)
     ratio = 48000 / 44100
     x, _ = O.noise(n * ch)
     x = x.reshape(n, ch)
