@@ -537,7 +537,11 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
                 // select, not left to wrap as a negative number — the compiler may split an offset into register + immediate,
                 // and the hardware's range check does not wrap that sum to 32 bits (a "negative" base plus a positive
                 // immediate would be rejected although the true offset is valid).
+#ifdef ABL_BL1     // ablation: the same number of X loads, all inside 16 KB (vL1D hits) — separates issue cost from L2->L1 bandwidth
+                const unsigned int oi = ((unsigned int)((lin - a.H) * CG + cv * VEC) * 4u) & 0x3ff0u;
+#else
                 const unsigned int oi = lin >= a.H ? (unsigned int)((lin - a.H) * CG + cv * VEC) * 4u : 0xfffffff0u;
+#endif
                 VecLoad<VEC>::load (&rb [u * VEC], rs_in, oi);
                 if (touches_hist) {
                     float hv [VEC];
@@ -678,6 +682,53 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
         // two separate loops (disjoint live ranges => registers = max of the two roles, not the sum);
         // both execute exactly nchunks + 1 barriers
         if (loader) {
+            if (CG && MT == 1 && !touches_hist) {
+                // No vector arithmetic per chunk (measured +10 %: vector-unit instructions of ANY wave on a SIMD take issue
+                // slots from its matrix pipe): every thread's offsets and LDS addresses are fixed, the chunk moves the
+                // resource BASES (scalar unit; the range check moves with them, so past-the-end reads stay 0), and the
+                // loop is unrolled by the two LDS buffers so their addresses are immediates.  Tiles that reach into the
+                // history buffer (first period group of a call) keep the general loop below.
+                constexpr unsigned int A_STEP = MF_KC * 4u, B_STEP = MF_KC * CG * 4u;
+                const unsigned int a_bytes = (unsigned int)((size_t) ROWS * g.ktot * 4), b_bytes = (unsigned int)((size_t) a.in_frames * a.C * 4);
+                const char *a_base = reinterpret_cast<const char *> (g.eff + (size_t) st * ROWS * g.ktot);
+                const char *b_base = reinterpret_cast<const char *> (a.in);
+                unsigned int boff [NB]; int bdst [NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int v = pt + u * MF_THREADS;
+                    const int jl = v / VPP, rem = v % VPP, kk = rem / VPF, cv = rem % VPF;
+                    boff [u] = (unsigned int)((w0 + jl * g.Q + kk - a.H) * CG + cv * VEC) * 4u;     // >= 0: the tile is past the history
+                    bdst [u] = (jl * CG + cv * VEC) * MF_LD + kk;
+                }
+                const int adst = a_row * MF_LD + a_kseg;
+                auto lean_fetch = [&] (int chunk) {
+                    const unsigned int sa = min ((unsigned int) chunk * A_STEP, a_bytes), sb = min ((unsigned int) chunk * B_STEP, b_bytes);
+                    const __amdgpu_buffer_rsrc_t ra_ = make_rsrc (a_base + sa, a_bytes - sa), rb_ = make_rsrc (b_base + sb, b_bytes - sb);
+                    VecLoad<4>::load (ra0, ra_, a_off0);
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) VecLoad<VEC>::load (&rb0 [u * VEC], rb_, boff [u]);
+                };
+                auto lean_commit = [&] (auto buf_tag) {
+                    constexpr int BUF = decltype (buf_tag)::value % NBUF;      // (NBUF = 1 only in the instantiations that never get here)
+                    f32x4 v; v [0] = ra0 [0]; v [1] = ra0 [1]; v [2] = ra0 [2]; v [3] = ra0 [3];
+                    *reinterpret_cast<f32x4 *> (&As_ [BUF] [adst]) = v;
+#pragma unroll
+                    for (int u = 0; u < NB; ++u)
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) Bs_ [BUF] [bdst [u] + e * MF_LD] = rb0 [u * VEC + e];
+                };
+                lean_fetch (0); lean_commit (std::integral_constant<int, 0> {}); lean_fetch (1);
+                __syncthreads ();
+                for (int chunk = 0; chunk < nchunks; chunk += 2) {
+                    lean_commit (std::integral_constant<int, 1> {}); lean_fetch (chunk + 2);
+                    __syncthreads ();
+                    if (chunk + 1 < nchunks) {
+                        lean_commit (std::integral_constant<int, 0> {}); lean_fetch (chunk + 3);
+                        __syncthreads ();
+                    }
+                }
+                return;
+            }
             // one register stage (a second one in flight — commit chunk c+1 while c+2 lands — measured within noise, +1.4 %)
             fetch (0, ra0, rb0); commit (0, 0, ra0, rb0); fetch (1, ra0, rb0);
             __syncthreads ();
@@ -898,6 +949,34 @@ void fir_mfma64_kernel (ArtFirArgs a, ArtSegTable segs, WideGeom g)
             }
         }
     };
+    // Tiles past the history buffer (all but the first period group of a call): fixed per-thread offsets, the chunk moves
+    // the resource bases on the scalar unit — no vector arithmetic per chunk beside the matrix pipe (see fir_mfma_kernel)
+    const unsigned int rows_bytes = (unsigned int)((size_t) NROWS * g.ktot * 8), in_bytes = (unsigned int)((size_t) a.in_frames * CG * 8);
+    const char *rows_base = reinterpret_cast<const char *> (g.rows + (size_t) st * NROWS * g.ktot);
+    static_assert (MW_THREADS % VPP == 0, "per-vector period step must be uniform");
+    const int aoff = (a_row * g.ktot + a_kseg) * 8;          // vector u / row tile m differ from the first by a UNIFORM step: scalar too
+    const int boff = ((w0 + (tid / VPP) * g.Q + (tid % VPP) / VPF - a.H) * CG + ((tid % VPP) % VPF) * VEC) * 8;
+    auto lean_fetch = [&] (int chunk) {
+#pragma unroll
+        for (int m = 0; m < NA; ++m) {
+            const unsigned int sa = min ((unsigned int) chunk * (MW_KC * 8u) + (unsigned int)(m * 32 * g.ktot) * 8u, rows_bytes);
+            const w_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128 (wide_rsrc (rows_base + sa, rows_bytes - sa), aoff, 0, 0);
+            ra [m * 2] = u2d (v.x, v.y); ra [m * 2 + 1] = u2d (v.z, v.w);
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const unsigned int sb = min ((unsigned int) chunk * (MW_KC * CG * 8u) + (unsigned int)(u * (MW_THREADS / VPP) * g.Q) * (CG * 8u), in_bytes);
+            const __amdgpu_buffer_rsrc_t r_in = wide_rsrc (reinterpret_cast<const char *> (a.in) + sb, in_bytes - sb);
+            if (VEC == 2) {
+                const w_u32x4 x = __builtin_amdgcn_raw_buffer_load_b128 (r_in, boff, 0, 0);
+                rb [u * VEC] = u2d (x.x, x.y); rb [u * VEC + (VEC - 1)] = u2d (x.z, x.w);
+            }
+            else {
+                const w_u32x2 x = __builtin_amdgcn_raw_buffer_load_b64 (r_in, boff, 0, 0);
+                rb [u * VEC] = u2d (x.x, x.y);
+            }
+        }
+    };
     auto commit = [&] () {
 #pragma unroll
         for (int m = 0; m < NA; ++m) {
@@ -925,12 +1004,12 @@ void fir_mfma64_kernel (ArtFirArgs a, ArtSegTable segs, WideGeom g)
 
     const int nchunks = g.ktot / MW_KC;
     const int frag = (lane & 15) * MW_LD + 2 * (lane >> 4);      // this lane's (row | column, k pair) inside a 16-wide tile
-    fetch (0);
+    if (touches_hist) fetch (0); else lean_fetch (0);
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         __syncthreads ();                                    // previous chunk fully consumed (first pass: status table complete)
         commit ();
         __syncthreads ();
-        if (chunk + 1 < nchunks) fetch (chunk + 1);          // global loads fly while the matrix cores work
+        if (chunk + 1 < nchunks) { if (touches_hist) fetch (chunk + 1); else lean_fetch (chunk + 1); }    // global loads fly while the matrix cores work
 #pragma unroll
         for (int grp = 0; grp < MW_KC / 8; ++grp) {
             f64x2 av [RT], bv [2];
