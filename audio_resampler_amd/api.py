@@ -137,6 +137,8 @@ def _bind(width):
         "stretchHipSetStream": (None, [ptr, ptr]),
         "stretchProcessDevice": (C.c_int, [ptr, ptr, C.c_int, ptr, C.c_double]),
         "stretchFlushDevice": (C.c_int, [ptr, ptr]),
+        "stretchProcessBatchDevice": (C.c_int, [ptr, C.c_int, ptr, ptr, ptr, ptr, ptr]),
+        "stretchFlushBatchDevice": (C.c_int, [ptr, C.c_int, ptr, ptr]),
     }
 
     _state = {"lib": None}

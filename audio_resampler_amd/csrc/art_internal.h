@@ -119,6 +119,12 @@ typedef struct {
 int arthip_stretch_call (const ArtStretchArgs *h, const art_s *d_in, int frames, art_s *d_out, double ratio, int flush,
                          int *d_result, void *stream);
 
+/* the same call on n independent streams in ONE launch (one workgroup per stream): d_items / d_done in device memory */
+typedef struct { int mark, fill, cur, pad; double drift; } ArtStretchState;          /* per stage; layout of stretch_kernels.hip */
+typedef struct { ArtStretchArgs args; const art_s *in; art_s *out; double ratio; int frames, flush; } ArtStretchItem;
+typedef struct { int made, pad; ArtStretchState state [2]; } ArtStretchDone;
+int arthip_stretch_batch (const ArtStretchItem *d_items, ArtStretchDone *d_done, int n, void *stream);
+
 int arthip_ingest (const unsigned char *d_in, art_s gain_factor, int bits, int bytes, int stride, art_s *d_out, int n, void *stream);
 
 #ifdef __cplusplus

@@ -17,6 +17,7 @@ struct artamd_stretch {
     int *d_result;
     void *stream;
     int blocks;                                        /* ring size in longest periods: 3, or 4 in fast mode */
+    void *d_batch; size_t batch_cap;                   /* batched calls led by this context: items + results */
 };
 
 static void *regrow (void *dev, size_t *cap, size_t need)
@@ -121,7 +122,7 @@ void stretchFree (Stretch *cxt)
         ArtStretchArgs *a = &cxt->hip->args;
         for (int s = 0; s < 2; ++s) for (int b = 0; b < 2; ++b) arthip_free (a->ring [s][b]);
         arthip_free (a->between); arthip_free (a->total); arthip_free (a->score); arthip_free (a->state);
-        arthip_free (cxt->hip->d_result); arthip_free (cxt->hip->d_in); arthip_free (cxt->hip->d_out);
+        arthip_free (cxt->hip->d_result); arthip_free (cxt->hip->d_in); arthip_free (cxt->hip->d_out); arthip_free (cxt->hip->d_batch);
         free (cxt->hip);
     }
     free (cxt->next);
@@ -180,6 +181,65 @@ int stretchProcessDevice (Stretch *cxt, const artsample_t *d_samples, int num_sa
 int stretchFlushDevice (Stretch *cxt, artsample_t *d_output)
 {
     return device_call (cxt, NULL, 0, d_output, 1.0, 1);
+}
+
+/* n independent streams, one launch: item i is exactly the call stretchProcessDevice (cxts [i], ...) / stretchFlushDevice
+ * would make — same device code, one workgroup per stream — so results are identical to n separate calls.  The launch
+ * goes to the stream of cxts [0], whose scratch also carries the item table. */
+static int batch_call (Stretch *const *cxts, int n, const artsample_t *const *d_samples, const int *num_samples,
+                       artsample_t *const *d_outputs, const double *ratios, int flush, int *produced)
+{
+    if (n <= 0) return 0;
+    struct artamd_stretch *lead = cxts [0]->hip;
+    const size_t items_bytes = ((size_t) n * sizeof (ArtStretchItem) + 63) & ~(size_t) 63, done_bytes = (size_t) n * sizeof (ArtStretchDone);
+    ArtStretchItem *items = malloc (items_bytes);
+    ArtStretchDone *done = malloc (done_bytes);
+    int rc = -1;
+
+    lead->d_batch = regrow (lead->d_batch, &lead->batch_cap, items_bytes + done_bytes);
+    if (!items || !done || !lead->d_batch) goto out;
+
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < i; ++j)
+            if (cxts [j] == cxts [i]) { fprintf (stderr, "artamd: stretch batch: a context appears twice\n"); goto out; }
+        items [i].args = cxts [i]->hip->args;
+        items [i].in = flush ? NULL : d_samples [i];
+        items [i].out = d_outputs [i];
+        items [i].ratio = flush ? 1.0 : ratios [i];
+        items [i].frames = flush ? 0 : num_samples [i];
+        /* a stream with nothing to process this round still takes part: its workgroup returns at once */
+        items [i].flush = flush;
+    }
+
+    ArtStretchDone *d_done = (ArtStretchDone *)((char *) lead->d_batch + items_bytes);
+    if (arthip_h2d (lead->d_batch, items, (size_t) n * sizeof (ArtStretchItem), lead->stream) ||
+        arthip_stretch_batch ((const ArtStretchItem *) lead->d_batch, d_done, n, lead->stream) ||
+        arthip_d2h (done, d_done, done_bytes, lead->stream) || arthip_sync (lead->stream)) {
+        fprintf (stderr, "artamd: stretch batch launch failed: %s\n", arthip_last_error ());
+        goto out;
+    }
+
+    for (int i = 0; i < n; ++i) {
+        Stretch *c = cxts [i];
+        produced [i] = done [i].made;
+        c->tail = done [i].state [0].mark; c->head = done [i].state [0].fill; c->outsamples_error = done [i].state [0].drift;
+        if (c->next) { c->next->tail = done [i].state [1].mark; c->next->head = done [i].state [1].fill; c->next->outsamples_error = done [i].state [1].drift; }
+    }
+    rc = 0;
+out:
+    free (items); free (done);
+    return rc;
+}
+
+int stretchProcessBatchDevice (Stretch *const *cxts, int n, const artsample_t *const *d_samples, const int *num_samples,
+                               artsample_t *const *d_outputs, const double *ratios, int *produced)
+{
+    return batch_call (cxts, n, d_samples, num_samples, d_outputs, ratios, 0, produced);
+}
+
+int stretchFlushBatchDevice (Stretch *const *cxts, int n, artsample_t *const *d_outputs, int *produced)
+{
+    return batch_call (cxts, n, NULL, NULL, d_outputs, NULL, 1, produced);
 }
 
 /* frames a call can emit at most: what is buffered plus what comes in, at the largest stage ratios, plus slack */

@@ -210,6 +210,10 @@ __device__ int feed (const StretchStage *stages, StretchState *states, Scratch &
     int left = values;
     while (left) {
         const int take = left < S.room - st.fill ? left : S.room - st.fill;
+        // Full ring and nothing processable: only reachable by feeding after a flush without a reset, where the reference's
+        // loop (stretch.c:195-212: nothing copied, nothing processed, num_samples unchanged) never ends.  A spinning workgroup would take the device with it: stop, keep
+        // what the call has produced, drop the rest of its input.
+        if (take == 0 && !(st.mark >= S.hi && st.fill - st.mark >= S.hi * (S.quick ? 3 : 2))) break;
         copy_values (S.ring [st.cur] + st.fill, in, take);
         left -= take; in += take; st.fill += take;
         __syncthreads ();
@@ -330,7 +334,51 @@ void stretch_call_kernel (StretchLaunch a, const art_s *in, int frames, art_s *o
     if (threadIdx.x == 0) *result = made;
 }
 
+// one workgroup per stream: the single-stream kernel's body on item blockIdx.x; the stream's state after the call is
+// copied beside the frame count so that the host reads everything back in one transfer
+__global__ __launch_bounds__ (ST_WG)
+void stretch_batch_kernel (const ArtStretchItem *items, ArtStretchDone *done)
+{
+    __shared__ Scratch L;
+    __shared__ StretchStage stage [2];
+    const ArtStretchItem &it = items [blockIdx.x];
+    if (threadIdx.x == 0) {
+        for (int s = 0; s < 2; ++s) {
+            stage [s].ring [0] = (art_s *) it.args.ring [s][0]; stage [s].ring [1] = (art_s *) it.args.ring [s][1];
+            stage [s].between = (art_s *) it.args.between;
+            stage [s].channels = it.args.channels; stage [s].room = it.args.room; stage [s].lo = it.args.lo; stage [s].hi = it.args.hi;
+            stage [s].quick = it.args.quick;
+        }
+        L.total = (art_s *) it.args.total; L.score = (art_s *) it.args.score;
+    }
+    StretchState *state = (StretchState *) it.args.state;
+    __syncthreads ();
+    int made;
+    if (it.flush) made = it.args.paired ? drain<true> (stage, state, L, it.out) : drain<false> (stage, state, L, it.out);
+    else if (it.frames <= 0) made = 0;             // as stretchProcessDevice: nothing to do for this stream this round
+    else {
+        const int values = it.frames * it.args.channels;
+        made = it.args.paired ? feed<true> (stage, state, L, it.in, values, it.out, it.ratio) : feed<false> (stage, state, L, it.in, values, it.out, it.ratio);
+    }
+    __syncthreads ();
+    if (threadIdx.x == 0) {
+        ArtStretchDone &d = done [blockIdx.x];
+        d.made = made; d.pad = 0;
+        for (int s = 0; s < 2; ++s) {
+            d.state [s].mark = state [s].mark; d.state [s].fill = state [s].fill; d.state [s].cur = state [s].cur;
+            d.state [s].pad = 0; d.state [s].drift = state [s].drift;
+        }
+    }
+}
+
 } // namespace
+
+extern "C" int arthip_stretch_batch (const ArtStretchItem *d_items, ArtStretchDone *d_done, int n, void *stream)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL (stretch_batch_kernel, dim3 (n), dim3 (ST_WG), 0, (hipStream_t) stream, d_items, d_done);
+    return hipGetLastError () == hipSuccess ? 0 : -1;
+}
 
 extern "C" int arthip_stretch_call (const ArtStretchArgs *h, const art_s *d_in, int frames, art_s *d_out, double ratio, int flush,
                                    int *d_result, void *stream)

@@ -92,6 +92,13 @@ void stretchHipSetStream (Stretch *cxt, void *hipStream);
  * count is the return value).  d_output must hold stretchGetOutputCapacity() frames. */
 int stretchProcessDevice (Stretch *cxt, const artsample_t *d_samples, int num_samples, artsample_t *d_output, double ratio);
 int stretchFlushDevice (Stretch *cxt, artsample_t *d_output);
+/* The stretcher is one serial state machine per stream, so the GPU earns its keep on MANY streams: these make the call
+ * above on n independent contexts in ONE launch, one workgroup per context (results identical to n separate calls; the
+ * launch uses the stream of cxts[0]; a context may appear only once).  produced[i] = frames written to d_outputs[i].
+ * Return 0, or -1 if the launch failed (nothing is then known about the contexts' state). */
+int stretchProcessBatchDevice (Stretch *const *cxts, int n, const artsample_t *const *d_samples, const int *num_samples,
+                               artsample_t *const *d_outputs, const double *ratios, int *produced);
+int stretchFlushBatchDevice (Stretch *const *cxts, int n, artsample_t *const *d_outputs, int *produced);
 
 #ifdef __cplusplus
 }

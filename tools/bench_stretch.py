@@ -55,4 +55,20 @@ for ch, flags, ratio, name in ((1, 0, 1.25, "mono x1.25"), (2, 0, 0.8, "stereo x
             [t.start() for t in th]; [t.join() for t in th]
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         row[f"gpu_realtime_factor_{nstreams}_streams"] = round(nstreams * secs / dt, 1)
+    # the batched entry point: one launch per round for all streams, one workgroup per stream
+    import ctypes as C
+    for nstreams in (64, 512):
+        ctxs = [S.HipStretch(rate // 350, rate // 50, ch, flags) for _ in range(nstreams)]
+        cap = ctxs[0].capacity(blk, ratio)
+        d_in = torch.from_numpy(x).cuda()
+        d_outs = [torch.empty(cap, ch, device="cuda") for _ in range(nstreams)]
+        ctx = (C.c_void_p * nstreams)(*[c.p for c in ctxs]); outs = (C.c_void_p * nstreams)(*[d.data_ptr() for d in d_outs])
+        made = (C.c_int * nstreams)(); rat = (C.c_double * nstreams)(*([ratio] * nstreams))
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for pos in range(0, x.shape[0], blk):
+            n = min(blk, x.shape[0] - pos)
+            ins = (C.c_void_p * nstreams)(*([d_in[pos:].data_ptr()] * nstreams)); fr = (C.c_int * nstreams)(*([n] * nstreams))
+            assert L.stretchProcessBatchDevice(ctx, nstreams, ins, fr, outs, rat, made) == 0
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        row[f"gpu_realtime_factor_batched_{nstreams}_streams"] = round(nstreams * secs / dt, 1)
     print(json.dumps(row), flush=True)
