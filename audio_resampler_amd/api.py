@@ -137,6 +137,7 @@ def _bind(width):
         "stretchHipSetStream": (None, [ptr, ptr]),
         "stretchProcessDevice": (C.c_int, [ptr, ptr, C.c_int, ptr, C.c_double]),
         "stretchFlushDevice": (C.c_int, [ptr, ptr]),
+        "resampleProcessBatchInterleavedDevice": (C.c_int, [ptr, C.c_int, ptr, ptr, ptr, ptr, ptr, ptr]),
         "stretchProcessBatchDevice": (C.c_int, [ptr, C.c_int, ptr, ptr, ptr, ptr, ptr]),
         "stretchFlushBatchDevice": (C.c_int, [ptr, C.c_int, ptr, ptr]),
     }
@@ -351,6 +352,20 @@ def _bind(width):
             out = (Biquad * self.n)()
             self.L.biquadBankRead(self.p, out)
             return out
+
+    def process_batch_device(resamplers, d_ins, n_ins, d_outs, out_caps, ratios):
+        """resampleProcessBatchInterleavedDevice over a list of Resampler objects: one call per context, one launch for those
+        the general kernel runs.  Returns [(input_used, output_generated), ...] (raises if a launch failed)."""
+        n = len(resamplers)
+        ctx = (C.c_void_p * n)(*[C.cast(r.p, C.c_void_p) for r in resamplers])
+        res = (ResampleResult * n)()
+        rc = lib().resampleProcessBatchInterleavedDevice(
+            ctx, n, (C.c_void_p * n)(*[_dev_ptr(d) for d in d_ins]), (C.c_int * n)(*[int(v) for v in n_ins]),
+            (C.c_void_p * n)(*[_dev_ptr(d) for d in d_outs]), (C.c_int * n)(*[int(v) for v in out_caps]),
+            (C.c_double * n)(*[float(v) for v in ratios]), res)
+        if rc:
+            raise RuntimeError("resampleProcessBatchInterleavedDevice failed")
+        return [(r.input_used, r.output_generated) for r in res]
 
     return types.SimpleNamespace(**{k: v for k, v in locals().items() if not k.startswith("_") and k != "width"}, width=width)
 

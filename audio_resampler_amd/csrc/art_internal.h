@@ -81,6 +81,13 @@ float arthip_event_elapsed_ms (void *start, void *stop);   /* synchronises on `s
 /* ---- sinc_fir.hip ---- */
 /* returns the kernel actually used (ART_KERNEL_*), <0 on launch failure */
 int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, void *stream);
+/* n independent general-kernel calls (default / precise mode) in one launch per kernel variant; d_table = device scratch of
+ * n * arthip_fir_batch_item_bytes () bytes; waits for the stream (the frame counts are host-side, the wait only protects
+ * the argument table) */
+size_t arthip_fir_batch_item_bytes (void);
+int arthip_fir_batch_max_segments (void);                /* ring-epoch segments a batched call may have */
+int arthip_fir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref);   /* what arthip_fir would do */
+int arthip_fir_batch (const ArtFirArgs *a, const ArtSegTable *segs, int n, void *d_table, void *stream);
 /* new_hist[H][C] = last H frames of (hist ++ in[0..appended)); in may be NULL => zeros appended */
 int arthip_roll_history (art_s *new_hist, const art_s *hist, const art_s *in, long in_pitch, int appended, int H, int C, void *stream);
 int arthip_interleave (art_s *dst, const art_s *src_planar, long pitch, int frames, int C, void *stream);

@@ -41,6 +41,8 @@ struct artamd_resampler {
     art_s *d_patch; size_t patch_cap;        /* end-point extrapolation: samples computed on the host */
     void *d_scratch; size_t scratch_cap;     /* MFMA path: effective rows + canonical positions of one launch */
     unsigned int *d_fix; size_t fix_cap;    /* [0] = counter, [1..] = output indices handed back by the MFMA kernel */
+    void *d_batch; size_t batch_cap;         /* argument table of the batched calls led by this context */
+    unsigned long batch_stamp;               /* last batched call this context took part in (duplicate check) */
 };
 
 /* ------------------------------------------------------------------------------------------
@@ -345,7 +347,7 @@ void resampleFree (Resample *cxt)
     if (hip) {
         arthip_sync (hip->stream);
         arthip_free (hip->d_bank); arthip_free (hip->d_hist [0]); arthip_free (hip->d_hist [1]);
-        arthip_free (hip->d_in); arthip_free (hip->d_out); arthip_free (hip->d_tmp); arthip_free (hip->d_fix); arthip_free (hip->d_scratch); arthip_free (hip->d_patch);
+        arthip_free (hip->d_in); arthip_free (hip->d_out); arthip_free (hip->d_tmp); arthip_free (hip->d_fix); arthip_free (hip->d_scratch); arthip_free (hip->d_patch); arthip_free (hip->d_batch);
         for (int i = 0; i < hip->ev_cap; ++i) arthip_event_destroy (hip->ev [i]);
         free (hip->ev);
         free (hip->segs);
@@ -687,6 +689,127 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
                  ((res.output_generated == 0) ? (cxt->flags & EXTRAPOLATE_PREFILL) : 0);
     hip->floor_active = trial.floorActive;
     return res;
+}
+
+/* ---- many independent streams, one launch -------------------------------------------------------------------------
+ * A service that resamples hundreds of streams in small blocks is launch-bound one call at a time.  This entry point
+ * plans every context's call on the host exactly as the single call does, gathers those the general kernel would run
+ * (any ratio per stream, default or EXTEND mode, ordinary call, on the stream of cxts [0]) into one launch per kernel
+ * variant — each stream cut into the tiles its own launch would use, so the samples are identical — and simply makes
+ * the remaining calls (flushes, strict mode, endpoint extrapolation, calls big enough for the matrix-core path, other
+ * streams) one by one.  results [i] is what resampleProcessInterleavedDevice (cxts [i], ...) would have returned. */
+static int batch_plan (Resample *cxt, const art_s *d_in, int nIn, art_s *d_out, int cap, double ratio, void *lead_stream,
+                       ArtFirArgs *a, ArtSegTable *tab, ResampleResult *res, ArtamdPosition *trial)
+{
+    struct artamd_resampler *hip = cxt->hip;
+    const int T = cxt->numTaps, C = cxt->numChannels, H = HIST_FRAMES (T);
+    ArtamdPosition pos;
+    int lin_floor, nseg;
+
+    if (nIn < 0 || hip->stream != lead_stream || hip->timing ||
+        (cxt->flags & (EXTRAPOLATE_ENDPOINTS | RESAMPLE_STRICT_ORDER | RESAMPLER_FLUSHED))) return 0;
+
+    pos.numTaps = T; pos.numFilters = cxt->numFilters; pos.flags = cxt->flags; pos.inputIndex = cxt->inputIndex;
+    pos.floorActive = hip->floor_active; pos.outputOffset = cxt->outputOffset; pos.fixedRatio = cxt->fixedRatio;
+    const double eff_ratio = (cxt->flags & RESAMPLE_FIXED_RATIO) ? cxt->fixedRatio : ratio;
+
+    for (;;) {
+        *trial = pos;
+        nseg = artamdPlanCall (trial, nIn, cap, ratio, res, hip->segs, hip->seg_cap, &lin_floor);
+        if (nseg <= hip->seg_cap) break;
+        hip->seg_cap = nseg + 16;
+        hip->segs = realloc (hip->segs, sizeof (ArtamdSegment) * hip->seg_cap);
+    }
+    if (nseg > arthip_fir_batch_max_segments () || res->output_generated == 0) return 0;
+
+    if (eff_ratio != hip->period_ratio) {
+        hip->period_ratio = eff_ratio;
+        find_period (eff_ratio, &hip->period_out, &hip->period_in);
+    }
+
+    memset (a, 0, sizeof (*a));
+    a->bank = hip->d_bank; a->hist = hip->d_hist [hip->cur];
+    a->in = d_in; a->in_pitch = 0; a->in_frames = (int) res->input_used;
+    a->out = d_out; a->out_pitch = 0;
+    a->C = C; a->T = T; a->F = cxt->numFilters; a->H = H;
+    a->interpolate = (cxt->flags & SUBSAMPLE_INTERPOLATE) != 0;
+    a->lowpass = (cxt->flags & INCLUDE_LOWPASS) != 0;
+    a->mode = (!ART_WIDE && (cxt->flags & EXTEND_CONVOLUTION_MATH)) ? ART_MODE_PRECISE : ART_MODE_FAST;
+    a->ratio = eff_ratio;
+    a->period_out = hip->period_out; a->period_in = hip->period_in;
+
+    tab->count = nseg; tab->lin_floor = lin_floor;
+    for (int s = 0; s < nseg; ++s) {
+        tab->first [s] = hip->segs [s].first_output;
+        tab->lin_base [s] = hip->segs [s].lin_base;
+        tab->base [s] = hip->segs [s].base_offset;
+    }
+    a->n_begin = hip->segs [0].first_output; a->n_end = res->output_generated;
+
+    /* would the single call take the matrix-core path?  (it has the hand-back list and scratch whenever the ratio is
+     * rational, the mode default and the kernel not pinned: stand-ins suffice for the question) */
+    if (a->period_out && a->mode == ART_MODE_FAST && hip->kernel_pref != ART_KERNEL_GENERAL) {
+        a->fix_count = (unsigned int *) hip; a->fix_list = (unsigned int *) hip; a->scratch = hip; a->scratch_bytes = (size_t) 8 << 20;
+        if (arthip_fir_takes_matrix_path (a, tab, hip->kernel_pref)) return 0;
+        a->fix_count = a->fix_list = NULL; a->scratch = NULL; a->scratch_bytes = 0;
+    }
+
+    const int appended = (int) res->input_used;
+    a->roll_dst = appended > 0 ? hip->d_hist [hip->cur ^ 1] : NULL;      /* the launch takes the history roll along */
+    a->roll_appended = appended;
+    return 1;
+}
+
+int resampleProcessBatchInterleavedDevice (Resample *const *cxts, int n, const artsample_t *const *d_inputs, const int *numInputFrames,
+                                           artsample_t *const *d_outputs, const int *numOutputFrames, const double *ratios,
+                                           ResampleResult *results)
+{
+    if (n <= 0) return 0;
+    struct artamd_resampler *lead = cxts [0]->hip;
+    ArtFirArgs *args = malloc (sizeof (ArtFirArgs) * (size_t) n);
+    ArtSegTable *tabs = malloc (sizeof (ArtSegTable) * (size_t) n);
+    ArtamdPosition *trials = malloc (sizeof (ArtamdPosition) * (size_t) n);
+    int *owner = malloc (sizeof (int) * (size_t) n);
+    int gathered = 0, rc = -1;
+
+    if (!args || !tabs || !trials || !owner) goto out;
+    {   /* a context may appear only once: stamp each with this call's number (one pass) */
+        static unsigned long calls;
+        const unsigned long stamp = __atomic_add_fetch (&calls, 1, __ATOMIC_RELAXED);
+        for (int i = 0; i < n; ++i) {
+            if (cxts [i]->hip->batch_stamp == stamp) { fprintf (stderr, "artamd: resample batch: a context appears twice\n"); goto out; }
+            cxts [i]->hip->batch_stamp = stamp;
+        }
+    }
+
+    for (int i = 0; i < n; ++i) {
+        if (batch_plan (cxts [i], d_inputs [i], numInputFrames [i], d_outputs [i], numOutputFrames [i], ratios [i], lead->stream,
+                        &args [gathered], &tabs [gathered], &results [i], &trials [gathered]))
+            owner [gathered++] = i;
+        else
+            results [i] = enqueue_call (cxts [i], d_inputs [i], 0, numInputFrames [i], d_outputs [i], 0, numOutputFrames [i], ratios [i]);
+    }
+
+    if (gathered) {
+        lead->d_batch = grow (lead->d_batch, &lead->batch_cap, arthip_fir_batch_item_bytes () * (size_t) gathered);
+        if (!lead->d_batch || arthip_fir_batch (args, tabs, gathered, lead->d_batch, lead->stream)) {
+            fprintf (stderr, "artamd: resample batch launch failed: %s\n", arthip_last_error ());
+            for (int k = 0; k < gathered; ++k) results [owner [k]].input_used = results [owner [k]].output_generated = 0;
+            goto out;
+        }
+        for (int k = 0; k < gathered; ++k) {
+            Resample *cxt = cxts [owner [k]];
+            if (args [k].roll_dst) cxt->hip->cur ^= 1;
+            cxt->outputOffset = trials [k].outputOffset; cxt->inputIndex = trials [k].inputIndex;
+            cxt->flags = (cxt->flags & ~(RESAMPLER_FLUSHED | EXTRAPOLATE_PREFILL)) | (trials [k].flags & RESAMPLER_FLUSHED);
+            cxt->hip->floor_active = trials [k].floorActive;
+            cxt->hip->last_kernel = ART_KERNEL_GENERAL;
+        }
+    }
+    rc = 0;
+out:
+    free (args); free (tabs); free (trials); free (owner);
+    return rc;
 }
 
 ResampleResult resampleProcessInterleavedDevice (Resample *cxt, const artsample_t *d_input, int numInputFrames,

@@ -117,8 +117,7 @@ constexpr unsigned int GEN_LIST_BLOCKS = 512;   // workgroups walking the fix li
 // `from_list`: instead of tiling [n_begin, n_end), every workgroup evaluates single output frames whose
 // indices were handed back by the MFMA kernel (a.fix_list / *a.fix_count).
 template <int CG, bool INTERP, bool PRECISE>
-__global__ __launch_bounds__ (GEN_THREADS)
-void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile, int from_list)
+__device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const ArtSegTable &segs, int tile, int from_list, unsigned int bx, unsigned int by)
 {
     using Acc = typename std::conditional<PRECISE || ART_WIDE, double, float>::type;   // 8-byte samples accumulate in double
     extern __shared__ __attribute__ ((aligned (16))) art_s xs [];
@@ -126,16 +125,16 @@ void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile, int from_list
     __shared__ double s_frac [GEN_MAX_TILE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ch0 = blockIdx.y * CG;
+    const int ch0 = by * CG;
     const int half = a.T / 2;
     const unsigned int list_len = from_list ? min (*a.fix_count, a.fix_cap) : 1u;
     // Blocks [0, workers) evaluate outputs (list mode: GEN_LIST_BLOCKS walkers of the fix list; else one tile each); any
     // further blocks (x only, y == 0) roll the history for the next call (reads hist ++ in, writes the OTHER history
     // buffer: independent of everything else in flight) — one launch less per call.
     const unsigned int workers = from_list ? GEN_LIST_BLOCKS : (a.n_end - a.n_begin + (unsigned int) tile - 1) / (unsigned int) tile;
-    if (blockIdx.x >= workers) {
-        if (blockIdx.y) return;
-        const int e = (int)(blockIdx.x - workers) * GEN_THREADS + tid;
+    if (bx >= workers) {
+        if (by) return;
+        const int e = (int)(bx - workers) * GEN_THREADS + tid;
         if (e < a.H * a.C) {
             const int f = e / a.C, c = e - f * a.C, lin = a.roll_appended + f;
             art_s v = 0;
@@ -145,7 +144,7 @@ void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile, int from_list
         }
         return;
     }
-  for (unsigned int item = blockIdx.x; item < (from_list ? list_len : workers); item += workers) {
+  for (unsigned int item = bx; item < (from_list ? list_len : workers); item += workers) {
     const unsigned int n0 = from_list ? a.fix_list [item] : a.n_begin + item * (unsigned int) tile;
     const int cnt = from_list ? 1 : (int) min ((unsigned int) tile, a.n_end - n0);
 
@@ -249,6 +248,40 @@ void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile, int from_list
             }
     }
   }
+}
+
+template <int CG, bool INTERP, bool PRECISE>
+__global__ __launch_bounds__ (GEN_THREADS)
+void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile, int from_list)
+{
+    fir_general_body<CG, INTERP, PRECISE> (a, segs, tile, from_list, blockIdx.x, blockIdx.y);
+}
+
+// Many independent streams, one launch: blockIdx.z picks a stream's call (its arguments sit in a table in device memory,
+// exactly what the single-stream launch would have passed by value), x / y are that call's own grid.  Same body, same
+// tile geometry => the samples are identical to n separate launches.
+constexpr int BATCH_SEGS = 4;                       // ring-epoch segments a batched call may have (small blocks have 1 or 2)
+struct FirBatchItem {
+    ArtFirArgs a;
+    int seg_count, lin_floor;
+    unsigned int first [BATCH_SEGS]; int lin_base [BATCH_SEGS]; double base [BATCH_SEGS];
+    int tile; unsigned int blocks_x, blocks_y; int pad;
+};
+
+template <int CG, bool INTERP, bool PRECISE>
+__global__ __launch_bounds__ (GEN_THREADS)
+void fir_general_batch_kernel (const FirBatchItem *items)
+{
+    __shared__ ArtSegTable s_tab;                   // the table the body expects, rebuilt from the item's few entries
+    const FirBatchItem &it = items [blockIdx.z];
+    if (blockIdx.x >= it.blocks_x || blockIdx.y >= it.blocks_y) return;
+    if (threadIdx.x < BATCH_SEGS) {
+        s_tab.first [threadIdx.x] = it.first [threadIdx.x]; s_tab.lin_base [threadIdx.x] = it.lin_base [threadIdx.x];
+        s_tab.base [threadIdx.x] = it.base [threadIdx.x];
+    }
+    if (threadIdx.x == 0) { s_tab.count = it.seg_count; s_tab.lin_floor = it.lin_floor; }
+    __syncthreads ();
+    fir_general_body<CG, INTERP, PRECISE> (it.a, s_tab, it.tile, 0, blockIdx.x, blockIdx.y);
 }
 
 // Strict kernel: one lane per output sample, taps visited in the reference's source order
@@ -1084,8 +1117,9 @@ __global__ void deinterleave_kernel (art_s *dst, long pitch, const art_s *src, i
     dst [(size_t) c * pitch + f] = src [e];
 }
 
+// tile size, LDS bytes and grid of one general-kernel launch (shared by the single and the batched launch)
 template <int CG>
-int launch_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st, int from_list = 0)
+bool general_geometry (const ArtFirArgs &a, int from_list, int *tile_out, size_t *lds_out, dim3 *grid_out, unsigned int crowd = 1)
 {
     // tile size: as many consecutive outputs as keep the staged span within the LDS budget
     const int lds_budget = 64 * 1024;
@@ -1094,15 +1128,26 @@ int launch_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st
     if (tile > GEN_MAX_TILE) tile = GEN_MAX_TILE;
     // small calls: prefer many small tiles (each wave walks its tile's outputs serially, so latency ~ tile/4
     // outputs) over staging efficiency, until there are about four workgroups per CU
+    // (`crowd` = launches of this size sharing the grid — the batched entry point: many streams fill the chip together, so
+    // each keeps larger tiles.  An output's value does not depend on the tile it is computed in.)
     const unsigned int total_outputs = a.n_end - a.n_begin;
-    while (tile > 4 && (total_outputs + tile - 1) / tile < 1024u) tile >>= 1;
+    while (tile > 4 && (unsigned long long)((total_outputs + tile - 1) / tile) * crowd < 1024u) tile >>= 1;
     if (tile < 1 || from_list) tile = 1;
     long span = a.T + (long) ceil (tile / a.ratio) + 3;
     size_t lds = (size_t) span * CG * sizeof (art_s);
-    if (lds > 160 * 1024 - 1024) return -1;                 // absurd ratio/taps combination
+    if (lds > 160 * 1024 - 1024) return false;              // absurd ratio/taps combination
     const unsigned int total = a.n_end - a.n_begin;
     const unsigned int roll_blocks = a.roll_dst ? (unsigned int)((a.H * a.C + GEN_THREADS - 1) / GEN_THREADS) : 0u;
-    dim3 grid ((from_list ? GEN_LIST_BLOCKS : (total + tile - 1) / tile) + roll_blocks, (a.C + CG - 1) / CG);
+    *tile_out = tile; *lds_out = lds;
+    *grid_out = dim3 ((from_list ? GEN_LIST_BLOCKS : (total + tile - 1) / tile) + roll_blocks, (a.C + CG - 1) / CG);
+    return true;
+}
+
+template <int CG>
+int launch_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st, int from_list = 0)
+{
+    int tile; size_t lds; dim3 grid;
+    if (!general_geometry<CG> (a, from_list, &tile, &lds, &grid)) return -1;
     const bool precise = (a.mode & 3) == ART_MODE_PRECISE;
 
 #define GO(I, P) do { auto k = fir_general_kernel<CG, I, P>; \
@@ -1114,6 +1159,37 @@ int launch_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st
     return 0;
 }
 
+template <int CG>
+int batch_variant (const ArtFirArgs *a, const ArtSegTable *segs, const int *which, int count, bool interp, bool precise,
+                          FirBatchItem *host, FirBatchItem *dev, hipStream_t st)
+{
+    size_t lds_max = 0; unsigned int gx = 0, gy = 0;
+    for (int k = 0; k < count; ++k) {
+        const int i = which [k];
+        int tile; size_t lds; dim3 grid;
+        if (!general_geometry<CG> (a [i], 0, &tile, &lds, &grid, (unsigned int) count)) return -1;
+        if (segs [i].count > BATCH_SEGS) return -1;
+        host [k].a = a [i]; host [k].seg_count = segs [i].count; host [k].lin_floor = segs [i].lin_floor;
+        for (int q = 0; q < BATCH_SEGS; ++q) {
+            const bool used = q < segs [i].count;
+            host [k].first [q] = used ? segs [i].first [q] : 0u; host [k].lin_base [q] = used ? segs [i].lin_base [q] : 0; host [k].base [q] = used ? segs [i].base [q] : 0.0;
+        }
+        host [k].tile = tile; host [k].blocks_x = grid.x; host [k].blocks_y = grid.y; host [k].pad = 0;
+        if (lds > lds_max) lds_max = lds;
+        if (grid.x > gx) gx = grid.x;
+        if (grid.y > gy) gy = grid.y;
+    }
+    if (hipMemcpyAsync (dev, host, sizeof (FirBatchItem) * (size_t) count, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+#define GOB(I, P) do { auto k = fir_general_batch_kernel<CG, I, P>; \
+        if (lds_max > 48 * 1024) (void) hipFuncSetAttribute ((const void *) k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_max); \
+        hipLaunchKernelGGL (k, dim3 (gx, gy, (unsigned int) count), dim3 (GEN_THREADS), lds_max, st, (const FirBatchItem *) dev); } while (0)
+    if (interp) { if (precise) GOB (true, true); else GOB (true, false); }
+    else        { if (precise) GOB (false, true); else GOB (false, false); }
+#undef GOB
+    return hipGetLastError () == hipSuccess ? 0 : -1;
+}
+
+
 } // namespace
 
 extern "C" {
@@ -1124,6 +1200,92 @@ static int run_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_
     if (a.C > 2) return launch_general<4> (a, segs, st, from_list);
     if (a.C == 2) return launch_general<2> (a, segs, st, from_list);
     return launch_general<1> (a, segs, st, from_list);
+}
+
+// does this call take the matrix-core path (arthip_fir), or the general kernel?  One rule, also asked by the batched entry
+// point, which only gathers calls the general kernel would have run anyway.
+static bool takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref)
+{
+    if (a->n_end <= a->n_begin || (a->mode & 3) == ART_MODE_STRICT) return false;
+#if !ART_WIDE
+    const unsigned int total = a->n_end - a->n_begin;
+    bool enough;
+    if (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32) {
+        const double k_ns = (0.2 + 0.04 * a->C) + 0.00007 * a->C * a->T;
+        const double chunks = (a->T + 63) / 32;
+        const double floor_ns = 14000.0 + 1400.0 * chunks + (a->C <= 2 ? 6000.0 : 0.0) + (a->C == 2 ? 700.0 * chunks : 0.0);
+        enough = total * k_ns >= floor_ns - 5000.0;
+    }
+    else
+        enough = (double) total * a->C * a->T >= 1.2e8;
+    return a->mode == ART_MODE_FAST && a->period_out > 0 && a->fix_list && a->scratch && a->in_pitch == 0 && a->out_pitch == 0 &&
+                         segs->lin_floor == INT_MIN && kernel_pref != ART_KERNEL_GENERAL &&
+                         (enough || kernel_pref >= ART_KERNEL_MFMA) && total >= (unsigned int) a->period_out;
+
+#else
+    const unsigned int total = a->n_end - a->n_begin;
+    const double k_ns = (0.2 + 0.05 * a->C) + 0.00021 * a->C * a->T;
+    const double floor_ns = 15000.0 + 4100.0 * ((a->T + 63) / 32);
+    const bool enough = total * k_ns >= floor_ns - 5000.0;
+    const bool small = (size_t) a->in_frames * a->C * 8 < 0x7fff0000ull && (size_t) a->H * a->C * 8 < 0x7fff0000ull &&
+                       ((uintptr_t) a->in % 16) == 0 && ((uintptr_t) a->hist % 16) == 0;
+    const int cgt = (small && (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32)) ? a->C : 0;
+    return a->mode == ART_MODE_FAST && a->period_out > 0 && a->fix_list && a->scratch && a->in_pitch == 0 && a->out_pitch == 0 &&
+                    segs->lin_floor == INT_MIN && kernel_pref != ART_KERNEL_GENERAL && cgt != 0 &&
+                    (enough || kernel_pref >= ART_KERNEL_MFMA) && total >= (unsigned int) a->period_out;
+#endif
+}
+
+int arthip_fir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref) { return takes_matrix_path (a, segs, kernel_pref) ? 1 : 0; }
+
+// n general-kernel calls of independent streams as ONE launch per kernel variant (column group x interpolation x
+// accumulator type; streams of one service normally share it).  d_table: device scratch of at least
+// n * arthip_fir_batch_item_bytes () bytes.  Returns 0, or -1 (nothing usable was launched for some item).
+size_t arthip_fir_batch_item_bytes (void) { return sizeof (FirBatchItem); }
+int arthip_fir_batch_max_segments (void) { return BATCH_SEGS; }
+
+int arthip_fir_batch (const ArtFirArgs *a, const ArtSegTable *segs, int n, void *d_table, void *stream)
+{
+    hipStream_t st = (hipStream_t) stream;
+    if (n <= 0) return 0;
+    // pinned staging (per calling thread, kept): the table goes to the device without the runtime's bounce through its own
+    // pinned buffers
+    static thread_local FirBatchItem *tl_host = nullptr;
+    static thread_local size_t tl_cap = 0;
+    if ((size_t) n > tl_cap) {
+        if (tl_host) (void) hipHostFree (tl_host);
+        tl_cap = (size_t) n + (size_t) n / 2 + 64;
+        if (hipHostMalloc ((void **) &tl_host, sizeof (FirBatchItem) * tl_cap, hipHostMallocDefault) != hipSuccess) { tl_host = nullptr; tl_cap = 0; return -1; }
+    }
+    FirBatchItem *host = tl_host;
+    int *which = (int *) malloc (sizeof (int) * (size_t) n);
+    if (!which) return -1;
+    int rc = 0, done = 0;
+    // group by kernel variant; each group takes its own slice of the table (the copies are asynchronous, the slices must
+    // not be reused inside one call)
+    for (int cgi = 0; cgi < 4 && !rc; ++cgi)
+        for (int v = 0; v < 4 && !rc; ++v) {
+            const bool interp = (v & 1) != 0, precise = (v & 2) != 0;
+            int count = 0;
+            for (int i = 0; i < n; ++i) {
+                const int cls = a [i].C > 4 ? 3 : a [i].C > 2 ? 2 : a [i].C == 2 ? 1 : 0;
+                if (cls == cgi && (a [i].interpolate != 0) == interp && (((a [i].mode & 3) == ART_MODE_PRECISE) == precise) && a [i].n_end > a [i].n_begin)
+                    which [count++] = i;
+            }
+            if (!count) continue;
+            FirBatchItem *hslice = host + done, *dslice = (FirBatchItem *) d_table + done;
+            switch (cgi) {
+                case 3: rc = batch_variant<8> (a, segs, which, count, interp, precise, hslice, dslice, st); break;
+                case 2: rc = batch_variant<4> (a, segs, which, count, interp, precise, hslice, dslice, st); break;
+                case 1: rc = batch_variant<2> (a, segs, which, count, interp, precise, hslice, dslice, st); break;
+                default: rc = batch_variant<1> (a, segs, which, count, interp, precise, hslice, dslice, st); break;
+            }
+            done += count;
+        }
+    // the host table must outlive the asynchronous copies out of it
+    if (hipStreamSynchronize (st) != hipSuccess) rc = -1;
+    free (which);
+    return rc;
 }
 
 int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, void *stream)
@@ -1151,18 +1313,7 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
     // The MFMA path is taken when the general kernel would take longer than the floor.  For channel counts without a
     // compiled column group the older rule stays: outputs x channels x taps of at least 1.2e8.
     const unsigned int total = a->n_end - a->n_begin;
-    bool enough;
-    if (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32) {
-        const double k_ns = (0.2 + 0.04 * a->C) + 0.00007 * a->C * a->T;
-        const double chunks = (a->T + 63) / 32;
-        const double floor_ns = 14000.0 + 1400.0 * chunks + (a->C <= 2 ? 6000.0 : 0.0) + (a->C == 2 ? 700.0 * chunks : 0.0);
-        enough = total * k_ns >= floor_ns - 5000.0;
-    }
-    else
-        enough = (double) total * a->C * a->T >= 1.2e8;
-    const bool mfma_ok = a->mode == ART_MODE_FAST && a->period_out > 0 && a->fix_list && a->scratch && a->in_pitch == 0 && a->out_pitch == 0 &&
-                         segs->lin_floor == INT_MIN && kernel_pref != ART_KERNEL_GENERAL &&
-                         (enough || kernel_pref >= ART_KERNEL_MFMA) && total >= (unsigned int) a->period_out;
+    const bool mfma_ok = takes_matrix_path (a, segs, kernel_pref);
 
     if (mfma_ok) {
         MfmaGeom g;
@@ -1222,15 +1373,10 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
     // ~ 15 us + 4.1 us per 32-tap chunk
     {
         const unsigned int total = a->n_end - a->n_begin;
-        const double k_ns = (0.2 + 0.05 * a->C) + 0.00021 * a->C * a->T;
-        const double floor_ns = 15000.0 + 4100.0 * ((a->T + 63) / 32);
-        const bool enough = total * k_ns >= floor_ns - 5000.0;
         const bool small = (size_t) a->in_frames * a->C * 8 < 0x7fff0000ull && (size_t) a->H * a->C * 8 < 0x7fff0000ull &&
                            ((uintptr_t) a->in % 16) == 0 && ((uintptr_t) a->hist % 16) == 0;
         const int cgt = (small && (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32)) ? a->C : 0;
-        const bool ok = a->mode == ART_MODE_FAST && a->period_out > 0 && a->fix_list && a->scratch && a->in_pitch == 0 && a->out_pitch == 0 &&
-                        segs->lin_floor == INT_MIN && kernel_pref != ART_KERNEL_GENERAL && cgt != 0 &&
-                        (enough || kernel_pref >= ART_KERNEL_MFMA) && total >= (unsigned int) a->period_out;
+        const bool ok = takes_matrix_path (a, segs, kernel_pref);
         if (ok) {
             WideGeom g;
             g.P = a->period_out; g.Q = a->period_in;

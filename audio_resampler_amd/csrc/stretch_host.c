@@ -18,6 +18,7 @@ struct artamd_stretch {
     void *stream;
     int blocks;                                        /* ring size in longest periods: 3, or 4 in fast mode */
     void *d_batch; size_t batch_cap;                   /* batched calls led by this context: items + results */
+    unsigned long batch_stamp;                         /* last batched call this context took part in (duplicate check) */
 };
 
 static void *regrow (void *dev, size_t *cap, size_t need)
@@ -199,9 +200,11 @@ static int batch_call (Stretch *const *cxts, int n, const artsample_t *const *d_
     lead->d_batch = regrow (lead->d_batch, &lead->batch_cap, items_bytes + done_bytes);
     if (!items || !done || !lead->d_batch) goto out;
 
+    static unsigned long calls;
+    const unsigned long stamp = __atomic_add_fetch (&calls, 1, __ATOMIC_RELAXED);
     for (int i = 0; i < n; ++i) {
-        for (int j = 0; j < i; ++j)
-            if (cxts [j] == cxts [i]) { fprintf (stderr, "artamd: stretch batch: a context appears twice\n"); goto out; }
+        if (cxts [i]->hip->batch_stamp == stamp) { fprintf (stderr, "artamd: stretch batch: a context appears twice\n"); goto out; }
+        cxts [i]->hip->batch_stamp = stamp;
         items [i].args = cxts [i]->hip->args;
         items [i].in = flush ? NULL : d_samples [i];
         items [i].out = d_outputs [i];

@@ -42,6 +42,16 @@ ResampleResult resampleProcessInterleavedDevice (Resample *cxt, const artsample_
                                                  artsample_t *d_output, int numOutputFrames, double ratio);
 ResampleResult resampleProcessAndFlushInterleavedDevice (Resample *cxt, const artsample_t *d_input, int numInputFrames,
                                                          artsample_t *d_output, int numOutputFrames, double ratio);
+/* Many independent streams, one launch: results [i] and the samples in d_outputs [i] are exactly what
+ * resampleProcessInterleavedDevice (cxts [i], d_inputs [i], numInputFrames [i], d_outputs [i], numOutputFrames [i], ratios [i])
+ * would have produced.  Contexts whose call the general kernel runs (any ratio per context, default or EXTEND mode, an
+ * ordinary call, on the stream of cxts [0]) share launches — a service with hundreds of small-block streams is
+ * launch-bound one call at a time; all other calls (strict mode, endpoint extrapolation, calls large enough for the
+ * matrix-core path, contexts on other streams) are simply made one by one.  A context may appear only once.  The call
+ * waits for the stream (only to release its argument table).  Returns 0, or -1 if a launch failed. */
+int resampleProcessBatchInterleavedDevice (Resample *const *cxts, int n, const artsample_t *const *d_inputs, const int *numInputFrames,
+                                           artsample_t *const *d_outputs, const int *numOutputFrames, const double *ratios,
+                                           ResampleResult *results);
 /* planar device buffers: channel c at d_input + c*inputPitch (in samples), likewise output */
 ResampleResult resampleProcessPlanarDevice (Resample *cxt, const artsample_t *d_input, long inputPitch, int numInputFrames,
                                             artsample_t *d_output, long outputPitch, int numOutputFrames, double ratio);

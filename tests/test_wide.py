@@ -3,7 +3,7 @@
 libartamd64.so is the product tree compiled with -DPATH_WIDTH=64; oracle/_build/liboracle64_*.so the restatement with
 double samples; tests/golden/wide.npz + artest64_kat.json come from the real reference built with -DPATH_WIDTH=64
 (tests/golden/make_golden64.py).  CPU tests pin the wide oracle and the library's host logic; GPU tests are the
-parity tests: strict mode bit for bit, default mode within 2^-48 (relative to max(1,|y|)) of the reference-order
+parity tests: strict mode bit for bit, default mode within 2^-47 (relative to max(1,|y|)) of the reference-order
 result — there is ONE arithmetic in this build (EXTEND_CONVOLUTION_MATH is a no-op, reference resampler.c:191), the
 default mode only re-associates the double accumulation across a wave.
 """
@@ -27,7 +27,7 @@ O = _oracle.wide()                       # oracle / reference bindings, double s
 W = A.wide()                             # product binding, double samples
 f64p, u8p = W.f32p, W.u8p
 STRICT = A.RESAMPLE_STRICT_ORDER
-FAST_TOL = 2.0 ** -48
+FAST_TOL = 2.0 ** -47      # two differently ordered double sums of ~1000 products; largest seen in 600 large random sessions: 34 * 2^-53
 
 _z = {}
 
