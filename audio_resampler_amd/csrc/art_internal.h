@@ -82,8 +82,7 @@ float arthip_event_elapsed_ms (void *start, void *stop);   /* synchronises on `s
 /* returns the kernel actually used (ART_KERNEL_*), <0 on launch failure */
 int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, void *stream);
 /* n independent general-kernel calls (default / precise mode) in one launch per kernel variant; d_table = device scratch of
- * n * arthip_fir_batch_item_bytes () bytes; waits for the stream (the frame counts are host-side, the wait only protects
- * the argument table) */
+ * n * arthip_fir_batch_item_bytes () bytes (reused call after call: stream order protects it); asynchronous like arthip_fir */
 size_t arthip_fir_batch_item_bytes (void);
 int arthip_fir_batch_max_segments (void);                /* ring-epoch segments a batched call may have */
 int arthip_fir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref);   /* what arthip_fir would do */

@@ -1249,15 +1249,20 @@ int arthip_fir_batch (const ArtFirArgs *a, const ArtSegTable *segs, int n, void 
     hipStream_t st = (hipStream_t) stream;
     if (n <= 0) return 0;
     // pinned staging (per calling thread, kept): the table goes to the device without the runtime's bounce through its own
-    // pinned buffers
-    static thread_local FirBatchItem *tl_host = nullptr;
-    static thread_local size_t tl_cap = 0;
-    if ((size_t) n > tl_cap) {
-        if (tl_host) (void) hipHostFree (tl_host);
-        tl_cap = (size_t) n + (size_t) n / 2 + 64;
-        if (hipHostMalloc ((void **) &tl_host, sizeof (FirBatchItem) * tl_cap, hipHostMallocDefault) != hipSuccess) { tl_host = nullptr; tl_cap = 0; return -1; }
+    // pinned buffers.  Two tables take turns, each guarded by an event recorded after the copies out of it: the call
+    // returns without waiting for the stream, and the host plans the next tick while this one runs.
+    struct Staging { FirBatchItem *host; size_t cap; hipEvent_t ev; bool pending; };
+    static thread_local Staging tl [2] = { { nullptr, 0, nullptr, false }, { nullptr, 0, nullptr, false } };
+    static thread_local int tl_turn = 0;
+    Staging &sg = tl [tl_turn ^= 1];
+    if (sg.pending) { (void) hipEventSynchronize (sg.ev); sg.pending = false; }
+    if (!sg.ev && hipEventCreateWithFlags (&sg.ev, hipEventDisableTiming) != hipSuccess) { sg.ev = nullptr; return -1; }
+    if ((size_t) n > sg.cap) {
+        if (sg.host) (void) hipHostFree (sg.host);
+        sg.cap = (size_t) n + (size_t) n / 2 + 64;
+        if (hipHostMalloc ((void **) &sg.host, sizeof (FirBatchItem) * sg.cap, hipHostMallocDefault) != hipSuccess) { sg.host = nullptr; sg.cap = 0; return -1; }
     }
-    FirBatchItem *host = tl_host;
+    FirBatchItem *host = sg.host;
     int *which = (int *) malloc (sizeof (int) * (size_t) n);
     if (!which) return -1;
     int rc = 0, done = 0;
@@ -1282,8 +1287,9 @@ int arthip_fir_batch (const ArtFirArgs *a, const ArtSegTable *segs, int n, void 
             }
             done += count;
         }
-    // the host table must outlive the asynchronous copies out of it
-    if (hipStreamSynchronize (st) != hipSuccess) rc = -1;
+    // the host table must outlive the asynchronous copies out of it: marked here, waited for before its next turn
+    if (hipEventRecord (sg.ev, st) == hipSuccess) sg.pending = true;
+    else if (hipStreamSynchronize (st) != hipSuccess) rc = -1;
     free (which);
     return rc;
 }

@@ -47,8 +47,8 @@ ResampleResult resampleProcessAndFlushInterleavedDevice (Resample *cxt, const ar
  * would have produced.  Contexts whose call the general kernel runs (any ratio per context, default or EXTEND mode, an
  * ordinary call, on the stream of cxts [0]) share launches — a service with hundreds of small-block streams is
  * launch-bound one call at a time; all other calls (strict mode, endpoint extrapolation, calls large enough for the
- * matrix-core path, contexts on other streams) are simply made one by one.  A context may appear only once.  The call
- * waits for the stream (only to release its argument table).  Returns 0, or -1 if a launch failed. */
+ * matrix-core path, contexts on other streams) are simply made one by one.  A context may appear only once.  Asynchronous
+ * like the single call: counts are returned at once, the samples land on the stream.  Returns 0, or -1 if a launch failed. */
 int resampleProcessBatchInterleavedDevice (Resample *const *cxts, int n, const artsample_t *const *d_inputs, const int *numInputFrames,
                                            artsample_t *const *d_outputs, const int *numOutputFrames, const double *ratios,
                                            ResampleResult *results);
