@@ -641,7 +641,19 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
         if ((cxt->flags & RESAMPLE_STRICT_ORDER) && extend) a.mode |= 4;
         a.ratio = eff_ratio;
         a.period_out = hip->period_out; a.period_in = hip->period_in;
-        if (a.period_out && a.mode == ART_MODE_FAST && hip->kernel_pref != ART_KERNEL_GENERAL) {
+        /* the matrix-core path needs a hand-back list and 8 MB of scratch: allocated only once a call of this context is
+         * actually big enough for it (asked with stand-ins first — a service with thousands of small-block contexts never
+         * pays for them) */
+        int matrix_sized = 0;
+        if (a.period_out && a.mode == ART_MODE_FAST && hip->kernel_pref != ART_KERNEL_GENERAL && !is_flush) {
+            ArtSegTable probe;
+            probe.count = 1; probe.lin_floor = lin_floor;
+            a.fix_count = a.fix_list = (unsigned int *) hip; a.scratch = hip; a.scratch_bytes = (size_t) 8 << 20;
+            a.n_begin = 0; a.n_end = res.output_generated;
+            matrix_sized = arthip_fir_takes_matrix_path (&a, &probe, hip->kernel_pref);
+            a.fix_count = a.fix_list = NULL; a.scratch = NULL; a.scratch_bytes = 0; a.n_begin = a.n_end = 0;
+        }
+        if (matrix_sized) {
             /* [0] per-launch count, [1] running total (diagnostics), [2..] the list */
             if (sizeof (unsigned int) * ((size_t) res.output_generated + 2) > hip->fix_cap) {
                 hip->d_fix = grow (hip->d_fix, &hip->fix_cap, sizeof (unsigned int) * ((size_t) res.output_generated + 2));
