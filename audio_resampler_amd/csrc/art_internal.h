@@ -65,6 +65,7 @@ typedef struct {
 
 /* ---- device_rt.hip ---- */
 int   arthip_device_count (void);
+int   arthip_current_device (void);
 void *arthip_malloc (size_t bytes);
 void  arthip_free (void *p);
 int   arthip_h2d (void *dst, const void *src, size_t bytes, void *stream);

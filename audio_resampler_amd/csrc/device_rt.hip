@@ -28,6 +28,7 @@ int arthip_device_count (void)
 }
 
 int artamdDeviceCount (void) { return arthip_device_count (); }
+int arthip_current_device (void) { int d = 0; return hipGetDevice (&d) == hipSuccess ? d : -1; }
 
 void *arthip_malloc (size_t bytes)
 {

@@ -11,6 +11,7 @@
 #define _USE_MATH_DEFINES
 #include <limits.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -23,9 +24,11 @@
 
 #define HIST_FRAMES(T) ((T) + (T) / 2)      /* frames of history kept in HBM between calls */
 
+struct BankEntry;
 struct artamd_resampler {
     void *stream;
-    art_s *d_bank;
+    struct BankEntry *bank;                 /* shared filter bank (bank_acquire / bank_release) */
+    art_s *d_bank;                          /* = bank->dev */
     art_s *d_hist [2];                      /* ping-pong history, HIST x C interleaved */
     int cur;
     art_s *d_in;  size_t in_cap;            /* staging for host-pointer calls (bytes) */
@@ -221,6 +224,57 @@ static void *grow (void *dev, size_t *cap, size_t need)
     return dev;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Filter banks are shared: a service opens thousands of contexts with a handful of presets, a bank is up to 4 MB of HBM
+ * and milliseconds of double-precision design work.  Contexts with the same (taps, filters, low-pass ratio, window) on the
+ * same device reference ONE device bank (read-only to every kernel) and copy the designed rows for their own host table
+ * (`filters` stays a private, writable array as in the reference).  Freed with its last context.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct BankEntry {
+    int T, F, bh, device, refs;
+    double lowpass;
+    art_s *host, *dev;
+    struct BankEntry *next;
+} BankEntry;
+
+static BankEntry *bank_list;
+static pthread_mutex_t bank_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static BankEntry *bank_acquire (int T, int F, double lowpass, int flags)
+{
+    const int bh = (flags & BLACKMAN_HARRIS) != 0, device = arthip_current_device ();
+    const size_t bytes = sizeof (art_s) * (size_t)(F + 1) * T;
+    BankEntry *e;
+
+    pthread_mutex_lock (&bank_lock);
+    for (e = bank_list; e; e = e->next)
+        if (e->T == T && e->F == F && e->bh == bh && e->device == device && e->lowpass == lowpass) { e->refs++; break; }
+    if (!e && (e = calloc (1, sizeof (*e)))) {
+        e->T = T; e->F = F; e->bh = bh; e->device = device; e->lowpass = lowpass; e->refs = 1;
+        e->host = malloc (bytes);
+        e->dev = arthip_malloc (bytes);
+        if (e->host) artamdBuildFilterBank (T, F, lowpass, flags, e->host);
+        if (!e->host || !e->dev || arthip_h2d (e->dev, e->host, bytes, NULL) || arthip_sync (NULL)) {
+            arthip_free (e->dev); free (e->host); free (e); e = NULL;
+        }
+        else { e->next = bank_list; bank_list = e; }
+    }
+    pthread_mutex_unlock (&bank_lock);
+    return e;
+}
+
+static void bank_release (BankEntry *e)
+{
+    if (!e) return;
+    pthread_mutex_lock (&bank_lock);
+    if (--e->refs == 0) {
+        for (BankEntry **p = &bank_list; *p; p = &(*p)->next)
+            if (*p == e) { *p = e->next; break; }
+        arthip_free (e->dev); free (e->host); free (e);
+    }
+    pthread_mutex_unlock (&bank_lock);
+}
+
 Resample *resampleInit (int numChannels, int numTaps, int numFilters, double lowpassRatio, int flags)
 {
     if (lowpassRatio > 0.0 && lowpassRatio < 1.0)
@@ -267,21 +321,27 @@ Resample *resampleInit (int numChannels, int numTaps, int numFilters, double low
     cxt->outputOffset = numTaps / 2;
     cxt->inputIndex = numTaps;
 
-    /* host copy of the bank, exposed through the reference's `filters` row-pointer table */
+    /* the bank: shared on the device, a private host copy exposed through the reference's `filters` row-pointer table */
+    hip->bank = bank_acquire (numTaps, numFilters, lowpassRatio, flags);
     art_s *bank = malloc (sizeof (art_s) * bank_count);
-    artamdBuildFilterBank (numTaps, numFilters, lowpassRatio, flags, bank);
     cxt->filters = malloc (sizeof (art_s *) * (size_t)(numFilters + 1));
+    if (!hip->bank || !bank || !cxt->filters) {
+        fprintf (stderr, "artamd: filter bank allocation failed: %s\n", arthip_last_error ());
+        free (bank); free (cxt->filters); cxt->filters = NULL;
+        resampleFree (cxt);
+        return NULL;
+    }
+    memcpy (bank, hip->bank->host, sizeof (art_s) * bank_count);
     for (int f = 0; f <= numFilters; ++f)
         cxt->filters [f] = bank + (size_t) f * numTaps;
 
-    hip->d_bank = arthip_malloc (sizeof (art_s) * bank_count);
+    hip->d_bank = hip->bank->dev;
     hip->d_hist [0] = arthip_malloc (hist_bytes);
     hip->d_hist [1] = arthip_malloc (hist_bytes);
     hip->seg_cap = 64;
     hip->segs = malloc (sizeof (ArtamdSegment) * hip->seg_cap);
 
-    if (!hip->d_bank || !hip->d_hist [0] || !hip->d_hist [1] ||
-        arthip_h2d (hip->d_bank, bank, sizeof (art_s) * bank_count, NULL) ||
+    if (!hip->d_hist [0] || !hip->d_hist [1] ||
         arthip_zero (hip->d_hist [0], hist_bytes, NULL) || arthip_zero (hip->d_hist [1], hist_bytes, NULL) ||
         arthip_sync (NULL)) {
         fprintf (stderr, "artamd: device allocation failed: %s\n", arthip_last_error ());
@@ -346,7 +406,7 @@ void resampleFree (Resample *cxt)
 
     if (hip) {
         arthip_sync (hip->stream);
-        arthip_free (hip->d_bank); arthip_free (hip->d_hist [0]); arthip_free (hip->d_hist [1]);
+        bank_release (hip->bank); arthip_free (hip->d_hist [0]); arthip_free (hip->d_hist [1]);
         arthip_free (hip->d_in); arthip_free (hip->d_out); arthip_free (hip->d_tmp); arthip_free (hip->d_fix); arthip_free (hip->d_scratch); arthip_free (hip->d_patch); arthip_free (hip->d_batch);
         for (int i = 0; i < hip->ev_cap; ++i) arthip_event_destroy (hip->ev [i]);
         free (hip->ev);

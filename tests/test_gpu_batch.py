@@ -80,3 +80,34 @@ def test_batch_argument_checks():
     with pytest.raises(RuntimeError):
         B.process_batch_device([r, r], [d, d], [10, 10], [d, d], [32, 32], [1.0, 1.0])          # a context twice
     assert B.process_batch_device([], [], [], [], [], []) == []
+
+
+def test_shared_filter_bank_lifecycle():
+    """Contexts with the same preset share one device bank (reference-counted) and keep private host rows: freeing one must
+    not disturb the others, a different preset gets its own bank, and writing into one context's `filters` rows (a plain
+    array in the reference too) must not leak into contexts opened later."""
+    import ctypes as C
+    import time
+    B = A.binding(32)
+    x = (np.random.default_rng(2).random((3000, 2)) - 0.5).astype(np.float32)
+
+    def run(r):
+        r.advance(190)
+        return r.process(x, 4000, 48000 / 44100)[2]
+
+    t0 = time.perf_counter(); a = B.Resampler(2, 380, 380); t1 = time.perf_counter()
+    b = B.Resampler(2, 380, 380); t2 = time.perf_counter()
+    c = B.Resampler(2, 380, 380, 0.9)
+    assert np.array_equal(a.bank(), b.bank()) and not np.array_equal(a.bank(), c.bank())
+    ya = run(a)
+    a.close()                                              # b keeps the shared bank alive
+    yb = run(b)
+    assert np.array_equal(ya.view(np.uint32), yb.view(np.uint32))
+    assert not np.array_equal(run(c).view(np.uint32), yb.view(np.uint32))
+    row = np.ctypeslib.as_array(b.c.filters[5], shape=(380,)); row[:] = 0.0          # scribble on b's private host rows
+    d = B.Resampler(2, 380, 380)
+    assert np.array_equal(run(d).view(np.uint32), yb.view(np.uint32))
+    b.close(); c.close(); d.close()
+    e = B.Resampler(2, 380, 380)                            # last reference gone: rebuilt from scratch, same bank
+    assert np.array_equal(run(e).view(np.uint32), yb.view(np.uint32))
+    print(f"first init {1e3 * (t1 - t0):.2f} ms, second (shared bank) {1e3 * (t2 - t1):.2f} ms")
