@@ -116,15 +116,21 @@ constexpr unsigned int GEN_LIST_BLOCKS = 512;   // workgroups walking the fix li
 // lanes stride the taps, every lane feeds CG channels and both interpolation rows from one LDS read.
 // `from_list`: instead of tiling [n_begin, n_end), every workgroup evaluates single output frames whose
 // indices were handed back by the MFMA kernel (a.fix_list / *a.fix_count).
-template <int CG, bool INTERP, bool PRECISE>
+// G: lanes that share one output frame (64 = a whole wave, or 16: four output frames per wave side by side — the cross-lane
+// reduction and the per-output bookkeeping are then paid once per FOUR outputs, which is most of the cost when taps x
+// channels is small).  G depends on the tap count only, never on the tile, so a frame's value does not depend on how a
+// call is cut up.
+template <int CG, bool INTERP, bool PRECISE, int G>
 __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const ArtSegTable &segs, int tile, int from_list, unsigned int bx, unsigned int by)
 {
+    constexpr int SUBS = 64 / G;
     using Acc = typename std::conditional<PRECISE || ART_WIDE, double, float>::type;   // 8-byte samples accumulate in double
     extern __shared__ __attribute__ ((aligned (16))) art_s xs [];
     __shared__ int s_ip [GEN_MAX_TILE], s_fi [GEN_MAX_TILE];
     __shared__ double s_frac [GEN_MAX_TILE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane / G, l = lane % G;       // output within the wave, lane within the output's group
     const int ch0 = by * CG;
     const int half = a.T / 2;
     const unsigned int list_len = from_list ? min (*a.fix_count, a.fix_cap) : 1u;
@@ -164,7 +170,9 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
     }
     __syncthreads ();
 
-    for (int i = wave; i < cnt; i += GEN_THREADS / 64) {
+    for (int i0 = wave * SUBS; i0 < cnt; i0 += (GEN_THREADS / 64) * SUBS) {
+        const bool live = i0 + sub < cnt;                       // (a dead group recomputes the tile's last frame and drops it)
+        const int i = live ? i0 + sub : cnt - 1;
         const int ip = s_ip [i], fi = s_fi [i];
         const art_s *x = xs + (size_t)(ip - half + 1 - lin_lo) * CG;
         art_s result [CG];
@@ -184,7 +192,7 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
             // Taps are visited in mirrored pairs from the window edges towards the centre (as the
             // reference does): partial sums stay small until the dominant central taps arrive, which
             // keeps the float accumulation error at or below the reference's.
-            for (int p = lane; p < half; p += 64) {
+            for (int p = l; p < half; p += G) {
 #pragma unroll
                 for (int side = 0; side < 2; ++side) {
                     const int k = side ? a.T - 1 - p : p;
@@ -213,9 +221,10 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
                 if (INTERP) { part [2 * c] = (double) acc0 [c]; part [2 * c + 1] = (double) acc1 [c]; }
                 else part [c] = (double) acc0 [c];
             }
-            wave_reduce<NV> (part, lane);
+            reduce_level<NV, G / 2> (part, lane);
 
-            constexpr int GROUP = 64 / NV;                       // lanes holding the same reduced value
+            static_assert (NV <= G, "one lane group must hold every value");
+            constexpr int GROUP = G / NV;                        // lanes holding the same reduced value
             const double mine = part [0];
             const double frac = s_frac [i];
             art_s y;
@@ -229,8 +238,8 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
             else
                 y = (art_s) mine;
 
-            const int owner = INTERP ? (lane / GROUP) >> 1 : lane / GROUP;
-            const bool writer = (lane % GROUP) == 0 && (!INTERP || ((lane / GROUP) & 1) == 0);
+            const int owner = INTERP ? (l / GROUP) >> 1 : l / GROUP;
+            const bool writer = live && (l % GROUP) == 0 && (!INTERP || ((l / GROUP) & 1) == 0);
             if (writer && ch0 + owner < a.C) {
                 const size_t n = n0 + i;
                 if (a.out_pitch) a.out [(size_t)(ch0 + owner) * a.out_pitch + n] = y;
@@ -241,7 +250,7 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
 
 #pragma unroll
         for (int c = 0; c < CG; ++c)
-            if (lane == c && ch0 + c < a.C) {
+            if (live && l == c && ch0 + c < a.C) {
                 const size_t n = n0 + i;
                 if (a.out_pitch) a.out [(size_t)(ch0 + c) * a.out_pitch + n] = result [c];
                 else a.out [n * a.C + ch0 + c] = result [c];
@@ -250,12 +259,18 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
   }
 }
 
-template <int CG, bool INTERP, bool PRECISE>
+template <int CG, bool INTERP, bool PRECISE, int G>
 __global__ __launch_bounds__ (GEN_THREADS)
 void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile, int from_list)
 {
-    fir_general_body<CG, INTERP, PRECISE> (a, segs, tile, from_list, blockIdx.x, blockIdx.y);
+    fir_general_body<CG, INTERP, PRECISE, G> (a, segs, tile, from_list, blockIdx.x, blockIdx.y);
 }
+
+// lanes per output frame: 16 up to 256 taps, the whole wave above.  Measured (8 ch x 48 taps 15 -> 35 Gsamples/s, stereo x
+// 156 taps 7.7 -> 13.9); at 380 taps the gain shrinks to 8-30 % (stereo is bound by the filter rows coming out of L2) while
+// a 16-lane group walks 12 tap pairs instead of 3 — a 10 ms block's launch goes from 5 to 7 us — so presets -3 / -4 keep
+// the whole wave.
+__host__ __device__ constexpr int general_group (int taps) { return taps <= 256 ? 16 : 64; }
 
 // Many independent streams, one launch: blockIdx.z picks a stream's call (its arguments sit in a table in device memory,
 // exactly what the single-stream launch would have passed by value), x / y are that call's own grid.  Same body, same
@@ -268,7 +283,7 @@ struct FirBatchItem {
     int tile; unsigned int blocks_x, blocks_y; int pad;
 };
 
-template <int CG, bool INTERP, bool PRECISE>
+template <int CG, bool INTERP, bool PRECISE, int G>
 __global__ __launch_bounds__ (GEN_THREADS)
 void fir_general_batch_kernel (const FirBatchItem *items)
 {
@@ -281,7 +296,7 @@ void fir_general_batch_kernel (const FirBatchItem *items)
     }
     if (threadIdx.x == 0) { s_tab.count = it.seg_count; s_tab.lin_floor = it.lin_floor; }
     __syncthreads ();
-    fir_general_body<CG, INTERP, PRECISE> (it.a, s_tab, it.tile, 0, blockIdx.x, blockIdx.y);
+    fir_general_body<CG, INTERP, PRECISE, G> (it.a, s_tab, it.tile, 0, blockIdx.x, blockIdx.y);
 }
 
 // Strict kernel: one lane per output sample, taps visited in the reference's source order
@@ -1150,17 +1165,19 @@ int launch_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st
     if (!general_geometry<CG> (a, from_list, &tile, &lds, &grid)) return -1;
     const bool precise = (a.mode & 3) == ART_MODE_PRECISE;
 
-#define GO(I, P) do { auto k = fir_general_kernel<CG, I, P>; \
+#define GO(I, P) do { if (general_group (a.T) == 16) GO_ (I, P, 16); else GO_ (I, P, 64); } while (0)
+#define GO_(I, P, GG) do { auto k = fir_general_kernel<CG, I, P, GG>; \
         if (lds > 48 * 1024) (void) hipFuncSetAttribute ((const void *) k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
         hipLaunchKernelGGL (k, grid, dim3 (GEN_THREADS), lds, st, a, segs, tile, from_list); } while (0)
     if (a.interpolate) { if (precise) GO (true, true); else GO (true, false); }
     else               { if (precise) GO (false, true); else GO (false, false); }
 #undef GO
+#undef GO_
     return 0;
 }
 
 template <int CG>
-int batch_variant (const ArtFirArgs *a, const ArtSegTable *segs, const int *which, int count, bool interp, bool precise,
+int batch_variant (const ArtFirArgs *a, const ArtSegTable *segs, const int *which, int count, bool interp, bool precise, bool group16,
                           FirBatchItem *host, FirBatchItem *dev, hipStream_t st)
 {
     size_t lds_max = 0; unsigned int gx = 0, gy = 0;
@@ -1180,12 +1197,14 @@ int batch_variant (const ArtFirArgs *a, const ArtSegTable *segs, const int *whic
         if (grid.y > gy) gy = grid.y;
     }
     if (hipMemcpyAsync (dev, host, sizeof (FirBatchItem) * (size_t) count, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
-#define GOB(I, P) do { auto k = fir_general_batch_kernel<CG, I, P>; \
+#define GOB(I, P) do { if (group16) GOB_ (I, P, 16); else GOB_ (I, P, 64); } while (0)
+#define GOB_(I, P, GG) do { auto k = fir_general_batch_kernel<CG, I, P, GG>; \
         if (lds_max > 48 * 1024) (void) hipFuncSetAttribute ((const void *) k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_max); \
         hipLaunchKernelGGL (k, dim3 (gx, gy, (unsigned int) count), dim3 (GEN_THREADS), lds_max, st, (const FirBatchItem *) dev); } while (0)
     if (interp) { if (precise) GOB (true, true); else GOB (true, false); }
     else        { if (precise) GOB (false, true); else GOB (false, false); }
 #undef GOB
+#undef GOB_
     return hipGetLastError () == hipSuccess ? 0 : -1;
 }
 
@@ -1211,7 +1230,8 @@ static bool takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int
     const unsigned int total = a->n_end - a->n_begin;
     bool enough;
     if (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32) {
-        const double k_ns = (0.2 + 0.04 * a->C) + 0.00007 * a->C * a->T;
+        // (up to 256 taps the general kernel works four frames per wave: its per-frame cost roughly halves)
+        const double k_ns = ((0.2 + 0.04 * a->C) + 0.00007 * a->C * a->T) * (general_group (a->T) == 16 ? 0.47 : 1.0);
         const double chunks = (a->T + 63) / 32;
         const double floor_ns = 14000.0 + 1400.0 * chunks + (a->C <= 2 ? 6000.0 : 0.0) + (a->C == 2 ? 700.0 * chunks : 0.0);
         enough = total * k_ns >= floor_ns - 5000.0;
@@ -1224,7 +1244,7 @@ static bool takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int
 
 #else
     const unsigned int total = a->n_end - a->n_begin;
-    const double k_ns = (0.2 + 0.05 * a->C) + 0.00021 * a->C * a->T;
+    const double k_ns = ((0.2 + 0.05 * a->C) + 0.00021 * a->C * a->T) * (general_group (a->T) == 16 ? 0.55 : 1.0);
     const double floor_ns = 15000.0 + 4100.0 * ((a->T + 63) / 32);
     const bool enough = total * k_ns >= floor_ns - 5000.0;
     const bool small = (size_t) a->in_frames * a->C * 8 < 0x7fff0000ull && (size_t) a->H * a->C * 8 < 0x7fff0000ull &&
@@ -1269,21 +1289,22 @@ int arthip_fir_batch (const ArtFirArgs *a, const ArtSegTable *segs, int n, void 
     // group by kernel variant; each group takes its own slice of the table (the copies are asynchronous, the slices must
     // not be reused inside one call)
     for (int cgi = 0; cgi < 4 && !rc; ++cgi)
-        for (int v = 0; v < 4 && !rc; ++v) {
-            const bool interp = (v & 1) != 0, precise = (v & 2) != 0;
+        for (int v = 0; v < 8 && !rc; ++v) {
+            const bool interp = (v & 1) != 0, precise = (v & 2) != 0, group16 = (v & 4) != 0;
             int count = 0;
             for (int i = 0; i < n; ++i) {
                 const int cls = a [i].C > 4 ? 3 : a [i].C > 2 ? 2 : a [i].C == 2 ? 1 : 0;
-                if (cls == cgi && (a [i].interpolate != 0) == interp && (((a [i].mode & 3) == ART_MODE_PRECISE) == precise) && a [i].n_end > a [i].n_begin)
+                if (cls == cgi && (a [i].interpolate != 0) == interp && (((a [i].mode & 3) == ART_MODE_PRECISE) == precise) &&
+                    (general_group (a [i].T) == 16) == group16 && a [i].n_end > a [i].n_begin)
                     which [count++] = i;
             }
             if (!count) continue;
             FirBatchItem *hslice = host + done, *dslice = (FirBatchItem *) d_table + done;
             switch (cgi) {
-                case 3: rc = batch_variant<8> (a, segs, which, count, interp, precise, hslice, dslice, st); break;
-                case 2: rc = batch_variant<4> (a, segs, which, count, interp, precise, hslice, dslice, st); break;
-                case 1: rc = batch_variant<2> (a, segs, which, count, interp, precise, hslice, dslice, st); break;
-                default: rc = batch_variant<1> (a, segs, which, count, interp, precise, hslice, dslice, st); break;
+                case 3: rc = batch_variant<8> (a, segs, which, count, interp, precise, group16, hslice, dslice, st); break;
+                case 2: rc = batch_variant<4> (a, segs, which, count, interp, precise, group16, hslice, dslice, st); break;
+                case 1: rc = batch_variant<2> (a, segs, which, count, interp, precise, group16, hslice, dslice, st); break;
+                default: rc = batch_variant<1> (a, segs, which, count, interp, precise, group16, hslice, dslice, st); break;
             }
             done += count;
         }
