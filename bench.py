@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--channels", type=int, default=8, help="channels per GPU")
     ap.add_argument("--block-frames", type=int, default=1 << 20, help="input frames per call")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 general, 2 MFMA")
+    ap.add_argument("--preroll-ms", type=float, default=200.0, help="untimed device pre-roll before the warmup steps (clock ramp); 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -139,6 +140,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Device pre-roll (NOT part of the W warmup steps, never timed): MI355X raises its clocks over the first tens of
+    # milliseconds of sustained load — measured on this workload: 0.213 ms per kernel in the first 5 ms, 0.179 ms after
+    # 100 ms — so a K of a few dozen 0.2 ms steps would otherwise time the ramp, not the steady state the metric means.
+    # Reported in the JSON line ("preroll_ms"); --preroll-ms 0 disables it.
+    if args.preroll_ms > 0:
+        t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) * 1e3 < args.preroll_ms:
+            for _ in range(8):
+                rs.process_device(d_in, block, d_out, cap, ratio)
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         used, made = rs.process_device(d_in, block, d_out, cap, ratio)
         assert used == block and made < cap
@@ -182,7 +193,7 @@ def main():
             "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "preroll_ms": args.preroll_ms,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{Cn * world}-channel stream ({Cn} ch/GPU), 44100->48000 Hz, preset -4 = 988 filters x 988 taps "
                                    f"Blackman-Harris interpolating (artest -4 -c8), float32 interleaved, {block} input frames per call, "

@@ -17,6 +17,12 @@ BH, IN, LP = A.BLACKMAN_HARRIS, A.SUBSAMPLE_INTERPOLATE, A.INCLUDE_LOWPASS
 
 
 def timed(fn, steps):
+    # untimed pre-roll: the device reaches its steady-state clocks only after tens of milliseconds of load (see bench.py)
+    t_pre = time.perf_counter(); fn(); torch.cuda.synchronize()
+    if time.perf_counter() - t_pre < 0.005:                  # (the slow serial stages are their own pre-roll)
+        while time.perf_counter() - t_pre < 0.15:
+            for _ in range(4): fn()
+            torch.cuda.synchronize()
     for _ in range(2): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     n = 0

@@ -1,4 +1,5 @@
-"""Summarise rocprofv3 --pmc CSVs produced by tools/pmc.sh: for each kernel, the counters of its LONGEST dispatch."""
+"""Summarise rocprofv3 --pmc CSVs produced by tools/pmc.sh: for each kernel, the counters of its LAST dispatch (bench.py
+pre-rolls the device for 200 ms before its steps, so the last launches run at steady-state clocks; the first ones do not)."""
 import csv, glob, os, sys, collections
 d = sys.argv[1]
 best = {}
@@ -10,11 +11,11 @@ for f in sorted(glob.glob(os.path.join(d, "*counter_collection.csv"))):
         if not key: continue
         did = (key, row["Dispatch_Id"])
         rows[did][row["Counter_Name"]] = float(row["Counter_Value"])
-        rows[did]["_ns"] = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+        rows[did]["_ns"] = int(row["End_Timestamp"]) - int(row["Start_Timestamp"]); rows[did]["_id"] = int(row["Dispatch_Id"])
         rows[did]["_grid"] = row["Grid_Size"]; rows[did]["_vgpr"] = row["VGPR_Count"]; rows[did]["_lds"] = row["LDS_Block_Size"]
     for (key, did), c in rows.items():
         cur = best.setdefault((key, os.path.basename(f)), c)
-        if c["_ns"] > cur["_ns"]: best[(key, os.path.basename(f))] = c
+        if c["_id"] > cur["_id"]: best[(key, os.path.basename(f))] = c
 for (key, f), c in sorted(best.items()):
     print(f"== {key}  [{f}]  duration {c['_ns']/1e3:.1f} us  grid {c['_grid']} vgpr {c['_vgpr']} lds {c['_lds']}")
     for k, v in sorted(c.items()):
