@@ -397,6 +397,7 @@ constexpr int MF_MAX_PPW = 64;            // periods per workgroup (C = 2)
 // effective row: adjacent rows differ by < 3e-3 per tap, so the row changes by < 6e-9 relative (a tenth of
 // half a float ulp).  The reference's own position arithmetic is quantised to ~1e-7 steps after 1M frames.
 constexpr double MF_PHASE_TOL = 2e-6;
+constexpr int MF_PAIR_TAPS = 32, MF_QUAD_TAPS = 160;     // distance from the central band beyond which 2 / 4 chunks share a flush
 
 struct MfmaGeom {
     int P, Q;                             // outputs / inputs per period
@@ -479,7 +480,10 @@ void mfma_prepare_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
 // A tiles multiply the SAME X tile: X staging and barriers per MFMA halve and every matrix wave runs two
 // independent accumulator chains.
 template <bool INTERP, int CG, bool WS, int MT>
-__global__ __launch_bounds__ (WS ? 2 * MF_THREADS : MF_THREADS, (WS && MT == 1) ? 4 : 2)
+// (six waves per SIMD = three workgroups per CU for the shipped form: stated as waves per EU, which the register allocator
+// honours — 80 VGPRs, no spills — where the launch-bounds hint alone let it drift to 86; the stereo instantiation needs
+// those 86 and runs two workgroups per CU rather than spill)
+__global__ __launch_bounds__ (WS ? 2 * MF_THREADS : MF_THREADS) __attribute__ ((amdgpu_waves_per_eu ((WS && MT == 1) ? (CG == 2 ? 5 : 6) : 2)))
 void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
 {
     constexpr int THREADS = WS ? 2 * MF_THREADS : MF_THREADS;
@@ -790,6 +794,75 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
             return;
         }
         __syncthreads ();
+        if (MT == 1 && CG != 2) {                   // (the stereo instantiation spills four registers in this form and loses 5-9 %: it keeps the plain loop)
+            // Every fp64 flush is vector-unit work that takes issue slots from the matrix pipe, and far from the central
+            // band the partial sums are tiny: there FOUR chunks (beyond MF_QUAD_TAPS from the band) or TWO (beyond
+            // MF_PAIR_TAPS) share one f32 accumulator before it is flushed; near the band one chunk per flush, inside it
+            // a flush every 4 k.  The K range is walked by plain loops with ONE shape of body each — the compiler
+            // allocates registers per loop, and any mixed-shape loop went over the 80 registers (§7).  Error probe
+            // (tools/err_probe.py: full-scale DC, square, sines, noise): worst case and rms unchanged.
+            const int lo_band = g.band_lo / MF_KC, hi_band = (g.band_hi + MF_KC - 1) / MF_KC;      // band chunks [lo_band, hi_band)
+            int near_lo = lo_band - MF_PAIR_TAPS / MF_KC, near_hi = hi_band + MF_PAIR_TAPS / MF_KC;         // single-flush chunks around it
+            if (near_lo < 0) near_lo = 0;
+            if (near_hi > nchunks) near_hi = nchunks;
+            near_lo &= ~1;                                                                        // pairs start on even chunks
+            auto mfma16 = [&] (auto fresh_tag, f32x16 &acc, int buf) {
+                const float *As = As_ [buf], *Bs = Bs_ [buf];
+#pragma unroll
+                for (int grp = 0; grp < MF_KC / 8; ++grp) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4 *> (&Bs [brow + grp * 8]);
+                    const f32x4 av = *reinterpret_cast<const f32x4 *> (&As [arow + grp * 8]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (decltype (fresh_tag)::value && grp == 0 && q == 0) {
+                            f32x16 z;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) z [r] = 0.0f;
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [q], bv [q], z, 0, 0, 0);
+                        }
+                        else acc = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [q], bv [q], acc, 0, 0, 0);
+                    }
+                    if (grp == 1) __builtin_amdgcn_sched_barrier (0);       // operands of two groups at a time (registers)
+                }
+            };
+            auto runs = [&] (auto n_tag, int from, int to) {        // [from, to): a multiple of N chunks, from even; N chunks per flush
+                constexpr int N = decltype (n_tag)::value;
+                for (int chunk = from; chunk < to; chunk += N) {
+                    f32x16 acc;
+                    mfma16 (std::true_type {}, acc, 0);
+#pragma unroll
+                    for (int q = 1; q < N; ++q) {
+                        __syncthreads ();
+                        mfma16 (std::false_type {}, acc, q & 1);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sum [0] [r] = sum [0] [r] + (double) acc [r];
+                    __syncthreads ();
+                }
+            };
+            auto singles = [&] (int from, int to) {
+                for (int chunk = from; chunk < to; ++chunk) { matrix_chunk (chunk, chunk & 1); __syncthreads (); }
+            };
+            const std::integral_constant<int, 2> two; const std::integral_constant<int, 4> four;
+            // left of the band: quads while at least MF_QUAD_TAPS taps away, then pairs, then singles into and through the band
+            int quad_lo = (lo_band - MF_QUAD_TAPS / MF_KC) & ~3;  if (quad_lo < 0) quad_lo = 0;  if (quad_lo > near_lo) quad_lo = near_lo & ~3;
+            runs (four, 0, quad_lo);
+            runs (two, quad_lo, quad_lo + ((near_lo - quad_lo) & ~1));
+            const int tail_from = near_hi + (near_hi & 1);
+            singles (quad_lo + ((near_lo - quad_lo) & ~1), tail_from < nchunks ? tail_from : nchunks);
+            if (tail_from < nchunks) {
+                // right of it: pairs up to MF_QUAD_TAPS taps away, quads beyond, whatever is left one by one
+                int quad_from = hi_band + MF_QUAD_TAPS / MF_KC;  quad_from += quad_from & 1;  if (quad_from < tail_from) quad_from = tail_from;
+                if (quad_from > nchunks) quad_from = tail_from + ((nchunks - tail_from) & ~1);
+                runs (two, tail_from, quad_from);
+                const int quad_to = quad_from + ((nchunks - quad_from) & ~3);
+                runs (four, quad_from, quad_to);
+                const int pair_to = quad_to + ((nchunks - quad_to) & ~1);
+                runs (two, quad_to, pair_to);
+                singles (pair_to, nchunks);
+            }
+        }
+        else
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             matrix_chunk (chunk, chunk & 1);
             __syncthreads ();
