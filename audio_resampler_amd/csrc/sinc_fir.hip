@@ -397,6 +397,7 @@ constexpr int MF_MAX_PPW = 64;            // periods per workgroup (C = 2)
 // effective row: adjacent rows differ by < 3e-3 per tap, so the row changes by < 6e-9 relative (a tenth of
 // half a float ulp).  The reference's own position arithmetic is quantised to ~1e-7 steps after 1M frames.
 constexpr double MF_PHASE_TOL = 2e-6;
+constexpr int MF_HEAD_PAD = 64;
 constexpr int MF_PAIR_TAPS = 32, MF_QUAD_TAPS = 160;     // distance from the central band beyond which 2 / 4 chunks share a flush
 
 struct MfmaGeom {
@@ -413,6 +414,9 @@ struct MfmaGeom {
     float *eff;                           // [slot_tiles*tile_rows][ktot]  blended rows, shifted to the tile's K origin, zero padded
     int *canon_ip, *canon_fi;             // [slot_tiles*tile_rows]        canonical position of each slot (period 0 of the launch)
     double *canon_frac;                 // K columns [band_lo, band_hi) hold every row's central taps
+    // the head of the call as ONE contiguous array (history ++ first input frames, MF_HEAD_PAD zero frames in front): tiles that
+    // reach into the history stage from it exactly as all others stage from `in` (written by mfma_prepare_kernel)
+    float *head; int head_frames;
 };
 
 typedef unsigned int u32x4 __attribute__ ((ext_vector_type (4)));
@@ -468,6 +472,18 @@ void mfma_prepare_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
         }
         dst [k] = c;
     }
+    // the call's head, gathered by the whole grid: linear frame lin = index - MF_HEAD_PAD; history below H, input above
+    if (g.head) {
+        const int blocks = gridDim.x * gridDim.y, me = blockIdx.y * gridDim.x + blockIdx.x;
+        const long total = (long) g.head_frames * a.C;
+        for (long e = (long) me * 256 + tid; e < total; e += (long) blocks * 256) {
+            const int f = (int)(e / a.C), c = (int)(e - (long) f * a.C), lin = f - MF_HEAD_PAD;
+            float v = 0.0f;
+            if (lin >= 0 && lin < a.H) v = a.hist [(size_t) lin * a.C + c];
+            else if (lin >= a.H && lin - a.H < a.in_frames) v = a.in [(size_t)(lin - a.H) * a.C + c];
+            g.head [e] = v;
+        }
+    }
 }
 
 // CG > 0: the stream has exactly CG channels (compile-time index math, vector loads);  CG == 0: any count.
@@ -483,7 +499,7 @@ template <bool INTERP, int CG, bool WS, int MT>
 // (six waves per SIMD = three workgroups per CU for the shipped form: stated as waves per EU, which the register allocator
 // honours — 80 VGPRs, no spills — where the launch-bounds hint alone let it drift to 86; the stereo instantiation needs
 // those 86 and runs two workgroups per CU rather than spill)
-__global__ __launch_bounds__ (WS ? 2 * MF_THREADS : MF_THREADS) __attribute__ ((amdgpu_waves_per_eu ((WS && MT == 1) ? (CG == 2 ? 5 : 6) : 2)))
+__global__ __launch_bounds__ (WS ? 2 * MF_THREADS : MF_THREADS) __attribute__ ((amdgpu_waves_per_eu ((WS && MT == 1) ? 6 : 2)))
 void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
 {
     constexpr int THREADS = WS ? 2 * MF_THREADS : MF_THREADS;
@@ -734,22 +750,24 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
         // two separate loops (disjoint live ranges => registers = max of the two roles, not the sum);
         // both execute exactly nchunks + 1 barriers
         if (loader) {
-            if (CG && MT == 1 && !touches_hist) {
+            if constexpr (CG != 0 && MT == 1) {
                 // No vector arithmetic per chunk (measured +10 %: vector-unit instructions of ANY wave on a SIMD take issue
                 // slots from its matrix pipe): every thread's offsets and LDS addresses are fixed, the chunk moves the
                 // resource BASES (scalar unit; the range check moves with them, so past-the-end reads stay 0), and the
-                // loop is unrolled by the two LDS buffers so their addresses are immediates.  Tiles that reach into the
-                // history buffer (first period group of a call) keep the general loop below.
+                // loop is unrolled by the two LDS buffers so their addresses are immediates.
                 constexpr unsigned int A_STEP = MF_KC * 4u, B_STEP = MF_KC * CG * 4u;
-                const unsigned int a_bytes = (unsigned int)((size_t) ROWS * g.ktot * 4), b_bytes = (unsigned int)((size_t) a.in_frames * a.C * 4);
+                // tiles that reach into the history read the call's contiguous head instead of `in` (same loop, other base)
+                const int origin = touches_hist ? -MF_HEAD_PAD : a.H;                  // linear index of the base's first frame
+                const unsigned int a_bytes = (unsigned int)((size_t) ROWS * g.ktot * 4);
+                const unsigned int b_bytes = touches_hist ? (unsigned int)((size_t) g.head_frames * a.C * 4) : (unsigned int)((size_t) a.in_frames * a.C * 4);
                 const char *a_base = reinterpret_cast<const char *> (g.eff + (size_t) st * ROWS * g.ktot);
-                const char *b_base = reinterpret_cast<const char *> (a.in);
+                const char *b_base = touches_hist ? reinterpret_cast<const char *> (g.head) : reinterpret_cast<const char *> (a.in);
                 unsigned int boff [NB]; int bdst [NB];
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
                     const int v = pt + u * MF_THREADS;
                     const int jl = v / VPP, rem = v % VPP, kk = rem / VPF, cv = rem % VPF;
-                    boff [u] = (unsigned int)((w0 + jl * g.Q + kk - a.H) * CG + cv * VEC) * 4u;     // >= 0: the tile is past the history
+                    boff [u] = (unsigned int)(max (w0 + jl * g.Q + kk - origin, 0) * CG + cv * VEC) * 4u;
                     bdst [u] = (jl * CG + cv * VEC) * MF_LD + kk;
                 }
                 const int adst = a_row * MF_LD + a_kseg;
@@ -781,20 +799,22 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
                 }
                 return;
             }
-            // one register stage (a second one in flight — commit chunk c+1 while c+2 lands — measured within noise, +1.4 %)
-            fetch (0, ra0, rb0); commit (0, 0, ra0, rb0); fetch (1, ra0, rb0);
-            __syncthreads ();
-            for (int chunk = 0; chunk < nchunks; ++chunk) {
-#ifndef ABL_NOLOAD
-                commit (chunk + 1, (chunk & 1) ^ 1, ra0, rb0);       // past-the-end chunks: loads return 0 / LDS unread
-                fetch (chunk + 2, ra0, rb0);
-#endif
+            else {
+                // (the two-m-tile experiment, kernel preference 4: the general staging code, one register stage)
+                fetch (0, ra0, rb0); commit (0, 0, ra0, rb0); fetch (1, ra0, rb0);
                 __syncthreads ();
+                for (int chunk = 0; chunk < nchunks; ++chunk) {
+#ifndef ABL_NOLOAD
+                    commit (chunk + 1, (chunk & 1) ^ 1, ra0, rb0);       // past-the-end chunks: loads return 0 / LDS unread
+                    fetch (chunk + 2, ra0, rb0);
+#endif
+                    __syncthreads ();
+                }
+                return;
             }
-            return;
         }
         __syncthreads ();
-        if (MT == 1 && CG != 2) {                   // (the stereo instantiation spills four registers in this form and loses 5-9 %: it keeps the plain loop)
+        if (MT == 1) {
             // Every fp64 flush is vector-unit work that takes issue slots from the matrix pipe, and far from the central
             // band the partial sums are tiny: there FOUR chunks (beyond MF_QUAD_TAPS from the band) or TWO (beyond
             // MF_PAIR_TAPS) share one f32 accumulator before it is flushed; near the band one chunk per flush, inside it
@@ -1306,7 +1326,7 @@ static bool takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int
         // (up to 256 taps the general kernel works four frames per wave: its per-frame cost roughly halves)
         const double k_ns = ((0.2 + 0.04 * a->C) + 0.00007 * a->C * a->T) * (general_group (a->T) == 16 ? 0.47 : 1.0);
         const double chunks = (a->T + 63) / 32;
-        const double floor_ns = 14000.0 + 1400.0 * chunks + (a->C <= 2 ? 6000.0 : 0.0) + (a->C == 2 ? 700.0 * chunks : 0.0);
+        const double floor_ns = 13500.0 + 550.0 * chunks + (a->C <= 2 ? 2000.0 : 0.0);
         enough = total * k_ns >= floor_ns - 5000.0;
     }
     else
@@ -1408,8 +1428,8 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
     // to beat the general kernel.  Cost models fitted to MI355X measurements (tools/bench_small_taps.py,
     // profiles/r1_small_calls.txt), n = output frames of the launch:
     //     general   ~ 5 us + n * k,    k = (0.2 + 0.04 C) + 0.00007 C T  ns per frame
-    //     MFMA      ~ max (floor, work-bound),   floor = 14 us + 1.4 us per 32-tap chunk  (+ 6 us, and 2.1 us per chunk
-    //                                             for C = 2: with <= 2 channels a workgroup replays 64 periods of positions)
+    //     MFMA      ~ max (floor, work-bound),   floor = 13.5 us + 0.55 us per 32-tap chunk (+ 2 us for C <= 2) — since every tile,
+    //                                             also those at the history seam, stages through the same loop (was 14 + 1.4)
     // The MFMA path is taken when the general kernel would take longer than the floor.  For channel counts without a
     // compiled column group the older rule stays: outputs x channels x taps of at least 1.2e8.
     const unsigned int total = a->n_end - a->n_begin;
@@ -1446,6 +1466,15 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
             g.canon_ip = (int *)(g.canon_frac + rows);
             g.canon_fi = g.canon_ip + rows;
             if (!base || (size_t)((char *)(g.canon_fi + rows) - base) > a->scratch_bytes) goto general_path;
+            g.head = nullptr; g.head_frames = 0;
+            if (ws && !wide) {
+                // the call's head as one contiguous array: everything a tile whose window starts inside the history can read
+                // (+ the two chunks the staging runs ahead)
+                const size_t used = (((size_t)((char *)(g.canon_fi + rows) - base)) + 255) & ~(size_t) 255;
+                g.head_frames = MF_HEAD_PAD + a->H + (g.ppw - 1) * g.Q + g.ktot + 3 * MF_KC;
+                if (used + (size_t) g.head_frames * a->C * sizeof (float) > a->scratch_bytes) goto general_path;
+                g.head = (float *)(base + used);
+            }
         }
         dim3 grid ((unsigned int)(8 * g.groups_per_xcd * g.slot_tiles), (unsigned int)((a->C + g.cg - 1) / g.cg));
 
