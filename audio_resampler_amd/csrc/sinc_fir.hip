@@ -956,6 +956,7 @@ constexpr int MW_COLS = 128;
 constexpr int MW_ROWS = 32;               // slots per workgroup
 constexpr int MW_MAX_PPW = 64;
 
+constexpr int MW_HEAD_PAD = 64;
 struct WideGeom {
     int P, Q;
     int slot_tiles;                       // ceil (P / 32)
@@ -964,6 +965,7 @@ struct WideGeom {
     int period_groups, groups_per_xcd;
     double *rows;                         // [slot_tiles][nrows][ktot]  filter rows shifted to the tile's K origin, zero padded
     int *canon_ip, *canon_fi;             // [slot_tiles*32]  canonical position of each slot (period 0 of the launch)
+    double *head; int head_frames;        // the call's head as one array (history ++ first input frames, MW_HEAD_PAD zero frames in front)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wide_rsrc (const void *base, size_t bytes)
@@ -994,6 +996,16 @@ void wide_prepare_kernel (ArtFirArgs a, ArtSegTable segs, WideGeom g)
         const bool in = tap >= 0 && tap < a.T;
         d0 [k] = in ? h0 [tap] : 0.0;
         if (INTERP) d1 [k] = in ? h0 [tap + a.T] : 0.0;
+    }
+    // the call's head, gathered by the whole grid (see mfma_prepare_kernel)
+    const int blocks = gridDim.x * gridDim.y, me = blockIdx.y * gridDim.x + blockIdx.x;
+    const long total = (long) g.head_frames * a.C;
+    for (long e = (long) me * 256 + tid; e < total; e += (long) blocks * 256) {
+        const int f = (int)(e / a.C), c = (int)(e - (long) f * a.C), lin = f - MW_HEAD_PAD;
+        double v = 0.0;
+        if (lin >= 0 && lin < a.H) v = a.hist [(size_t) lin * a.C + c];
+        else if (lin >= a.H && lin - a.H < a.in_frames) v = a.in [(size_t)(lin - a.H) * a.C + c];
+        g.head [e] = v;
     }
 }
 
@@ -1047,56 +1059,26 @@ void fir_mfma64_kernel (ArtFirArgs a, ArtSegTable segs, WideGeom g)
         s_status [e] = status;
     }
 
-    // ---- staging plan: raw buffer loads, everything out of range reads as 0
-    const __amdgpu_buffer_rsrc_t rs_in = wide_rsrc (a.in, (size_t) a.in_frames * CG * 8);
-    const __amdgpu_buffer_rsrc_t rs_hist = wide_rsrc (a.hist, (size_t) a.H * CG * 8);
-    const __amdgpu_buffer_rsrc_t rs_rows = wide_rsrc (g.rows + (size_t) st * NROWS * g.ktot, (size_t) NROWS * g.ktot * 8);
+    // ---- staging plan: raw buffer loads, everything out of range reads as 0.  Fixed per-thread offsets; the chunk moves the
+    // resource bases on the scalar unit — no vector arithmetic per chunk beside the matrix pipe (see fir_mfma_kernel).  A tile
+    // whose window starts inside the history stages from the call's contiguous head (wide_prepare_kernel), all others from `in`.
     const bool touches_hist = w0 < a.H;
-    // A: thread -> (row, 2 consecutive k), NROWS/32 vectors per thread
+    const int origin = touches_hist ? -MW_HEAD_PAD : a.H;                      // linear index of the base's first frame
     constexpr int NA = NROWS / 32;
     const int a_row = tid >> 3, a_kseg = (tid & 7) * 2;
-    // B: thread -> NB vectors of VEC channels of one frame of one period
     constexpr int VEC = CG >= 2 ? 2 : 1;
     constexpr int VPF = CG / VEC, VPP = MW_KC * VPF;
     constexpr int NB = (PPW * VPP) / MW_THREADS;
     static_assert ((PPW * VPP) % MW_THREADS == 0, "staging plan");
+    static_assert (MW_THREADS % VPP == 0, "per-vector period step must be uniform");
 
     double ra [NA * 2], rb [NB * VEC];
-    auto fetch = [&] (int chunk) {
-        const int k0 = chunk * MW_KC;
-#pragma unroll
-        for (int m = 0; m < NA; ++m) {
-            const w_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128 (rs_rows, (int)(((m * 32 + a_row) * g.ktot + k0 + a_kseg) * 8), 0, 0);
-            ra [m * 2] = u2d (v.x, v.y); ra [m * 2 + 1] = u2d (v.z, v.w);
-        }
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            const int v = tid + u * MW_THREADS;
-            const int jl = v / VPP, rem = v % VPP, kk = rem / VPF, cv = rem % VPF;
-            const int lin = w0 + jl * g.Q + k0 + kk;
-            // below H the frame lives in the history buffer: force the `in` offset out of range by a select rather than
-            // by letting a negative number wrap (see the single-precision kernel)
-            const int oi = lin >= a.H ? ((lin - a.H) * CG + cv * VEC) * 8 : (int) 0xfffffff0u;
-            const int oh = (lin >= 0 && lin < a.H) ? (lin * CG + cv * VEC) * 8 : (int) 0xfffffff0u;
-            if (VEC == 2) {
-                w_u32x4 x = __builtin_amdgcn_raw_buffer_load_b128 (rs_in, oi, 0, 0);
-                if (touches_hist) { const w_u32x4 h = __builtin_amdgcn_raw_buffer_load_b128 (rs_hist, oh, 0, 0); x |= h; }
-                rb [u * VEC] = u2d (x.x, x.y); rb [u * VEC + (VEC - 1)] = u2d (x.z, x.w);
-            }
-            else {
-                w_u32x2 x = __builtin_amdgcn_raw_buffer_load_b64 (rs_in, oi, 0, 0);
-                if (touches_hist) { const w_u32x2 h = __builtin_amdgcn_raw_buffer_load_b64 (rs_hist, oh, 0, 0); x |= h; }
-                rb [u * VEC] = u2d (x.x, x.y);
-            }
-        }
-    };
-    // Tiles past the history buffer (all but the first period group of a call): fixed per-thread offsets, the chunk moves
-    // the resource bases on the scalar unit — no vector arithmetic per chunk beside the matrix pipe (see fir_mfma_kernel)
-    const unsigned int rows_bytes = (unsigned int)((size_t) NROWS * g.ktot * 8), in_bytes = (unsigned int)((size_t) a.in_frames * CG * 8);
+    const unsigned int rows_bytes = (unsigned int)((size_t) NROWS * g.ktot * 8);
+    const unsigned int in_bytes = touches_hist ? (unsigned int)((size_t) g.head_frames * CG * 8) : (unsigned int)((size_t) a.in_frames * CG * 8);
     const char *rows_base = reinterpret_cast<const char *> (g.rows + (size_t) st * NROWS * g.ktot);
-    static_assert (MW_THREADS % VPP == 0, "per-vector period step must be uniform");
+    const char *in_base = touches_hist ? reinterpret_cast<const char *> (g.head) : reinterpret_cast<const char *> (a.in);
     const int aoff = (a_row * g.ktot + a_kseg) * 8;          // vector u / row tile m differ from the first by a UNIFORM step: scalar too
-    const int boff = ((w0 + (tid / VPP) * g.Q + (tid % VPP) / VPF - a.H) * CG + ((tid % VPP) % VPF) * VEC) * 8;
+    const int boff = (max (w0 + (tid / VPP) * g.Q + (tid % VPP) / VPF - origin, 0) * CG + ((tid % VPP) % VPF) * VEC) * 8;
     auto lean_fetch = [&] (int chunk) {
 #pragma unroll
         for (int m = 0; m < NA; ++m) {
@@ -1107,7 +1089,7 @@ void fir_mfma64_kernel (ArtFirArgs a, ArtSegTable segs, WideGeom g)
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             const unsigned int sb = min ((unsigned int) chunk * (MW_KC * CG * 8u) + (unsigned int)(u * (MW_THREADS / VPP) * g.Q) * (CG * 8u), in_bytes);
-            const __amdgpu_buffer_rsrc_t r_in = wide_rsrc (reinterpret_cast<const char *> (a.in) + sb, in_bytes - sb);
+            const __amdgpu_buffer_rsrc_t r_in = wide_rsrc (in_base + sb, in_bytes - sb);
             if (VEC == 2) {
                 const w_u32x4 x = __builtin_amdgcn_raw_buffer_load_b128 (r_in, boff, 0, 0);
                 rb [u * VEC] = u2d (x.x, x.y); rb [u * VEC + (VEC - 1)] = u2d (x.z, x.w);
@@ -1145,12 +1127,12 @@ void fir_mfma64_kernel (ArtFirArgs a, ArtSegTable segs, WideGeom g)
 
     const int nchunks = g.ktot / MW_KC;
     const int frag = (lane & 15) * MW_LD + 2 * (lane >> 4);      // this lane's (row | column, k pair) inside a 16-wide tile
-    if (touches_hist) fetch (0); else lean_fetch (0);
+    lean_fetch (0);
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         __syncthreads ();                                    // previous chunk fully consumed (first pass: status table complete)
         commit ();
         __syncthreads ();
-        if (chunk + 1 < nchunks) { if (touches_hist) fetch (chunk + 1); else lean_fetch (chunk + 1); }    // global loads fly while the matrix cores work
+        if (chunk + 1 < nchunks) lean_fetch (chunk + 1);     // global loads fly while the matrix cores work
 #pragma unroll
         for (int grp = 0; grp < MW_KC / 8; ++grp) {
             f64x2 av [RT], bv [2];
@@ -1522,8 +1504,11 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
             g.rows = (double *) base;
             g.canon_ip = (int *)(base + ((row_bytes + 15) & ~(size_t) 15));
             g.canon_fi = g.canon_ip + (size_t) g.slot_tiles * MW_ROWS;
-            if (base && (size_t)((char *)(g.canon_fi + (size_t) g.slot_tiles * MW_ROWS) - base) <= a->scratch_bytes &&
-                (size_t) g.nrows * g.ktot * 8 < 0x7fff0000ull) {
+            const size_t used = (((size_t)((char *)(g.canon_fi + (size_t) g.slot_tiles * MW_ROWS) - base)) + 255) & ~(size_t) 255;
+            g.head_frames = MW_HEAD_PAD + a->H + (ppw - 1) * g.Q + g.ktot + 3 * MW_KC;
+            g.head = (double *)(base + used);
+            if (base && used + (size_t) g.head_frames * a->C * sizeof (double) <= a->scratch_bytes &&
+                (size_t) g.head_frames * a->C * 8 < 0x7fff0000ull && (size_t) g.nrows * g.ktot * 8 < 0x7fff0000ull) {
                 const dim3 grid ((unsigned int)(8 * g.groups_per_xcd * g.slot_tiles));
                 if (a->interpolate) hipLaunchKernelGGL (wide_prepare_kernel<true>, dim3 (g.slot_tiles, MW_ROWS), dim3 (256), 0, st, *a, *segs, g);
                 else hipLaunchKernelGGL (wide_prepare_kernel<false>, dim3 (g.slot_tiles, MW_ROWS), dim3 (256), 0, st, *a, *segs, g);
