@@ -714,12 +714,13 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
             a.fix_count = a.fix_list = NULL; a.scratch = NULL; a.scratch_bytes = 0; a.n_begin = a.n_end = 0;
         }
         if (matrix_sized) {
-            /* [0] per-launch count, [1] running total (diagnostics), [2..] the list */
-            if (sizeof (unsigned int) * ((size_t) res.output_generated + 2) > hip->fix_cap) {
-                hip->d_fix = grow (hip->d_fix, &hip->fix_cap, sizeof (unsigned int) * ((size_t) res.output_generated + 2));
+            /* [0] per-launch count, [1] running total of outputs the matrix kernels evaluated off their canonical pattern
+             * (diagnostics only: they are computed inside the kernel) */
+            if (!hip->d_fix) {
+                hip->d_fix = grow (hip->d_fix, &hip->fix_cap, 64);
                 if (hip->d_fix) arthip_zero (hip->d_fix, 2 * sizeof (unsigned int), hip->stream);
             }
-            if (hip->d_fix) { a.fix_count = hip->d_fix; a.fix_list = hip->d_fix + 2; a.fix_cap = res.output_generated; }
+            if (hip->d_fix) { a.fix_count = hip->d_fix; a.fix_list = hip->d_fix + 2; a.fix_cap = 0; }
             if (!hip->d_scratch) hip->d_scratch = grow (hip->d_scratch, &hip->scratch_cap, (size_t) 8 << 20);
             a.scratch = hip->d_scratch; a.scratch_bytes = hip->d_scratch ? hip->scratch_cap : 0;
         }

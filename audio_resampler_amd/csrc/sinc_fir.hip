@@ -69,6 +69,28 @@ __device__ __forceinline__ Pos locate (const ArtFirArgs &a, const ArtSegTable &s
     return p;
 }
 
+// One output sample evaluated by ONE lane, fp64 accumulation, the reference's lerp: what the matrix-core kernels do with
+// an output whose exact position is not its slot's canonical one (rare — a phase on a filter boundary that rounds the other
+// way): cheaper than a follow-up launch for a list that is almost always empty.
+template <bool INTERP>
+__device__ __forceinline__ art_s direct_sample (const ArtFirArgs &a, int lin_floor, Pos p, int ch)
+{
+    const int half = a.T / 2, w = p.ip - half + 1;
+    if (!INTERP && !a.lowpass && (p.fi % a.F) == 0) return load_frame (a, lin_floor, w + half - 1 + p.fi / a.F, ch);
+    const art_s *h0 = a.bank + (size_t) p.fi * a.T;
+    double s0 = 0.0, s1 = 0.0;
+    for (int q = 0; q < half; ++q)                            // mirrored pairs from the edges inwards, as everywhere
+        for (int side = 0; side < 2; ++side) {
+            const int k = side ? a.T - 1 - q : q;
+            const double v = (double) load_frame (a, lin_floor, w + k, ch);
+            s0 = s0 + (double) h0 [k] * v;
+            if (INTERP) s1 = s1 + (double) h0 [k + a.T] * v;
+        }
+    if (!INTERP) return (art_s) s0;
+    const double left = s0 * (1.0 - p.frac), right = s1 * p.frac;
+    return (art_s)(left + right);
+}
+
 // Cross-lane reduction of NV per-lane partial sums, carried out in fp64 so that the handful of
 // large-magnitude additions near the root of the tree do not each cost half a float ulp.
 // Halving butterfly: at every level half of the values change hands, so NV values cost
@@ -109,19 +131,16 @@ __attribute__ ((unused)) __device__ __forceinline__ double fused (double a, doub
 
 constexpr int GEN_THREADS = 256;
 constexpr int GEN_MAX_TILE = 32;
-constexpr unsigned int GEN_LIST_BLOCKS = 512;   // workgroups walking the fix list in list mode
 
 // General kernel: one workgroup per tile of consecutive output frames; the tile's input span is
 // staged once in LDS (coalesced frame-major reads), then each wave evaluates whole output frames:
 // lanes stride the taps, every lane feeds CG channels and both interpolation rows from one LDS read.
-// `from_list`: instead of tiling [n_begin, n_end), every workgroup evaluates single output frames whose
-// indices were handed back by the MFMA kernel (a.fix_list / *a.fix_count).
 // G: lanes that share one output frame (64 = a whole wave, or 16: four output frames per wave side by side — the cross-lane
 // reduction and the per-output bookkeeping are then paid once per FOUR outputs, which is most of the cost when taps x
 // channels is small).  G depends on the tap count only, never on the tile, so a frame's value does not depend on how a
 // call is cut up.
 template <int CG, bool INTERP, bool PRECISE, int G>
-__device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const ArtSegTable &segs, int tile, int from_list, unsigned int bx, unsigned int by)
+__device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const ArtSegTable &segs, int tile, unsigned int bx, unsigned int by)
 {
     constexpr int SUBS = 64 / G;
     using Acc = typename std::conditional<PRECISE || ART_WIDE, double, float>::type;   // 8-byte samples accumulate in double
@@ -133,11 +152,10 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
     const int sub = lane / G, l = lane % G;       // output within the wave, lane within the output's group
     const int ch0 = by * CG;
     const int half = a.T / 2;
-    const unsigned int list_len = from_list ? min (*a.fix_count, a.fix_cap) : 1u;
-    // Blocks [0, workers) evaluate outputs (list mode: GEN_LIST_BLOCKS walkers of the fix list; else one tile each); any
+    // Blocks [0, workers) evaluate one tile of outputs each; any
     // further blocks (x only, y == 0) roll the history for the next call (reads hist ++ in, writes the OTHER history
     // buffer: independent of everything else in flight) — one launch less per call.
-    const unsigned int workers = from_list ? GEN_LIST_BLOCKS : (a.n_end - a.n_begin + (unsigned int) tile - 1) / (unsigned int) tile;
+    const unsigned int workers = (a.n_end - a.n_begin + (unsigned int) tile - 1) / (unsigned int) tile;
     if (bx >= workers) {
         if (by) return;
         const int e = (int)(bx - workers) * GEN_THREADS + tid;
@@ -150,11 +168,11 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
         }
         return;
     }
-  for (unsigned int item = bx; item < (from_list ? list_len : workers); item += workers) {
-    const unsigned int n0 = from_list ? a.fix_list [item] : a.n_begin + item * (unsigned int) tile;
-    const int cnt = from_list ? 1 : (int) min ((unsigned int) tile, a.n_end - n0);
+  {
+    const unsigned int n0 = a.n_begin + bx * (unsigned int) tile;
+    const int cnt = (int) min ((unsigned int) tile, a.n_end - n0);
 
-    __syncthreads ();                       // LDS reuse across list items
+    __syncthreads ();
     if (tid < cnt) {
         Pos p = locate<INTERP> (a, segs, n0 + tid);
         s_ip [tid] = p.ip; s_fi [tid] = p.fi; s_frac [tid] = p.frac;
@@ -261,9 +279,9 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
 
 template <int CG, bool INTERP, bool PRECISE, int G>
 __global__ __launch_bounds__ (GEN_THREADS)
-void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile, int from_list)
+void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile)
 {
-    fir_general_body<CG, INTERP, PRECISE, G> (a, segs, tile, from_list, blockIdx.x, blockIdx.y);
+    fir_general_body<CG, INTERP, PRECISE, G> (a, segs, tile, blockIdx.x, blockIdx.y);
 }
 
 // lanes per output frame: 16 up to 256 taps, the whole wave above.  Measured (8 ch x 48 taps 15 -> 35 Gsamples/s, stereo x
@@ -296,7 +314,7 @@ void fir_general_batch_kernel (const FirBatchItem *items)
     }
     if (threadIdx.x == 0) { s_tab.count = it.seg_count; s_tab.lin_floor = it.lin_floor; }
     __syncthreads ();
-    fir_general_body<CG, INTERP, PRECISE, G> (it.a, s_tab, it.tile, 0, blockIdx.x, blockIdx.y);
+    fir_general_body<CG, INTERP, PRECISE, G> (it.a, s_tab, it.tile, blockIdx.x, blockIdx.y);
 }
 
 // Strict kernel: one lane per output sample, taps visited in the reference's source order
@@ -520,6 +538,22 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
     // holds ~2 MB of input + the phase rows instead of seeing the whole call (measured before the remap:
     // 46 % L2 misses, 16x the algorithmic bytes fetched from the fabric; after: 4 % and 1.6x).
     // Placement only affects speed.
+    // Workgroups past the tile grid (x only, y == 0) roll the history for the next call — reads hist ++ in, writes the OTHER
+    // history buffer: independent of everything else in flight, and one launch less per call.
+    const unsigned int tile_blocks = 8u * (unsigned int) g.groups_per_xcd * (unsigned int) g.slot_tiles;
+    if (blockIdx.x >= tile_blocks) {
+        if (blockIdx.y == 0 && a.roll_dst) {
+            const int e = (int)(blockIdx.x - tile_blocks) * THREADS + tid;
+            if (e < a.H * a.C) {
+                const int f = e / a.C, c = e - f * a.C, lin = a.roll_appended + f;
+                float v = 0.0f;
+                if (lin < a.H) v = a.hist [(size_t) lin * a.C + c];
+                else if (a.in && lin - a.H < a.in_frames) v = a.in [(size_t)(lin - a.H) * a.C + c];
+                a.roll_dst [e] = v;
+            }
+        }
+        return;
+    }
     const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
     const int st = within % g.slot_tiles, jg = xcd * g.groups_per_xcd + within / g.slot_tiles;
     if (jg >= g.period_groups) return;
@@ -559,11 +593,7 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
             // (resampler.c:156-168), so window and products are identical, as is the pass-through sample
             else status = (dip * a.F + dfi == 0) ? 0 : 1;
             if (!INTERP && status == 0 && !a.lowpass && (p.fi % a.F) == 0) status = 3;
-            if (status == 1) {
-                const unsigned int slot = atomicAdd (a.fix_count, 1u);
-                if (slot < a.fix_cap) a.fix_list [slot] = n;
-                atomicAdd (a.fix_count + 1, 1u);
-            }
+            if (status == 1) { atomicAdd (a.fix_count, 1u); atomicAdd (a.fix_count + 1, 1u); }       // (diagnostics: resampleHipLastHandedBack)
         }
         s_status [e] = status;
     }
@@ -918,6 +948,10 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
                     y = load_frame (a, INT_MIN, s_ip [i] + jl * g.Q + s_fi [i] / a.F, ch_base + c);
                 a.out [n * a.C + ch_base + c] = y;
             }
+            else if (status == 1) {                            // off the canonical pattern: evaluated here at its exact position
+                const size_t n = (size_t) n_tile + (size_t) jl * g.P + i;
+                a.out [n * a.C + ch_base + c] = direct_sample<INTERP> (a, INT_MIN, locate<INTERP> (a, segs, (unsigned int) n), ch_base + c);
+            }
         }
     }
 }
@@ -1023,6 +1057,21 @@ void fir_mfma64_kernel (ArtFirArgs a, ArtSegTable segs, WideGeom g)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware mapping as in the single-precision kernel: XCD x takes a contiguous range of period groups
+    // workgroups past the tile grid roll the history for the next call (see fir_mfma_kernel)
+    const unsigned int tile_blocks = 8u * (unsigned int) g.groups_per_xcd * (unsigned int) g.slot_tiles;
+    if (blockIdx.x >= tile_blocks) {
+        if (a.roll_dst) {
+            const int e = (int)(blockIdx.x - tile_blocks) * MW_THREADS + (int) threadIdx.x;
+            if (e < a.H * a.C) {
+                const int f = e / a.C, c = e - f * a.C, lin = a.roll_appended + f;
+                double v = 0.0;
+                if (lin < a.H) v = a.hist [(size_t) lin * a.C + c];
+                else if (a.in && lin - a.H < a.in_frames) v = a.in [(size_t)(lin - a.H) * a.C + c];
+                a.roll_dst [e] = v;
+            }
+        }
+        return;
+    }
     const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
     const int st = within % g.slot_tiles, jg = xcd * g.groups_per_xcd + within / g.slot_tiles;
     if (jg >= g.period_groups) return;
@@ -1051,9 +1100,7 @@ void fir_mfma64_kernel (ArtFirArgs a, ArtSegTable segs, WideGeom g)
                 if (status == 0 && !a.lowpass && (p.fi % a.F) == 0) status = 3;
             }
             if (status == 1) {
-                const unsigned int slot = atomicAdd (a.fix_count, 1u);
-                if (slot < a.fix_cap) a.fix_list [slot] = n;
-                atomicAdd (a.fix_count + 1, 1u);
+                atomicAdd (a.fix_count, 1u); atomicAdd (a.fix_count + 1, 1u);       // (diagnostics: resampleHipLastHandedBack)
             }
         }
         s_status [e] = status;
@@ -1175,6 +1222,10 @@ void fir_mfma64_kernel (ArtFirArgs a, ArtSegTable segs, WideGeom g)
                     else y = acc [t][c][r];
                     a.out [n * CG + ch] = y;
                 }
+                else if (status == 1) {                        // off the canonical pattern: evaluated here at its exact position
+                    const size_t n = (size_t) n_tile + (size_t) jl * g.P + i;
+                    a.out [n * CG + ch] = direct_sample<INTERP> (a, INT_MIN, locate<INTERP> (a, segs, (unsigned int) n), ch);
+                }
             }
     }
 }
@@ -1209,7 +1260,7 @@ __global__ void deinterleave_kernel (art_s *dst, long pitch, const art_s *src, i
 
 // tile size, LDS bytes and grid of one general-kernel launch (shared by the single and the batched launch)
 template <int CG>
-bool general_geometry (const ArtFirArgs &a, int from_list, int *tile_out, size_t *lds_out, dim3 *grid_out, unsigned int crowd = 1)
+bool general_geometry (const ArtFirArgs &a, int *tile_out, size_t *lds_out, dim3 *grid_out, unsigned int crowd = 1)
 {
     // tile size: as many consecutive outputs as keep the staged span within the LDS budget
     const int lds_budget = 64 * 1024;
@@ -1222,28 +1273,28 @@ bool general_geometry (const ArtFirArgs &a, int from_list, int *tile_out, size_t
     // each keeps larger tiles.  An output's value does not depend on the tile it is computed in.)
     const unsigned int total_outputs = a.n_end - a.n_begin;
     while (tile > 4 && (unsigned long long)((total_outputs + tile - 1) / tile) * crowd < 1024u) tile >>= 1;
-    if (tile < 1 || from_list) tile = 1;
+    if (tile < 1) tile = 1;
     long span = a.T + (long) ceil (tile / a.ratio) + 3;
     size_t lds = (size_t) span * CG * sizeof (art_s);
     if (lds > 160 * 1024 - 1024) return false;              // absurd ratio/taps combination
     const unsigned int total = a.n_end - a.n_begin;
     const unsigned int roll_blocks = a.roll_dst ? (unsigned int)((a.H * a.C + GEN_THREADS - 1) / GEN_THREADS) : 0u;
     *tile_out = tile; *lds_out = lds;
-    *grid_out = dim3 ((from_list ? GEN_LIST_BLOCKS : (total + tile - 1) / tile) + roll_blocks, (a.C + CG - 1) / CG);
+    *grid_out = dim3 ((total + tile - 1) / tile + roll_blocks, (a.C + CG - 1) / CG);
     return true;
 }
 
 template <int CG>
-int launch_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st, int from_list = 0)
+int launch_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st)
 {
     int tile; size_t lds; dim3 grid;
-    if (!general_geometry<CG> (a, from_list, &tile, &lds, &grid)) return -1;
+    if (!general_geometry<CG> (a, &tile, &lds, &grid)) return -1;
     const bool precise = (a.mode & 3) == ART_MODE_PRECISE;
 
 #define GO(I, P) do { if (general_group (a.T) == 16) GO_ (I, P, 16); else GO_ (I, P, 64); } while (0)
 #define GO_(I, P, GG) do { auto k = fir_general_kernel<CG, I, P, GG>; \
         if (lds > 48 * 1024) (void) hipFuncSetAttribute ((const void *) k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
-        hipLaunchKernelGGL (k, grid, dim3 (GEN_THREADS), lds, st, a, segs, tile, from_list); } while (0)
+        hipLaunchKernelGGL (k, grid, dim3 (GEN_THREADS), lds, st, a, segs, tile); } while (0)
     if (a.interpolate) { if (precise) GO (true, true); else GO (true, false); }
     else               { if (precise) GO (false, true); else GO (false, false); }
 #undef GO
@@ -1259,7 +1310,7 @@ int batch_variant (const ArtFirArgs *a, const ArtSegTable *segs, const int *whic
     for (int k = 0; k < count; ++k) {
         const int i = which [k];
         int tile; size_t lds; dim3 grid;
-        if (!general_geometry<CG> (a [i], 0, &tile, &lds, &grid, (unsigned int) count)) return -1;
+        if (!general_geometry<CG> (a [i], &tile, &lds, &grid, (unsigned int) count)) return -1;
         if (segs [i].count > BATCH_SEGS) return -1;
         host [k].a = a [i]; host [k].seg_count = segs [i].count; host [k].lin_floor = segs [i].lin_floor;
         for (int q = 0; q < BATCH_SEGS; ++q) {
@@ -1288,12 +1339,12 @@ int batch_variant (const ArtFirArgs *a, const ArtSegTable *segs, const int *whic
 
 extern "C" {
 
-static int run_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st, int from_list)
+static int run_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st)
 {
-    if (a.C > 4) return launch_general<8> (a, segs, st, from_list);
-    if (a.C > 2) return launch_general<4> (a, segs, st, from_list);
-    if (a.C == 2) return launch_general<2> (a, segs, st, from_list);
-    return launch_general<1> (a, segs, st, from_list);
+    if (a.C > 4) return launch_general<8> (a, segs, st);
+    if (a.C > 2) return launch_general<4> (a, segs, st);
+    if (a.C == 2) return launch_general<2> (a, segs, st);
+    return launch_general<1> (a, segs, st);
 }
 
 // does this call take the matrix-core path (arthip_fir), or the general kernel?  One rule, also asked by the batched entry
@@ -1458,7 +1509,9 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
                 g.head = (float *)(base + used);
             }
         }
-        dim3 grid ((unsigned int)(8 * g.groups_per_xcd * g.slot_tiles), (unsigned int)((a->C + g.cg - 1) / g.cg));
+        const unsigned int wg_threads = ws ? 2 * MF_THREADS : MF_THREADS;
+        const unsigned int roll_blocks = a->roll_dst ? (unsigned int)((a->H * a->C + wg_threads - 1) / wg_threads) : 0u;
+        dim3 grid ((unsigned int)(8 * g.groups_per_xcd * g.slot_tiles) + roll_blocks, (unsigned int)((a->C + g.cg - 1) / g.cg));
 
         if (a->interpolate) hipLaunchKernelGGL (mfma_prepare_kernel<true>, dim3 (g.slot_tiles, g.tile_rows), dim3 (256), 0, st, *a, *segs, g);
         else hipLaunchKernelGGL (mfma_prepare_kernel<false>, dim3 (g.slot_tiles, g.tile_rows), dim3 (256), 0, st, *a, *segs, g);
@@ -1472,8 +1525,8 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
                                             case 1: MF_GO (false, 1); break; default: MF_GO (false, 0); }
 #undef MF_GO
         if (a->ev_stop) arthip_event_record (a->ev_stop, stream);
-        if (hipGetLastError () != hipSuccess) return -1;
-        if (run_general (*a, *segs, st, 1)) return -1;          // outputs handed back (usually none) + the history roll
+        // (outputs off the canonical pattern are evaluated inside the kernel, and its extra workgroups roll the history:
+        // two launches per call — prepare, main — where there were three)
         return hipGetLastError () == hipSuccess ? (ART_KERNEL_MFMA | (a->roll_dst ? ART_FIR_ROLLED : 0)) : -1;
     }
 
@@ -1509,7 +1562,8 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
             g.head = (double *)(base + used);
             if (base && used + (size_t) g.head_frames * a->C * sizeof (double) <= a->scratch_bytes &&
                 (size_t) g.head_frames * a->C * 8 < 0x7fff0000ull && (size_t) g.nrows * g.ktot * 8 < 0x7fff0000ull) {
-                const dim3 grid ((unsigned int)(8 * g.groups_per_xcd * g.slot_tiles));
+                const unsigned int roll_blocks = a->roll_dst ? (unsigned int)((a->H * a->C + MW_THREADS - 1) / MW_THREADS) : 0u;
+                const dim3 grid ((unsigned int)(8 * g.groups_per_xcd * g.slot_tiles) + roll_blocks);
                 if (a->interpolate) hipLaunchKernelGGL (wide_prepare_kernel<true>, dim3 (g.slot_tiles, MW_ROWS), dim3 (256), 0, st, *a, *segs, g);
                 else hipLaunchKernelGGL (wide_prepare_kernel<false>, dim3 (g.slot_tiles, MW_ROWS), dim3 (256), 0, st, *a, *segs, g);
                 if (a->ev_start) arthip_event_record (a->ev_start, stream);
@@ -1520,8 +1574,6 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
                                                     case 4: MW_GO (false, 4); break; case 2: MW_GO (false, 2); break; default: MW_GO (false, 1); }
 #undef MW_GO
                 if (a->ev_stop) arthip_event_record (a->ev_stop, stream);
-                if (hipGetLastError () != hipSuccess) return -1;
-                if (run_general (*a, *segs, st, 1)) return -1;          // outputs handed back + the history roll
                 return hipGetLastError () == hipSuccess ? (ART_KERNEL_MFMA | (a->roll_dst ? ART_FIR_ROLLED : 0)) : -1;
             }
         }
@@ -1532,7 +1584,7 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
 general_path:
 #endif
     if (a->ev_start) arthip_event_record (a->ev_start, stream);
-    if (run_general (*a, *segs, st, 0)) return -1;
+    if (run_general (*a, *segs, st)) return -1;
     if (a->ev_stop) arthip_event_record (a->ev_stop, stream);
     return hipGetLastError () == hipSuccess ? (ART_KERNEL_GENERAL | (a->roll_dst ? ART_FIR_ROLLED : 0)) : -1;
 }

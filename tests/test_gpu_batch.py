@@ -111,3 +111,29 @@ def test_shared_filter_bank_lifecycle():
     e = B.Resampler(2, 380, 380)                            # last reference gone: rebuilt from scratch, same bank
     assert np.array_equal(run(e).view(np.uint32), yb.view(np.uint32))
     print(f"first init {1e3 * (t1 - t0):.2f} ms, second (shared bank) {1e3 * (t2 - t1):.2f} ms")
+
+
+@pytest.mark.parametrize("width", [32, 64])
+def test_outputs_off_the_canonical_pattern_are_evaluated_inside_the_matrix_kernel(width):
+    """44.1 -> 48 kHz with 300 nearest-filter phases: thousands of outputs land on a filter boundary and round to the other
+    row than their slot's canonical one.  The matrix-core kernels evaluate those themselves at their exact position (no
+    follow-up launch): they must be counted (resampleHipLastHandedBack) and the whole output must meet the parity bar."""
+    import _oracle
+    from _hip import tolerance_ok
+    B = A.binding(width); O = _oracle.binding(width)
+    dt = np.float32 if width == 32 else np.float64
+    ch, T, F = 2, 380, 300
+    h = B.Resampler(ch, T, F, 0.0, BH); o = O.OracleResampler(ch, T, F, 0.0, _oracle.BH | _oracle.PRECISE)
+    h.set_kernel(2); h.advance(T / 2); o.advance(T / 2)
+    rng = np.random.default_rng(3)
+    for k in range(3):
+        n = 60000 + 777 * k
+        x = (rng.random((n, ch)) - 0.5).astype(dt)
+        cap = int(n * 48000 / 44100 * 1.01) + T
+        u, g, y = h.process(x, cap, 48000 / 44100); uo, go, yo = o.process(x, cap, 48000 / 44100)
+        assert (u, g) == (uo, go) and h.last_kernel() == 2
+        if width == 32:
+            assert tolerance_ok(np.array(y), np.array(yo))[0]
+        else:
+            assert np.all(np.abs(np.array(y) - np.array(yo)) <= 2.0 ** -47 * np.maximum(1.0, np.abs(np.array(yo))))
+    assert h.handed_back() > 1000
