@@ -1356,8 +1356,10 @@ static bool takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int
     const unsigned int total = a->n_end - a->n_begin;
     bool enough;
     if (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32) {
-        // (up to 256 taps the general kernel works four frames per wave: its per-frame cost roughly halves)
-        const double k_ns = ((0.2 + 0.04 * a->C) + 0.00007 * a->C * a->T) * (general_group (a->T) == 16 ? 0.47 : 1.0);
+        // (up to 256 taps the general kernel works four frames per wave: its per-frame cost roughly halves; with long filters
+        // a mid-sized call is cut into 16-frame tiles that each stage ~T frames: 1.5x per frame below ~40k outputs — measured)
+        const double k_ns = ((0.2 + 0.04 * a->C) + 0.00007 * a->C * a->T) * (general_group (a->T) == 16 ? 0.47 : 1.0) *
+                            ((a->T >= 512 && total < 40000u) ? 1.5 : 1.0);
         const double chunks = (a->T + 63) / 32;
         const double floor_ns = 13500.0 + 550.0 * chunks + (a->C <= 2 ? 2000.0 : 0.0);
         enough = total * k_ns >= floor_ns - 5000.0;
