@@ -155,6 +155,19 @@ int artamdPlanCall (ArtamdPosition *p, int nIn, int cap, double ratio, ResampleR
         double limit = (double)(top - half);
         unsigned int lo = made, hi = ucap;
 
+        /* two bisection steps placed around the arithmetic estimate (any probe inside [lo, hi) is a valid step of the same
+         * monotone search, so the answer is unchanged): a 1M-frame call has 70-180 ring epochs, 21 steps each otherwise */
+        {
+            const double est = (limit - base) * ratio;
+            if (est > 2.0 && est < 4.0e9) {
+                const unsigned int e = (unsigned int) est;
+                for (int probe = 0; probe < 2; ++probe) {
+                    const unsigned int mid = probe ? e + 2 : e - 2;
+                    if (mid >= lo && mid < hi) { if (base + (double) mid / ratio < limit) lo = mid + 1; else hi = mid; }
+                }
+            }
+        }
+
         while (lo < hi) {                               /* first j with position(j) >= limit */
             unsigned int mid = lo + (hi - lo) / 2;
             if (base + (double) mid / ratio < limit) lo = mid + 1; else hi = mid;
