@@ -43,7 +43,7 @@ typedef struct {
     long in_pitch;                       /* 0: interleaved [frame][C]; else planar, channel c at in + c*in_pitch */
     art_s *out;
     long out_pitch;
-    art_s *roll_dst;                     /* when set: the launch that evaluates the fix list also rolls the history */
+    art_s *roll_dst;                     /* when set: the FIR launch also rolls the history (extra workgroups) */
     int roll_appended;                   /*   (frames appended by this call) into roll_dst; arthip_fir then returns k | ART_FIR_ROLLED */                      /* 0: interleaved; else planar */
     int in_frames;                       /* frames valid at `in` (reads beyond return 0) */
     int C, T, F, H;
@@ -54,7 +54,8 @@ typedef struct {
     /* periodic-phase structure for the MFMA kernel (0 = none): out frame n+period_out sits exactly
      * period_in input frames after out frame n */
     int period_out, period_in;
-    /* scratch for outputs the MFMA kernel hands back to the general kernel (device memory) */
+    /* counters of outputs the matrix kernels evaluated off their slot's canonical pattern (device memory; fix_list is only
+     * tested for non-NULL: the path needs the counters) */
     unsigned int *fix_list, *fix_count;
     unsigned int fix_cap;
     /* device scratch for the MFMA path: per-launch effective rows + canonical slot positions */

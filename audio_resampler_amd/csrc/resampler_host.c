@@ -43,7 +43,7 @@ struct artamd_resampler {
     int timing; void **ev; int ev_count, ev_cap;
     art_s *d_patch; size_t patch_cap;        /* end-point extrapolation: samples computed on the host */
     void *d_scratch; size_t scratch_cap;     /* MFMA path: effective rows + canonical positions of one launch */
-    unsigned int *d_fix; size_t fix_cap;    /* [0] = counter, [1..] = output indices handed back by the MFMA kernel */
+    unsigned int *d_fix; size_t fix_cap;    /* [0] per-launch, [1] running count of outputs the matrix kernels evaluated off-pattern */
     void *d_batch; size_t batch_cap;         /* argument table of the batched calls led by this context */
     unsigned long batch_stamp;               /* last batched call this context took part in (duplicate check) */
 };
@@ -552,7 +552,7 @@ static void *timing_event (struct artamd_resampler *hip)
 }
 int  resampleHipLastKernel (Resample *cxt) { return cxt->hip->last_kernel; }
 
-/* outputs the MFMA kernel has handed back to the general kernel so far (synchronises) */
+/* outputs the matrix kernels have evaluated off their canonical pattern so far (synchronises) */
 unsigned int resampleHipLastHandedBack (Resample *cxt)
 {
     unsigned int n = 0;
@@ -714,7 +714,7 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
         if ((cxt->flags & RESAMPLE_STRICT_ORDER) && extend) a.mode |= 4;
         a.ratio = eff_ratio;
         a.period_out = hip->period_out; a.period_in = hip->period_in;
-        /* the matrix-core path needs a hand-back list and 8 MB of scratch: allocated only once a call of this context is
+        /* the matrix-core path needs its counters and 8 MB of scratch: allocated only once a call of this context is
          * actually big enough for it (asked with stand-ins first — a service with thousands of small-block contexts never
          * pays for them) */
         int matrix_sized = 0;
@@ -832,7 +832,7 @@ static int batch_plan (Resample *cxt, const art_s *d_in, int nIn, art_s *d_out, 
     }
     a->n_begin = hip->segs [0].first_output; a->n_end = res->output_generated;
 
-    /* would the single call take the matrix-core path?  (it has the hand-back list and scratch whenever the ratio is
+    /* would the single call take the matrix-core path?  (it has its counters and scratch whenever the ratio is
      * rational, the mode default and the kernel not pinned: stand-ins suffice for the question) */
     if (a->period_out && a->mode == ART_MODE_FAST && hip->kernel_pref != ART_KERNEL_GENERAL) {
         a->fix_count = (unsigned int *) hip; a->fix_list = (unsigned int *) hip; a->scratch = hip; a->scratch_bytes = (size_t) 8 << 20;

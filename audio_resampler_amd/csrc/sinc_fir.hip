@@ -399,8 +399,8 @@ void fir_strict_kernel (ArtFirArgs a, ArtSegTable segs, int precise)
 // arithmetic and compared with its slot's canonical values (taken from the workgroup's first period).
 // Equal, or the same position within MF_PHASE_TOL filter steps (phase values on a filter boundary can round to
 // the neighbouring (fi-1, frac ~ 1) representation; the effective rows differ by < 1e-10 relative):
-// the tile's row is used.  Anything else (ratio drift, ring-epoch seams) goes to a fix list that the
-// general kernel evaluates.
+// the tile's row is used.  Anything else (ratio drift, ring-epoch seams) is evaluated in the epilogue by the lane that
+// owns the output, at its exact position (direct_sample) and counted (fix_count: diagnostics).
 // ---------------------------------------------------------------------------------------------------
 
 typedef float f32x16 __attribute__ ((ext_vector_type (16)));
@@ -472,7 +472,7 @@ void mfma_prepare_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
     const Pos p = locate<INTERP> (a, segs, a.n_begin + st * R + min (row, rows_valid - 1));
     if (tid == 0) {
         g.canon_ip [st * R + row] = p.ip; g.canon_fi [st * R + row] = p.fi; g.canon_frac [st * R + row] = p.frac;
-        if (st == 0 && row == 0) a.fix_count [0] = 0;       // per-launch hand-back counter (the main kernel follows in-stream)
+        if (st == 0 && row == 0) a.fix_count [0] = 0;       // per-launch count of off-pattern outputs (the main kernel follows in-stream)
     }
     const float *h0 = a.bank + (size_t) p.fi * a.T;
     const int shift = p.ip - p0.ip;
@@ -525,7 +525,7 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
     constexpr int ROWS = 32 * MT;
     __shared__ __attribute__ ((aligned (16))) float As_ [NBUF] [ROWS * MF_LD];
     __shared__ __attribute__ ((aligned (16))) float Bs_ [NBUF] [MF_COLS * MF_LD];
-    __shared__ unsigned char s_status [ROWS * MF_MAX_PPW];    // 0 ok, 1 handed back, 2 masked, 3 pass-through
+    __shared__ unsigned char s_status [ROWS * MF_MAX_PPW];    // 0 ok, 1 off the pattern (evaluated directly), 2 masked, 3 pass-through
     __shared__ int s_fi [ROWS], s_shift [ROWS], s_ip [ROWS];
     __shared__ double s_frac [ROWS];
 
@@ -970,7 +970,7 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
 //    than a double ulp.  The A tile carries both rows of every slot — rows 0-31: h[fi_i], rows 32-63: h[fi_i + 1],
 //    each shifted to the tile's K origin — and the epilogue blends s0, s1 with the output's OWN fraction, taken
 //    from the exact fp64 replay of its position.  An output may use the tile whenever its integer position and
-//    filter index equal the slot's; anything else goes to the fix list (general kernel).
+//    filter index equal the slot's; anything else is evaluated directly in the epilogue (direct_sample).
 //  * accumulation is fp64 throughout (v_mfma_f64_16x16x4_f64), so there is no flush scheme.
 //
 // 4 waves; wave w owns columns [32w, 32w+32) x all rows: 2 column tiles x (4 | 2) row tiles of 16x16.  K is staged
@@ -1052,7 +1052,7 @@ void fir_mfma64_kernel (ArtFirArgs a, ArtSegTable segs, WideGeom g)
     __shared__ __attribute__ ((aligned (16))) double As [NROWS * MW_LD];
     __shared__ __attribute__ ((aligned (16))) double Bs [MW_COLS * MW_LD];
     __shared__ double s_frac [INTERP ? MW_ROWS * PPW : 1];             // the exact fraction of every (slot, period)
-    __shared__ unsigned char s_status [MW_ROWS * PPW];                 // 0 ok, 1 handed back, 2 masked, 3 pass-through
+    __shared__ unsigned char s_status [MW_ROWS * PPW];                 // 0 ok, 1 off the pattern (evaluated directly), 2 masked, 3 pass-through
     __shared__ int s_fi [MW_ROWS], s_ip [MW_ROWS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

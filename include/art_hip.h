@@ -31,7 +31,7 @@ void resampleHipSynchronize (Resample *cxt);
  * 2 = MFMA periodic-phase kernel where applicable (falls back to 1 elsewhere) */
 void resampleHipSetKernel (Resample *cxt, int which);
 int  resampleHipLastKernel (Resample *cxt);          /* which kernel produced the bulk of the last call */
-unsigned int resampleHipLastHandedBack (Resample *cxt);   /* outputs the MFMA kernel has passed to the general kernel so far */
+unsigned int resampleHipLastHandedBack (Resample *cxt);   /* outputs the matrix-core kernels evaluated at their own exact position, off their slot's canonical pattern, so far */
 /* HIP-event timing of the dominant FIR kernel only (events recorded on the context's stream immediately
  * before and after that kernel's launch; the fix-up and history kernels are outside the bracket).  Enable, run calls, then read: returns accumulated kernel milliseconds and the launch count
  * since timing was (re-)enabled; the read synchronises. */
