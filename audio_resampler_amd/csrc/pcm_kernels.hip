@@ -881,7 +881,7 @@ void decimate_pipe_kernel (ArtDecArgs a, const art_s *in, int frames, unsigned c
                 art_s *tile = tiles + (k % 3) * DEC_CHUNK, *dth = dths + (k & 1) * DEC_CHUNK;
                 for (int e = ht; e < nf * Cg; e += HELPERS) {
                     const int f = e / Cg, c = e - f * Cg;
-                    tile [e] = in [(size_t)(f0 + f) * a.C + c0 + c];
+                    tile [e] = in [(size_t)(f0 + f) * a.C + c0 + c] * scale;     // (the serial wave's first operation, done here: same product)
                 }
                 if (DITHER) {
                     const int segs_per_ch = (nf + DEC_SEG - 1) / DEC_SEG;
@@ -923,7 +923,7 @@ void decimate_pipe_kernel (ArtDecArgs a, const art_s *in, int frames, unsigned c
             art_s *tile = tiles + (it % 3) * DEC_CHUNK;
             const art_s *dth = dths + (it & 1) * DEC_CHUNK;
             auto one = [&] (art_s smp, art_s dither) -> art_s {
-                const art_s scaled = smp * scale;
+                const art_s scaled = smp;                       // already times `scale` (phase A)
                 const art_s code = scaled - fb;
                 const art_s dithered = code + dither;
                 const art_s qf = round_half_up (dithered);
