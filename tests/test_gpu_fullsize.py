@@ -79,3 +79,29 @@ def test_full_size_decimation_checksum_equals_oracle():
         assert clips == wclips
         assert checksum_bytes(got) == checksum_bytes(want)
         assert np.array_equal(got, want)
+
+
+def test_bench_line_keeps_its_contract():
+    """bench.py prints ONE JSON line with the fields the driver reads (metric / value / unit / n_gpus / steps / warmup /
+    ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload) plus `roofline` and — unless
+    switched off — `cpu_baseline`; the workload is BASELINE.json's, the kernel the matrix-core one, value = samples / time."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2", "--preroll-ms", "20", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["unit"] == "Msamples/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and d["config"]["fir_kernel"] == "mfma" and d["config"]["block_frames"] == 1 << 20
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # value is whole-job samples over the timed region: consistent with ms_per_step and the workload's size
+    per_step = d["value"] * 1e6 * d["ms_per_step"] * 1e-3
+    assert abs(per_step - (1 << 20) * 8 * 48000 / 44100) / per_step < 0.01
