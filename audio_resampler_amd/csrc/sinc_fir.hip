@@ -284,11 +284,11 @@ void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile)
     fir_general_body<CG, INTERP, PRECISE, G> (a, segs, tile, blockIdx.x, blockIdx.y);
 }
 
-// lanes per output frame: 16 up to 256 taps, the whole wave above.  Measured (8 ch x 48 taps 15 -> 35 Gsamples/s, stereo x
-// 156 taps 7.7 -> 13.9); at 380 taps the gain shrinks to 8-30 % (stereo is bound by the filter rows coming out of L2) while
-// a 16-lane group walks 12 tap pairs instead of 3 — a 10 ms block's launch goes from 5 to 7 us — so presets -3 / -4 keep
-// the whole wave.
-__host__ __device__ constexpr int general_group (int taps) { return taps <= 256 ? 16 : 64; }
+// lanes per output frame: 16 up to 256 taps, 32 up to 512, the whole wave above.  Measured (8 ch x 48 taps 15 -> 35
+// Gsamples/s, stereo x 156 taps 7.7 -> 13.9; stereo x 380 taps 6.7 -> 8.2 with 32 lanes): several frames per wave keep more
+// coefficient loads in flight and share the reduction.  16 lanes at 380 taps gains no more than 32 but makes a group walk 12
+// tap pairs where a wave walks 3 — a 10 ms block's launch went from 5 to 7 us — so the group shrinks with the tap count.
+__host__ __device__ constexpr int general_group (int taps) { return taps <= 256 ? 16 : taps <= 512 ? 32 : 64; }
 
 // Many independent streams, one launch: blockIdx.z picks a stream's call (its arguments sit in a table in device memory,
 // exactly what the single-stream launch would have passed by value), x / y are that call's own grid.  Same body, same
@@ -1291,7 +1291,7 @@ int launch_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st
     if (!general_geometry<CG> (a, &tile, &lds, &grid)) return -1;
     const bool precise = (a.mode & 3) == ART_MODE_PRECISE;
 
-#define GO(I, P) do { if (general_group (a.T) == 16) GO_ (I, P, 16); else GO_ (I, P, 64); } while (0)
+#define GO(I, P) do { const int gg = general_group (a.T); if (gg == 16) GO_ (I, P, 16); else if (gg == 32) GO_ (I, P, 32); else GO_ (I, P, 64); } while (0)
 #define GO_(I, P, GG) do { auto k = fir_general_kernel<CG, I, P, GG>; \
         if (lds > 48 * 1024) (void) hipFuncSetAttribute ((const void *) k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
         hipLaunchKernelGGL (k, grid, dim3 (GEN_THREADS), lds, st, a, segs, tile); } while (0)
@@ -1303,7 +1303,7 @@ int launch_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st
 }
 
 template <int CG>
-int batch_variant (const ArtFirArgs *a, const ArtSegTable *segs, const int *which, int count, bool interp, bool precise, bool group16,
+int batch_variant (const ArtFirArgs *a, const ArtSegTable *segs, const int *which, int count, bool interp, bool precise, int group,
                           FirBatchItem *host, FirBatchItem *dev, hipStream_t st)
 {
     size_t lds_max = 0; unsigned int gx = 0, gy = 0;
@@ -1323,7 +1323,7 @@ int batch_variant (const ArtFirArgs *a, const ArtSegTable *segs, const int *whic
         if (grid.y > gy) gy = grid.y;
     }
     if (hipMemcpyAsync (dev, host, sizeof (FirBatchItem) * (size_t) count, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
-#define GOB(I, P) do { if (group16) GOB_ (I, P, 16); else GOB_ (I, P, 64); } while (0)
+#define GOB(I, P) do { if (group == 16) GOB_ (I, P, 16); else if (group == 32) GOB_ (I, P, 32); else GOB_ (I, P, 64); } while (0)
 #define GOB_(I, P, GG) do { auto k = fir_general_batch_kernel<CG, I, P, GG>; \
         if (lds_max > 48 * 1024) (void) hipFuncSetAttribute ((const void *) k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_max); \
         hipLaunchKernelGGL (k, dim3 (gx, gy, (unsigned int) count), dim3 (GEN_THREADS), lds_max, st, (const FirBatchItem *) dev); } while (0)
@@ -1358,7 +1358,7 @@ static bool takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int
     if (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32) {
         // (up to 256 taps the general kernel works four frames per wave: its per-frame cost roughly halves; with long filters
         // a mid-sized call is cut into 16-frame tiles that each stage ~T frames: 1.5x per frame below ~40k outputs — measured)
-        const double k_ns = ((0.2 + 0.04 * a->C) + 0.00007 * a->C * a->T) * (general_group (a->T) == 16 ? 0.47 : 1.0) *
+        const double k_ns = ((0.2 + 0.04 * a->C) + 0.00007 * a->C * a->T) * (general_group (a->T) == 16 ? 0.47 : general_group (a->T) == 32 ? 0.8 : 1.0) *
                             ((a->T >= 512 && total < 40000u) ? 1.5 : 1.0);
         const double chunks = (a->T + 63) / 32;
         const double floor_ns = 13500.0 + 550.0 * chunks + (a->C <= 2 ? 2000.0 : 0.0);
@@ -1372,7 +1372,7 @@ static bool takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int
 
 #else
     const unsigned int total = a->n_end - a->n_begin;
-    const double k_ns = ((0.2 + 0.05 * a->C) + 0.00021 * a->C * a->T) * (general_group (a->T) == 16 ? 0.55 : 1.0);
+    const double k_ns = ((0.2 + 0.05 * a->C) + 0.00021 * a->C * a->T) * (general_group (a->T) == 16 ? 0.55 : general_group (a->T) == 32 ? 0.85 : 1.0);
     const double floor_ns = 15000.0 + 4100.0 * ((a->T + 63) / 32);
     const bool enough = total * k_ns >= floor_ns - 5000.0;
     const bool small = (size_t) a->in_frames * a->C * 8 < 0x7fff0000ull && (size_t) a->H * a->C * 8 < 0x7fff0000ull &&
@@ -1417,22 +1417,23 @@ int arthip_fir_batch (const ArtFirArgs *a, const ArtSegTable *segs, int n, void 
     // group by kernel variant; each group takes its own slice of the table (the copies are asynchronous, the slices must
     // not be reused inside one call)
     for (int cgi = 0; cgi < 4 && !rc; ++cgi)
-        for (int v = 0; v < 8 && !rc; ++v) {
-            const bool interp = (v & 1) != 0, precise = (v & 2) != 0, group16 = (v & 4) != 0;
+        for (int v = 0; v < 12 && !rc; ++v) {
+            const bool interp = (v & 1) != 0, precise = (v & 2) != 0;
+            const int group = 16 << (v >> 2);                     // 16, 32, 64 lanes per output frame
             int count = 0;
             for (int i = 0; i < n; ++i) {
                 const int cls = a [i].C > 4 ? 3 : a [i].C > 2 ? 2 : a [i].C == 2 ? 1 : 0;
                 if (cls == cgi && (a [i].interpolate != 0) == interp && (((a [i].mode & 3) == ART_MODE_PRECISE) == precise) &&
-                    (general_group (a [i].T) == 16) == group16 && a [i].n_end > a [i].n_begin)
+                    general_group (a [i].T) == group && a [i].n_end > a [i].n_begin)
                     which [count++] = i;
             }
             if (!count) continue;
             FirBatchItem *hslice = host + done, *dslice = (FirBatchItem *) d_table + done;
             switch (cgi) {
-                case 3: rc = batch_variant<8> (a, segs, which, count, interp, precise, group16, hslice, dslice, st); break;
-                case 2: rc = batch_variant<4> (a, segs, which, count, interp, precise, group16, hslice, dslice, st); break;
-                case 1: rc = batch_variant<2> (a, segs, which, count, interp, precise, group16, hslice, dslice, st); break;
-                default: rc = batch_variant<1> (a, segs, which, count, interp, precise, group16, hslice, dslice, st); break;
+                case 3: rc = batch_variant<8> (a, segs, which, count, interp, precise, group, hslice, dslice, st); break;
+                case 2: rc = batch_variant<4> (a, segs, which, count, interp, precise, group, hslice, dslice, st); break;
+                case 1: rc = batch_variant<2> (a, segs, which, count, interp, precise, group, hslice, dslice, st); break;
+                default: rc = batch_variant<1> (a, segs, which, count, interp, precise, group, hslice, dslice, st); break;
             }
             done += count;
         }
