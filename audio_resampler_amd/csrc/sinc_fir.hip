@@ -284,11 +284,13 @@ void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile)
     fir_general_body<CG, INTERP, PRECISE, G> (a, segs, tile, blockIdx.x, blockIdx.y);
 }
 
-// lanes per output frame: 16 up to 256 taps, 32 up to 512, the whole wave above.  Measured (8 ch x 48 taps 15 -> 35
-// Gsamples/s, stereo x 156 taps 7.7 -> 13.9; stereo x 380 taps 6.7 -> 8.2 with 32 lanes): several frames per wave keep more
-// coefficient loads in flight and share the reduction.  16 lanes at 380 taps gains no more than 32 but makes a group walk 12
-// tap pairs where a wave walks 3 — a 10 ms block's launch went from 5 to 7 us — so the group shrinks with the tap count.
-__host__ __device__ constexpr int general_group (int taps) { return taps <= 256 ? 16 : taps <= 512 ? 32 : 64; }
+// lanes per output frame: 16 up to 256 taps, 32 above (64 — one frame per wave — is what the kernel started with and still
+// instantiates for experiments).  Measured at 1M-frame blocks: 8 ch x 48 taps 15 -> 35 Gsamples/s, stereo x 156 taps 7.7 ->
+// 13.9 (16 lanes); stereo x 380 taps 6.7 -> 8.2, 8 ch x 988 taps 7.5 -> 8.4 (32 lanes): several frames per wave keep more
+// coefficient loads in flight and share the reduction.  The price is latency on calls too small to fill the chip — a
+// group walks more tap pairs than a wave did: 12 -> 14 us for 1,024 frames at 8 ch x 988 taps — which is why 16 lanes stop
+// at 256 taps (at 380 they gain no more than 32 and cost a 10 ms block 2 us).
+__host__ __device__ constexpr int general_group (int taps) { return taps <= 256 ? 16 : 32; }
 
 // Many independent streams, one launch: blockIdx.z picks a stream's call (its arguments sit in a table in device memory,
 // exactly what the single-stream launch would have passed by value), x / y are that call's own grid.  Same body, same
@@ -1358,7 +1360,7 @@ static bool takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int
     if (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32) {
         // (up to 256 taps the general kernel works four frames per wave: its per-frame cost roughly halves; with long filters
         // a mid-sized call is cut into 16-frame tiles that each stage ~T frames: 1.5x per frame below ~40k outputs — measured)
-        const double k_ns = ((0.2 + 0.04 * a->C) + 0.00007 * a->C * a->T) * (general_group (a->T) == 16 ? 0.47 : general_group (a->T) == 32 ? 0.8 : 1.0) *
+        const double k_ns = ((0.2 + 0.04 * a->C) + 0.00007 * a->C * a->T) * (general_group (a->T) == 16 ? 0.47 : 0.85) *
                             ((a->T >= 512 && total < 40000u) ? 1.5 : 1.0);
         const double chunks = (a->T + 63) / 32;
         const double floor_ns = 13500.0 + 550.0 * chunks + (a->C <= 2 ? 2000.0 : 0.0);
@@ -1372,7 +1374,7 @@ static bool takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int
 
 #else
     const unsigned int total = a->n_end - a->n_begin;
-    const double k_ns = ((0.2 + 0.05 * a->C) + 0.00021 * a->C * a->T) * (general_group (a->T) == 16 ? 0.55 : general_group (a->T) == 32 ? 0.85 : 1.0);
+    const double k_ns = ((0.2 + 0.05 * a->C) + 0.00021 * a->C * a->T) * (general_group (a->T) == 16 ? 0.55 : a->T <= 512 ? 0.85 : 0.95);
     const double floor_ns = 15000.0 + 4100.0 * ((a->T + 63) / 32);
     const bool enough = total * k_ns >= floor_ns - 5000.0;
     const bool small = (size_t) a->in_frames * a->C * 8 < 0x7fff0000ull && (size_t) a->H * a->C * 8 < 0x7fff0000ull &&
