@@ -105,6 +105,10 @@ def _bind(width):
         # art_hip.h
         "artamdDeviceCount": (C.c_int, []),
         "artamdVersion": (C.c_char_p, []),
+        "artamdSetDevices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
+        "resampleHipGetDevice": (C.c_int, [RP]),
+        "resampleHipNumShards": (C.c_int, [RP]),
+        "resampleHipShardInfo": (C.c_int, [RP, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "resampleHipSetStream": (None, [RP, ptr]),
         "resampleHipSynchronize": (None, [RP]),
         "resampleHipSetKernel": (None, [RP, C.c_int]),
@@ -225,6 +229,15 @@ def _bind(width):
 
         def set_stream(self, stream_ptr):
             self.L.resampleHipSetStream(self.p, stream_ptr)
+
+        def shards(self):
+            """[(device, first_channel, channels), ...] of a RESAMPLE_MULTITHREADED context spread over devices; [] otherwise"""
+            out = []
+            for k in range(self.L.resampleHipNumShards(self.p)):
+                d, f, n = C.c_int(), C.c_int(), C.c_int()
+                self.L.resampleHipShardInfo(self.p, k, C.byref(d), C.byref(f), C.byref(n))
+                out.append((d.value, f.value, n.value))
+            return out
 
         def set_kernel(self, which):
             self.L.resampleHipSetKernel(self.p, which)

@@ -67,6 +67,17 @@ typedef struct {
 /* ---- device_rt.hip ---- */
 int   arthip_device_count (void);
 int   arthip_current_device (void);
+int   arthip_set_device (int device);
+void *arthip_stream_create (void);                         /* non-blocking stream on the current device */
+void  arthip_stream_destroy (void *stream);
+int   arthip_copy2d (void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t rows, void *stream);   /* any direction */
+int   arthip_copy (void *dst, const void *src, size_t bytes, void *stream);                                                /* any direction */
+void *arthip_host_alloc (size_t bytes);                    /* page-locked host memory */
+void  arthip_host_free (void *p);
+void *arthip_order_event_create (void);                    /* event without timing, for cross-stream ordering */
+int   arthip_stream_wait_event (void *stream, void *event);
+int   arthip_event_sync (void *event);
+void  arthip_enable_peer (int device, int peer);
 void *arthip_malloc (size_t bytes);
 void  arthip_free (void *p);
 int   arthip_h2d (void *dst, const void *src, size_t bytes, void *stream);

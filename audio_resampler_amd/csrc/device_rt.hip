@@ -46,6 +46,53 @@ int arthip_d2d (void *d, const void *s, size_t n, void *st) { return n ? fail (h
 int arthip_zero (void *d, size_t n, void *st) { return n ? fail (hipMemsetAsync (d, 0, n, (hipStream_t) st), "memset") : 0; }
 int arthip_sync (void *st) { return fail (hipStreamSynchronize ((hipStream_t) st), "sync"); }
 
+int arthip_set_device (int device) { return fail (hipSetDevice (device), "hipSetDevice"); }
+
+void *arthip_stream_create (void)
+{
+    // shards of one context run side by side: their streams must not serialise against the null stream
+    hipStream_t s = nullptr;
+    return fail (hipStreamCreateWithFlags (&s, hipStreamNonBlocking), "hipStreamCreate") ? nullptr : (void *) s;
+}
+void arthip_stream_destroy (void *s) { if (s) (void) hipStreamDestroy ((hipStream_t) s); }
+
+// strided rows between any two address spaces (host <-> device, device <-> device, across devices under UVA):
+// `rows` rows of `width` bytes, row starts `dpitch` / `spitch` bytes apart
+int arthip_copy2d (void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t rows, void *st)
+{
+    if (!width || !rows) return 0;
+    return fail (hipMemcpy2DAsync (dst, dpitch, src, spitch, width, rows, hipMemcpyDefault, (hipStream_t) st), "copy2D");
+}
+int arthip_copy (void *dst, const void *src, size_t n, void *st) { return n ? fail (hipMemcpyAsync (dst, src, n, hipMemcpyDefault, (hipStream_t) st), "copy") : 0; }
+
+// page-locked host memory for the staging buffers of the host-pointer entry points
+void *arthip_host_alloc (size_t bytes)
+{
+    void *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    return fail (hipHostMalloc (&p, bytes, hipHostMallocDefault), "hipHostMalloc") ? nullptr : p;
+}
+void arthip_host_free (void *p) { if (p) (void) hipHostFree (p); }
+
+// ordering events (no timing): `waiter` stream continues only after everything recorded so far on `signaller`
+void *arthip_order_event_create (void)
+{
+    hipEvent_t e = nullptr;
+    return fail (hipEventCreateWithFlags (&e, hipEventDisableTiming), "hipEventCreate") ? nullptr : (void *) e;
+}
+int arthip_stream_wait_event (void *st, void *ev) { return fail (hipStreamWaitEvent ((hipStream_t) st, (hipEvent_t) ev, 0), "hipStreamWaitEvent"); }
+int arthip_event_sync (void *ev) { return fail (hipEventSynchronize ((hipEvent_t) ev), "hipEventSynchronize"); }
+
+// let `device` read and write memory that lives on `peer` (xGMI); harmless when already enabled or impossible
+void arthip_enable_peer (int device, int peer)
+{
+    int can = 0, prev = 0;
+    if (device == peer || hipDeviceCanAccessPeer (&can, device, peer) != hipSuccess || !can) return;
+    if (hipGetDevice (&prev) != hipSuccess) return;
+    if (hipSetDevice (device) == hipSuccess) { (void) hipDeviceEnablePeerAccess (peer, 0); (void) hipGetLastError (); }
+    (void) hipSetDevice (prev);
+}
+
 void *arthip_event_create (void)
 {
     // timing events: no system-scope fence when they fire (nothing on the host reads device memory off them), which

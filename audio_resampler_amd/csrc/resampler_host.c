@@ -24,9 +24,23 @@
 
 #define HIST_FRAMES(T) ((T) + (T) / 2)      /* frames of history kept in HBM between calls */
 
+/* host-pointer calls up to this many bytes (in + out) go through page-locked staging buffers (one dense DMA each way, no
+ * bounce through the runtime's own buffers); larger ones are copied straight from / to the caller's memory */
+#define STAGE_LIMIT ((size_t) 8 << 20)          /* (environment ARTAMD_STAGE_LIMIT=bytes overrides: tests force either path) */
+
 struct BankEntry;
 struct artamd_resampler {
+    int device;                             /* HIP device this context lives on (made current around every call) */
     void *stream;
+    int own_stream;                         /* the stream was created by the library (shards of a sharded context) */
+    /* a sharded context (RESAMPLE_MULTITHREADED with several devices / ARTAMD_SHARDS): no device state of its own, its
+     * channels are spread over `nshards` ordinary contexts that run side by side (reference resampler.c:442-470 fans the
+     * channels of ONE context out to worker threads; here to devices) */
+    int nshards;
+    Resample **shards;
+    int *shard_first;                       /* first channel of each shard (nshards + 1 entries) */
+    void *ev_parent, **ev_shard;            /* ordering events of the device-pointer calls */
+    art_s *h_in, *h_out; size_t h_in_cap, h_out_cap;     /* page-locked staging of the host-pointer calls */
     struct BankEntry *bank;                 /* shared filter bank (bank_acquire / bank_release) */
     art_s *d_bank;                          /* = bank->dev */
     art_s *d_hist [2];                      /* ping-pong history, HIST x C interleaved */
@@ -113,8 +127,19 @@ void artamdBuildFilterBank (int T, int F, double lowpass, int flags, artsample_t
  * counts and the carried position are bit-identical to the loop.
  * ---------------------------------------------------------------------------------------- */
 
+static int plan_call (ArtamdPosition *p, int nIn, int cap, double ratio, ResampleResult *result,
+                      ArtamdSegment *segs, int max_segs, int *lin_floor_out, int keep_offset);
+
 int artamdPlanCall (ArtamdPosition *p, int nIn, int cap, double ratio, ResampleResult *result,
                     ArtamdSegment *segs, int max_segs, int *lin_floor_out)
+{
+    return plan_call (p, nIn, cap, ratio, result, segs, max_segs, lin_floor_out, 0);
+}
+
+/* keep_offset: the call is the silent first part of a caller's call that the library split in two (consume_silently): the
+ * end-of-call re-quantisation of the position (resampler.c:533-535) belongs to the second part only */
+static int plan_call (ArtamdPosition *p, int nIn, int cap, double ratio, ResampleResult *result,
+                      ArtamdSegment *segs, int max_segs, int *lin_floor_out, int keep_offset)
 {
     const int T = p->numTaps, half = T / 2, ring = 16 * T, drop = 15 * T;
     double base = p->outputOffset;
@@ -193,7 +218,7 @@ int artamdPlanCall (ArtamdPosition *p, int nIn, int cap, double ratio, ResampleR
 
     base += made ? (double) made / ratio : 0.0;
 
-    if (flags & RESAMPLER_SNAP_OFFSET)
+    if ((flags & RESAMPLER_SNAP_OFFSET) && !keep_offset)
         base = floor (base) + floor ((base - floor (base)) * p->numFilters + 0.5) / p->numFilters;
 
     p->outputOffset = base; p->inputIndex = wp; p->flags = flags;
@@ -236,6 +261,88 @@ static void *grow (void *dev, size_t *cap, size_t need)
     *cap = dev ? want : 0;
     return dev;
 }
+
+static void *grow_pinned (void *host, size_t *cap, size_t need)
+{
+    if (need <= *cap) return host;
+    arthip_host_free (host);
+    size_t want = need + need / 2 + 4096;
+    host = arthip_host_alloc (want);
+    *cap = host ? want : 0;
+    return host;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Devices.  An ordinary context lives on the HIP device that is current when it is created and makes that device current
+ * around every call it serves, whatever the calling thread had selected.  A context created with RESAMPLE_MULTITHREADED
+ * spreads its channels over the devices of this list (artamdSetDevices, or environment ARTAMD_DEVICES="0,1,2,3"; default:
+ * every visible device) — the reference's one-worker-per-channel fan-out (resampler.c:185-186, :442-470) with GPUs for
+ * threads.  ARTAMD_SHARDS=n forces the number of shards (several shards per device, or sharding on a single device: the
+ * way the path is tested on a one-GPU box).
+ * ---------------------------------------------------------------------------------------- */
+#define MAX_DEVICES 64
+static int dev_list [MAX_DEVICES], dev_count = -1;        /* -1: not resolved yet */
+static pthread_mutex_t dev_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static void resolve_devices (void)
+{
+    const int visible = arthip_device_count ();
+    const char *env = getenv ("ARTAMD_DEVICES");
+
+    dev_count = 0;
+    if (env && *env) {
+        while (*env && dev_count < MAX_DEVICES) {
+            char *end;
+            long d = strtol (env, &end, 10);
+            if (end == env) break;
+            if (d >= 0 && d < visible) dev_list [dev_count++] = (int) d;
+            else fprintf (stderr, "artamd: ARTAMD_DEVICES names device %ld, %d visible: ignored\n", d, visible);
+            env = (*end == ',') ? end + 1 : end;
+        }
+    }
+    if (!dev_count)
+        for (int d = 0; d < visible && d < MAX_DEVICES; ++d) dev_list [dev_count++] = d;
+}
+
+int artamdSetDevices (const int *devices, int count)
+{
+    const int visible = arthip_device_count ();
+    int rc = 0;
+
+    pthread_mutex_lock (&dev_lock);
+    if (count <= 0 || !devices) resolve_devices ();
+    else {
+        for (int i = 0; i < count; ++i)
+            if (devices [i] < 0 || devices [i] >= visible) rc = -1;
+        if (!rc) {
+            dev_count = count < MAX_DEVICES ? count : MAX_DEVICES;
+            for (int i = 0; i < dev_count; ++i) dev_list [i] = devices [i];
+        }
+    }
+    pthread_mutex_unlock (&dev_lock);
+    return rc;
+}
+
+/* how many shards a RESAMPLE_MULTITHREADED context of `channels` channels gets (0 or 1: an ordinary context) and on which
+ * device shard s lives */
+static int shard_plan (int channels, int *devices_out)
+{
+    pthread_mutex_lock (&dev_lock);
+    if (dev_count < 0) resolve_devices ();
+    int n = dev_count > 1 ? dev_count : 0;
+    const char *env = getenv ("ARTAMD_SHARDS");
+    if (env && *env) n = atoi (env);
+    if (n > channels) n = channels;
+    if (n > MAX_DEVICES) n = MAX_DEVICES;
+    for (int s = 0; s < n; ++s) devices_out [s] = dev_count ? dev_list [s % dev_count] : 0;
+    pthread_mutex_unlock (&dev_lock);
+    return n;
+}
+
+/* make a context's device current for the duration of a call; restored afterwards */
+#define ENTER_DEVICE(hip) const int prev_device_ = arthip_current_device (); \
+                          if (prev_device_ != (hip)->device) arthip_set_device ((hip)->device)
+#define LEAVE_DEVICE(hip) do { if (prev_device_ != (hip)->device && prev_device_ >= 0) arthip_set_device (prev_device_); } while (0)
 
 /* ------------------------------------------------------------------------------------------
  * Filter banks are shared: a service opens thousands of contexts with a handful of presets, a bank is up to 4 MB of HBM
@@ -288,6 +395,123 @@ static void bank_release (BankEntry *e)
     pthread_mutex_unlock (&bank_lock);
 }
 
+/* an ordinary context on the current device (parameters already validated, lowpassRatio normalised) */
+static Resample *init_leaf (int numChannels, int numTaps, int numFilters, double lowpassRatio, int flags, int private_stream)
+{
+    Resample *cxt = calloc (1, sizeof (Resample));
+    struct artamd_resampler *hip = calloc (1, sizeof (*hip));
+    const size_t bank_count = (size_t)(numFilters + 1) * numTaps;
+    const size_t hist_bytes = sizeof (art_s) * (size_t) HIST_FRAMES (numTaps) * numChannels;
+
+    if (!cxt || !hip) {
+        fprintf (stderr, "artamd: out of memory\n");
+        free (cxt); free (hip);
+        return NULL;
+    }
+
+    cxt->hip = hip;
+    cxt->numChannels = numChannels;
+    cxt->numSamples = numTaps * 16;
+    cxt->numFilters = numFilters;
+    cxt->numTaps = numTaps;
+    cxt->flags = flags;
+    cxt->lowpassRatio = lowpassRatio;
+    cxt->outputOffset = numTaps / 2;
+    cxt->inputIndex = numTaps;
+    hip->device = arthip_current_device ();
+    if (private_stream) { hip->stream = arthip_stream_create (); hip->own_stream = hip->stream != NULL; }
+
+    /* the bank: shared on the device, a private host copy exposed through the reference's `filters` row-pointer table */
+    hip->bank = bank_acquire (numTaps, numFilters, lowpassRatio, flags);
+    art_s *bank = malloc (sizeof (art_s) * bank_count);
+    cxt->filters = malloc (sizeof (art_s *) * (size_t)(numFilters + 1));
+    if (!hip->bank || !bank || !cxt->filters) {
+        fprintf (stderr, "artamd: filter bank allocation failed: %s\n", arthip_last_error ());
+        free (bank); free (cxt->filters); cxt->filters = NULL;
+        resampleFree (cxt);
+        return NULL;
+    }
+    memcpy (bank, hip->bank->host, sizeof (art_s) * bank_count);
+    for (int f = 0; f <= numFilters; ++f)
+        cxt->filters [f] = bank + (size_t) f * numTaps;
+
+    hip->d_bank = hip->bank->dev;
+    hip->d_hist [0] = arthip_malloc (hist_bytes);
+    hip->d_hist [1] = arthip_malloc (hist_bytes);
+    hip->seg_cap = 64;
+    hip->segs = malloc (sizeof (ArtamdSegment) * hip->seg_cap);
+
+    if (!hip->d_hist [0] || !hip->d_hist [1] || !hip->segs || (private_stream && !hip->stream) ||
+        arthip_zero (hip->d_hist [0], hist_bytes, hip->stream) || arthip_zero (hip->d_hist [1], hist_bytes, hip->stream) ||
+        arthip_sync (hip->stream)) {
+        fprintf (stderr, "artamd: device allocation failed: %s\n", arthip_last_error ());
+        resampleFree (cxt);
+        return NULL;
+    }
+
+    if (flags & EXTRAPOLATE_ENDPOINTS)
+        cxt->flags |= EXTRAPOLATE_PREFILL;
+
+    return cxt;
+}
+
+/* a sharded context: `count` ordinary contexts on devices [s], each with a contiguous channel slice and its own stream */
+static Resample *init_sharded (int numChannels, int numTaps, int numFilters, double lowpassRatio, int flags, int count, const int *devices)
+{
+    Resample *cxt = calloc (1, sizeof (Resample));
+    struct artamd_resampler *hip = calloc (1, sizeof (*hip));
+    const int prev = arthip_current_device ();
+
+    if (!cxt || !hip) { free (cxt); free (hip); return NULL; }
+    cxt->hip = hip;
+    cxt->numChannels = numChannels;
+    cxt->numSamples = numTaps * 16;
+    cxt->numFilters = numFilters;
+    cxt->numTaps = numTaps;
+    cxt->flags = flags;
+    cxt->lowpassRatio = lowpassRatio;
+    cxt->outputOffset = numTaps / 2;
+    cxt->inputIndex = numTaps;
+    hip->device = prev;                                  /* device-pointer calls: where the caller's buffers are expected */
+    hip->shards = calloc ((size_t) count, sizeof (Resample *));
+    hip->shard_first = calloc ((size_t) count + 1, sizeof (int));
+    hip->ev_shard = calloc ((size_t) count, sizeof (void *));
+    hip->ev_parent = arthip_order_event_create ();
+    int ok = hip->shards && hip->shard_first && hip->ev_shard && hip->ev_parent;
+
+    /* contiguous, balanced channel slices: the first (channels % count) shards get one channel more */
+    const int base = numChannels / count, extra = numChannels % count;
+    for (int s = 0; ok && s < count; ++s) {
+        const int width = base + (s < extra ? 1 : 0);
+        hip->shard_first [s + 1] = hip->shard_first [s] + width;
+        arthip_set_device (devices [s]);
+        arthip_enable_peer (devices [s], prev);          /* planar device-pointer calls read the caller's buffers in place */
+        hip->shards [s] = init_leaf (width, numTaps, numFilters, lowpassRatio, flags & ~RESAMPLE_MULTITHREADED, 1);
+        hip->ev_shard [s] = arthip_order_event_create ();
+        hip->nshards = s + 1;
+        ok = hip->shards [s] && hip->ev_shard [s];
+    }
+    if (prev >= 0) arthip_set_device (prev);
+
+    if (ok) {       /* `filters`: a private copy of the rows, as in every context */
+        const size_t bank_count = (size_t)(numFilters + 1) * numTaps;
+        art_s *bank = malloc (sizeof (art_s) * bank_count);
+        cxt->filters = malloc (sizeof (art_s *) * (size_t)(numFilters + 1));
+        if (bank && cxt->filters) {
+            memcpy (bank, hip->shards [0]->filters [0], sizeof (art_s) * bank_count);
+            for (int f = 0; f <= numFilters; ++f) cxt->filters [f] = bank + (size_t) f * numTaps;
+        }
+        else { free (bank); free (cxt->filters); cxt->filters = NULL; ok = 0; }
+    }
+    if (!ok) {
+        fprintf (stderr, "artamd: sharded context: allocation failed: %s\n", arthip_last_error ());
+        resampleFree (cxt);
+        return NULL;
+    }
+    cxt->flags = hip->shards [0]->flags | RESAMPLE_MULTITHREADED;
+    return cxt;
+}
+
 Resample *resampleInit (int numChannels, int numTaps, int numFilters, double lowpassRatio, int flags)
 {
     if (lowpassRatio > 0.0 && lowpassRatio < 1.0)
@@ -319,53 +543,14 @@ Resample *resampleInit (int numChannels, int numTaps, int numFilters, double low
 
     { const char *env = getenv ("ARTAMD_STRICT"); if (env && *env && *env != '0') flags |= RESAMPLE_STRICT_ORDER; }
 
-    Resample *cxt = calloc (1, sizeof (Resample));
-    struct artamd_resampler *hip = calloc (1, sizeof (*hip));
-    const size_t bank_count = (size_t)(numFilters + 1) * numTaps;
-    const size_t hist_bytes = sizeof (art_s) * (size_t) HIST_FRAMES (numTaps) * numChannels;
-
-    cxt->hip = hip;
-    cxt->numChannels = numChannels;
-    cxt->numSamples = numTaps * 16;
-    cxt->numFilters = numFilters;
-    cxt->numTaps = numTaps;
-    cxt->flags = flags;
-    cxt->lowpassRatio = lowpassRatio;
-    cxt->outputOffset = numTaps / 2;
-    cxt->inputIndex = numTaps;
-
-    /* the bank: shared on the device, a private host copy exposed through the reference's `filters` row-pointer table */
-    hip->bank = bank_acquire (numTaps, numFilters, lowpassRatio, flags);
-    art_s *bank = malloc (sizeof (art_s) * bank_count);
-    cxt->filters = malloc (sizeof (art_s *) * (size_t)(numFilters + 1));
-    if (!hip->bank || !bank || !cxt->filters) {
-        fprintf (stderr, "artamd: filter bank allocation failed: %s\n", arthip_last_error ());
-        free (bank); free (cxt->filters); cxt->filters = NULL;
-        resampleFree (cxt);
-        return NULL;
-    }
-    memcpy (bank, hip->bank->host, sizeof (art_s) * bank_count);
-    for (int f = 0; f <= numFilters; ++f)
-        cxt->filters [f] = bank + (size_t) f * numTaps;
-
-    hip->d_bank = hip->bank->dev;
-    hip->d_hist [0] = arthip_malloc (hist_bytes);
-    hip->d_hist [1] = arthip_malloc (hist_bytes);
-    hip->seg_cap = 64;
-    hip->segs = malloc (sizeof (ArtamdSegment) * hip->seg_cap);
-
-    if (!hip->d_hist [0] || !hip->d_hist [1] ||
-        arthip_zero (hip->d_hist [0], hist_bytes, NULL) || arthip_zero (hip->d_hist [1], hist_bytes, NULL) ||
-        arthip_sync (NULL)) {
-        fprintf (stderr, "artamd: device allocation failed: %s\n", arthip_last_error ());
-        resampleFree (cxt);
-        return NULL;
+    if ((flags & RESAMPLE_MULTITHREADED) && numChannels > 1) {
+        int devices [MAX_DEVICES];
+        const int count = shard_plan (numChannels, devices);
+        if (count > 1)
+            return init_sharded (numChannels, numTaps, numFilters, lowpassRatio, flags, count, devices);
     }
 
-    if (flags & EXTRAPOLATE_ENDPOINTS)
-        cxt->flags |= EXTRAPOLATE_PREFILL;
-
-    return cxt;
+    return init_leaf (numChannels, numTaps, numFilters, lowpassRatio, flags, 0);
 }
 
 static unsigned long gcd_of (unsigned long a, unsigned long b)
@@ -405,8 +590,11 @@ Resample *resampleFixedRatioInit (int numChannels, int numTaps, int maxFilters, 
 
     Resample *cxt = resampleInit (numChannels, numTaps, maxFilters, lowpass * ratio, flags | RESAMPLE_FIXED_RATIO);
 
-    if (cxt)
+    if (cxt) {
         cxt->fixedRatio = destinRate / sourceRate;
+        for (int k = 0; k < cxt->hip->nshards; ++k)
+            cxt->hip->shards [k]->fixedRatio = cxt->fixedRatio;
+    }
 
     return cxt;
 }
@@ -418,10 +606,20 @@ void resampleFree (Resample *cxt)
     struct artamd_resampler *hip = cxt->hip;
 
     if (hip) {
-        arthip_sync (hip->stream);
+        for (int k = 0; k < hip->nshards; ++k) {
+            resampleFree (hip->shards [k]);
+            arthip_event_destroy (hip->ev_shard [k]);
+        }
+        ENTER_DEVICE (hip);
+        if (!hip->shards) arthip_sync (hip->stream);
+        arthip_event_destroy (hip->ev_parent);
+        free (hip->shards); free (hip->shard_first); free (hip->ev_shard);
         bank_release (hip->bank); arthip_free (hip->d_hist [0]); arthip_free (hip->d_hist [1]);
         arthip_free (hip->d_in); arthip_free (hip->d_out); arthip_free (hip->d_tmp); arthip_free (hip->d_fix); arthip_free (hip->d_scratch); arthip_free (hip->d_patch); arthip_free (hip->d_batch);
+        arthip_host_free (hip->h_in); arthip_host_free (hip->h_out);
         for (int i = 0; i < hip->ev_cap; ++i) arthip_event_destroy (hip->ev [i]);
+        if (hip->own_stream) arthip_stream_destroy (hip->stream);
+        LEAVE_DEVICE (hip);
         free (hip->ev);
         free (hip->segs);
         free (hip);
@@ -434,10 +632,17 @@ void resampleFree (Resample *cxt)
 void resampleReset (Resample *cxt)
 {
     struct artamd_resampler *hip = cxt->hip;
-    const size_t hist_bytes = sizeof (art_s) * (size_t) HIST_FRAMES (cxt->numTaps) * cxt->numChannels;
 
-    arthip_zero (hip->d_hist [0], hist_bytes, hip->stream);
-    arthip_zero (hip->d_hist [1], hist_bytes, hip->stream);
+    for (int k = 0; k < hip->nshards; ++k)
+        resampleReset (hip->shards [k]);
+
+    if (!hip->nshards) {
+        const size_t hist_bytes = sizeof (art_s) * (size_t) HIST_FRAMES (cxt->numTaps) * cxt->numChannels;
+        ENTER_DEVICE (hip);
+        arthip_zero (hip->d_hist [0], hist_bytes, hip->stream);
+        arthip_zero (hip->d_hist [1], hist_bytes, hip->stream);
+        LEAVE_DEVICE (hip);
+    }
     hip->floor_active = 0;
     cxt->outputOffset = cxt->numTaps / 2;
     cxt->inputIndex = cxt->numTaps;
@@ -463,8 +668,11 @@ void resampleAdvancePosition (Resample *cxt, double delta)
         fprintf (stderr, "resampleAdvancePosition() can only advance forward!\n");
     else if (!(cxt->flags & SUBSAMPLE_INTERPOLATE) && floor (delta) != delta)
         fprintf (stderr, "resampleAdvancePosition() cannot advance partial samples without interpolation!\n");
-    else
+    else {
         cxt->outputOffset += delta;
+        for (int k = 0; k < cxt->hip->nshards; ++k)      /* the same addition on the same value: the shards stay in step */
+            cxt->hip->shards [k]->outputOffset += delta;
+    }
 }
 
 /* Dry runs.  These step the position by repeated addition of 1/ratio (reference resampler.c:874, :912)
@@ -517,24 +725,76 @@ unsigned int resampleGetExpectedOutput (Resample *cxt, int numInputFrames, doubl
  * Processing
  * ---------------------------------------------------------------------------------------- */
 
-void resampleHipSetStream (Resample *cxt, void *stream) { cxt->hip->stream = stream; }
-void resampleHipSynchronize (Resample *cxt) { arthip_sync (cxt->hip->stream); }
-void resampleHipSetKernel (Resample *cxt, int which) { cxt->hip->kernel_pref = which; }
+/* Work already enqueued on the old stream (history ping-pong, matrix-path scratch, staging) must not race with what the
+ * next call puts on the new one: the old stream is drained before the swap. */
+void resampleHipSetStream (Resample *cxt, void *stream)
+{
+    struct artamd_resampler *hip = cxt->hip;
+    if (hip->stream == stream) return;
+    ENTER_DEVICE (hip);
+    if (!hip->nshards) arthip_sync (hip->stream);
+    if (hip->own_stream) { arthip_stream_destroy (hip->stream); hip->own_stream = 0; }
+    hip->stream = stream;
+    LEAVE_DEVICE (hip);
+}
+
+void resampleHipSynchronize (Resample *cxt)
+{
+    struct artamd_resampler *hip = cxt->hip;
+    for (int k = 0; k < hip->nshards; ++k) resampleHipSynchronize (hip->shards [k]);
+    ENTER_DEVICE (hip);
+    arthip_sync (hip->stream);
+    LEAVE_DEVICE (hip);
+}
+
+void resampleHipSetKernel (Resample *cxt, int which)
+{
+    cxt->hip->kernel_pref = which;
+    for (int k = 0; k < cxt->hip->nshards; ++k) resampleHipSetKernel (cxt->hip->shards [k], which);
+}
+
+int resampleHipGetDevice (Resample *cxt) { return cxt->hip->device; }
+int resampleHipNumShards (Resample *cxt) { return cxt->hip->nshards; }
+
+int resampleHipShardInfo (Resample *cxt, int shard, int *device, int *firstChannel, int *numChannels)
+{
+    struct artamd_resampler *hip = cxt->hip;
+    if (shard < 0 || shard >= hip->nshards) return -1;
+    if (device) *device = hip->shards [shard]->hip->device;
+    if (firstChannel) *firstChannel = hip->shard_first [shard];
+    if (numChannels) *numChannels = hip->shard_first [shard + 1] - hip->shard_first [shard];
+    return 0;
+}
 
 void resampleHipSetTiming (Resample *cxt, int enable)
 {
     struct artamd_resampler *hip = cxt->hip;
     hip->timing = enable;
     hip->ev_count = 0;
+    for (int k = 0; k < hip->nshards; ++k) resampleHipSetTiming (hip->shards [k], enable);
 }
 
+/* a sharded context reports its slowest shard (the shards run side by side) */
 double resampleHipReadTiming (Resample *cxt, int *numLaunches)
 {
     struct artamd_resampler *hip = cxt->hip;
     double total = 0.0;
+    if (hip->nshards) {
+        int launches = 0;
+        for (int k = 0; k < hip->nshards; ++k) {
+            int n = 0;
+            const double ms = resampleHipReadTiming (hip->shards [k], &n);
+            if (ms > total) total = ms;
+            if (n > launches) launches = n;
+        }
+        if (numLaunches) *numLaunches = launches;
+        return total;
+    }
+    ENTER_DEVICE (hip);
     arthip_sync (hip->stream);
     for (int i = 0; i + 1 < hip->ev_count; i += 2)
         total += arthip_event_elapsed_ms (hip->ev [i], hip->ev [i + 1]);
+    LEAVE_DEVICE (hip);
     if (numLaunches) *numLaunches = hip->ev_count / 2;
     hip->ev_count = 0;
     return total;
@@ -543,22 +803,32 @@ double resampleHipReadTiming (Resample *cxt, int *numLaunches)
 static void *timing_event (struct artamd_resampler *hip)
 {
     if (hip->ev_count == hip->ev_cap) {
-        int cap = hip->ev_cap ? hip->ev_cap * 2 : 64;
-        hip->ev = realloc (hip->ev, sizeof (void *) * cap);
+        const int cap = hip->ev_cap ? hip->ev_cap * 2 : 64;
+        void **grown = realloc (hip->ev, sizeof (void *) * cap);
+        if (!grown) return NULL;
+        hip->ev = grown;
         for (int i = hip->ev_cap; i < cap; ++i) hip->ev [i] = arthip_event_create ();
         hip->ev_cap = cap;
     }
     return hip->ev [hip->ev_count++];
 }
-int  resampleHipLastKernel (Resample *cxt) { return cxt->hip->last_kernel; }
+
+int  resampleHipLastKernel (Resample *cxt) { return cxt->hip->nshards ? cxt->hip->shards [0]->hip->last_kernel : cxt->hip->last_kernel; }
 
 /* outputs the matrix kernels have evaluated off their canonical pattern so far (synchronises) */
 unsigned int resampleHipLastHandedBack (Resample *cxt)
 {
+    struct artamd_resampler *hip = cxt->hip;
     unsigned int n = 0;
-    if (!cxt->hip->d_fix) return 0;
-    arthip_d2h (&n, cxt->hip->d_fix + 1, sizeof (n), cxt->hip->stream);      /* running total since context creation */
-    arthip_sync (cxt->hip->stream);
+    if (hip->nshards) {
+        for (int k = 0; k < hip->nshards; ++k) n += resampleHipLastHandedBack (hip->shards [k]);
+        return n;
+    }
+    if (!hip->d_fix) return 0;
+    ENTER_DEVICE (hip);
+    arthip_d2h (&n, hip->d_fix + 1, sizeof (n), hip->stream);      /* running total since context creation */
+    arthip_sync (hip->stream);
+    LEAVE_DEVICE (hip);
     return n;
 }
 
@@ -626,14 +896,23 @@ static void prefill_history (Resample *cxt, const art_s *d_in, long in_pitch)
     free (planes); free (older); free (patch);
 }
 
-/* Forward extrapolation of half a window at flush time; returns a device buffer of T/2 frames x C. */
-static const art_s *flush_tail (Resample *cxt)
+/* Forward extrapolation of half a window at flush time; returns a device buffer of T/2 frames x C.  *tail_out (optional)
+ * receives the same samples on the host, planar [c][T/2] (caller frees). */
+static const art_s *flush_tail (Resample *cxt, art_s **tail_out)
 {
     struct artamd_resampler *hip = cxt->hip;
     const int T = cxt->numTaps, C = cxt->numChannels, H = HIST_FRAMES (T), half = T / 2;
     art_s *planes = malloc (sizeof (art_s) * (size_t) half * C);
     art_s *work = malloc (sizeof (art_s) * (size_t) T);
     art_s *patch = malloc (sizeof (art_s) * (size_t) half * C);
+    art_s *tail = tail_out ? malloc (sizeof (art_s) * (size_t) half * C) : NULL;
+
+    if (tail_out) *tail_out = NULL;
+    if (!planes || !work || !patch || (tail_out && !tail)) {
+        fprintf (stderr, "artamd: out of memory (end-point extrapolation)\n");
+        free (planes); free (work); free (patch); free (tail);
+        return NULL;
+    }
 
     gather_linear (cxt, NULL, 0, H - half, half, planes);
 
@@ -642,6 +921,7 @@ static const art_s *flush_tail (Resample *cxt)
         art_extrapolate_forward (work, half, half);
         for (int f = 0; f < half; ++f)
             patch [(size_t) f * C + c] = work [half + f];
+        if (tail) memcpy (tail + (size_t) c * half, work + half, sizeof (art_s) * (size_t) half);
     }
 
     hip->d_patch = grow (hip->d_patch, &hip->patch_cap, sizeof (art_s) * (size_t) half * C);
@@ -650,7 +930,70 @@ static const art_s *flush_tail (Resample *cxt)
         arthip_sync (hip->stream);
     }
     free (planes); free (work); free (patch);
+    if (tail_out) *tail_out = tail;
     return hip->d_patch;
+}
+
+/* The stream's FIRST output is produced by the flush call itself (fewer than T/2 frames ever arrived): the reference's
+ * prefill then runs after the postfill (resampler.c:775-791 then :812-819) over the real samples ++ the flush tail.
+ * inputIndex is the value BEFORE the flush; `tail` = flush_tail's host copy, planar [c][T/2]. */
+static void prefill_at_flush (Resample *cxt, const art_s *tail)
+{
+    struct artamd_resampler *hip = cxt->hip;
+    const int T = cxt->numTaps, C = cxt->numChannels, H = HIST_FRAMES (T), half = T / 2;
+    const int real = cxt->inputIndex - T, known = real + half, extra = T - known;
+
+    if (real < 0 || known < 8 || extra <= 0) return;                     /* reference resampler.c:695 / :815 */
+
+    art_s *samples = malloc (sizeof (art_s) * (size_t) known * C);       /* planar [c][known], oldest first */
+    art_s *recent = malloc (sizeof (art_s) * (size_t)(real ? real : 1) * C);
+    art_s *older = malloc (sizeof (art_s) * (size_t) extra);
+    art_s *patch = malloc (sizeof (art_s) * (size_t) extra * C);
+    if (!samples || !recent || !older || !patch) {
+        fprintf (stderr, "artamd: out of memory (end-point extrapolation)\n");
+        free (samples); free (recent); free (older); free (patch);
+        return;
+    }
+
+    if (real) gather_linear (cxt, NULL, 0, H - real, real, recent);      /* ring [T, inputIndex) = the newest `real` history frames */
+
+    for (int c = 0; c < C; ++c) {
+        memcpy (samples + (size_t) c * known, recent + (size_t) c * real, sizeof (art_s) * (size_t) real);
+        memcpy (samples + (size_t) c * known + real, tail + (size_t) c * half, sizeof (art_s) * (size_t) half);
+        art_extrapolate_backward (samples + (size_t) c * known, known, older, extra);
+        for (int e = 0; e < extra; ++e)                                  /* older[e] is ring index T-1-e */
+            patch [(size_t)(extra - 1 - e) * C + c] = older [e];
+    }
+
+    /* ring [known, T) = linear [H - inputIndex + known, H - inputIndex + T) = [T, H - real): inside the history */
+    arthip_h2d (hip->d_hist [hip->cur] + (size_t)(H - cxt->inputIndex + known) * C, patch, sizeof (art_s) * (size_t) extra * C, hip->stream);
+    arthip_sync (hip->stream);
+    free (samples); free (recent); free (older); free (patch);
+}
+
+static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pitch, int nIn,
+                                    art_s *d_out, long out_pitch, int cap, double ratio);
+
+/* The first `frames` input frames of a call go into the history without any output being due (the caller established
+ * that): position and ring epoch advance exactly as the reference's loop would have advanced them. */
+static int consume_silently (Resample *cxt, const art_s *d_in, long in_pitch, int frames, double ratio)
+{
+    struct artamd_resampler *hip = cxt->hip;
+    const int T = cxt->numTaps, C = cxt->numChannels, H = HIST_FRAMES (T);
+    ArtamdPosition pos;
+    ResampleResult res;
+    int lin_floor;
+
+    pos.numTaps = T; pos.numFilters = cxt->numFilters; pos.flags = cxt->flags; pos.inputIndex = cxt->inputIndex;
+    pos.floorActive = hip->floor_active; pos.outputOffset = cxt->outputOffset; pos.fixedRatio = cxt->fixedRatio;
+    plan_call (&pos, frames, 1, ratio, &res, NULL, 0, &lin_floor, 1);
+    if (res.output_generated || (int) res.input_used != frames) return -1;
+
+    if (arthip_roll_history (hip->d_hist [hip->cur ^ 1], hip->d_hist [hip->cur], d_in, in_pitch, frames, H, C, hip->stream)) return -1;
+    hip->cur ^= 1;
+    cxt->outputOffset = pos.outputOffset; cxt->inputIndex = pos.inputIndex;
+    hip->floor_active = pos.floorActive;
+    return 0;
 }
 
 /* Plan one call, enqueue the FIR launches and the history roll.  `d_in` holds the call's input on
@@ -670,12 +1013,32 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
     const int is_flush = nIn < 0 && !(cxt->flags & RESAMPLER_FLUSHED);
     const double eff_ratio = (cxt->flags & RESAMPLE_FIXED_RATIO) ? cxt->fixedRatio : ratio;
 
+    /* EXTRAPOLATE_ENDPOINTS, first output of the stream only after the ring has rewound (the position was advanced by more
+     * than 15 T): the reference extrapolates backwards from the samples that arrived SINCE the rewind, over the history
+     * (resampler.c:812-819 with the ring's inputIndex).  Everything before the frame that makes output 0 possible is
+     * consumed silently first; the rest of the call then starts inside the right ring epoch and prefills as usual. */
+    if ((cxt->flags & EXTRAPOLATE_PREFILL) && !is_flush && nIn > 1 && cap > 0 && !(cxt->flags & RESAMPLER_FLUSHED)) {
+        ResampleResult one;
+        trial = pos;
+        if (plan_call (&trial, nIn, 1, ratio, &one, NULL, 0, &lin_floor, 1) >= 2 && one.output_generated == 1 && one.input_used >= 2) {
+            const int lead = (int) one.input_used - 1;
+            if (consume_silently (cxt, d_in, in_pitch, lead, ratio)) {
+                fprintf (stderr, "artamd: end-point extrapolation: could not advance to the first output: %s\n", arthip_last_error ());
+                return res;
+            }
+            res = enqueue_call (cxt, in_pitch ? d_in + lead : d_in + (size_t) lead * C, in_pitch, nIn - lead, d_out, out_pitch, cap, ratio);
+            res.input_used += (unsigned int) lead;
+            return res;
+        }
+    }
+
     for (;;) {
         trial = pos;
         nseg = artamdPlanCall (&trial, nIn, cap, ratio, &res, hip->segs, hip->seg_cap, &lin_floor);
         if (nseg <= hip->seg_cap) break;
-        hip->seg_cap = nseg + 16;
-        hip->segs = realloc (hip->segs, sizeof (ArtamdSegment) * hip->seg_cap);
+        ArtamdSegment *grown = realloc (hip->segs, sizeof (ArtamdSegment) * (size_t)(nseg + 16));
+        if (!grown) { fprintf (stderr, "artamd: out of memory (segment table)\n"); res.input_used = res.output_generated = 0; return res; }
+        hip->segs = grown; hip->seg_cap = nseg + 16;
     }
 
     if (eff_ratio != hip->period_ratio) {
@@ -688,13 +1051,20 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
     int rolled = 0;
 
     if (cxt->flags & EXTRAPOLATE_ENDPOINTS) {
-        /* prefill: first output of the stream, produced by an ordinary call whose first output precedes any
-         * ring rewind (streams that emit nothing until a flush, or only after 15*T frames, start from silence) */
-        if ((cxt->flags & EXTRAPOLATE_PREFILL) && res.output_generated && !(nIn < 0) &&
-            (nseg == 1 || hip->segs [1].first_output > 0))
-            prefill_history (cxt, d_in, in_pitch);
-        if (is_flush)
-            flush_in = flush_tail (cxt);
+        /* prefill just before the first output of the stream (resampler.c:812-819), whichever call produces it: an
+         * ordinary call (a rewind right in front of output 0 leaves one known sample: nothing to extrapolate from), a
+         * flush continued after it was cut short, or — below — the flush call itself */
+        const int first_now = (cxt->flags & EXTRAPOLATE_PREFILL) && res.output_generated;
+        if (first_now && !is_flush && (nseg == 1 || hip->segs [1].first_output > 0))
+            prefill_history (cxt, nIn > 0 ? d_in : NULL, in_pitch);
+        if (is_flush) {
+            art_s *tail = NULL;
+            flush_in = flush_tail (cxt, first_now ? &tail : NULL);
+            /* (a flush that had to rewind the ring first leaves more than T known samples: nothing to prefill) */
+            if (first_now && tail && trial.inputIndex == cxt->inputIndex + T / 2)
+                prefill_at_flush (cxt, tail);
+            free (tail);
+        }
     }
 
     if (res.output_generated) {
@@ -792,7 +1162,7 @@ static int batch_plan (Resample *cxt, const art_s *d_in, int nIn, art_s *d_out, 
     ArtamdPosition pos;
     int lin_floor, nseg;
 
-    if (nIn < 0 || hip->stream != lead_stream || hip->timing ||
+    if (nIn < 0 || hip->stream != lead_stream || hip->timing || hip->nshards || hip->device != arthip_current_device () ||
         (cxt->flags & (EXTRAPOLATE_ENDPOINTS | RESAMPLE_STRICT_ORDER | RESAMPLER_FLUSHED))) return 0;
 
     pos.numTaps = T; pos.numFilters = cxt->numFilters; pos.flags = cxt->flags; pos.inputIndex = cxt->inputIndex;
@@ -803,8 +1173,9 @@ static int batch_plan (Resample *cxt, const art_s *d_in, int nIn, art_s *d_out, 
         *trial = pos;
         nseg = artamdPlanCall (trial, nIn, cap, ratio, res, hip->segs, hip->seg_cap, &lin_floor);
         if (nseg <= hip->seg_cap) break;
-        hip->seg_cap = nseg + 16;
-        hip->segs = realloc (hip->segs, sizeof (ArtamdSegment) * hip->seg_cap);
+        ArtamdSegment *grown = realloc (hip->segs, sizeof (ArtamdSegment) * (size_t)(nseg + 16));
+        if (!grown) return 0;                                 /* (the one-by-one path reports it) */
+        hip->segs = grown; hip->seg_cap = nseg + 16;
     }
     if (nseg > arthip_fir_batch_max_segments () || res->output_generated == 0) return 0;
 
@@ -852,6 +1223,7 @@ int resampleProcessBatchInterleavedDevice (Resample *const *cxts, int n, const a
 {
     if (n <= 0) return 0;
     struct artamd_resampler *lead = cxts [0]->hip;
+    ENTER_DEVICE (lead);
     ArtFirArgs *args = malloc (sizeof (ArtFirArgs) * (size_t) n);
     ArtSegTable *tabs = malloc (sizeof (ArtSegTable) * (size_t) n);
     ArtamdPosition *trials = malloc (sizeof (ArtamdPosition) * (size_t) n);
@@ -873,7 +1245,7 @@ int resampleProcessBatchInterleavedDevice (Resample *const *cxts, int n, const a
                         &args [gathered], &tabs [gathered], &results [i], &trials [gathered]))
             owner [gathered++] = i;
         else
-            results [i] = enqueue_call (cxts [i], d_inputs [i], 0, numInputFrames [i], d_outputs [i], 0, numOutputFrames [i], ratios [i]);
+            results [i] = resampleProcessInterleavedDevice (cxts [i], d_inputs [i], numInputFrames [i], d_outputs [i], numOutputFrames [i], ratios [i]);
     }
 
     if (gathered) {
@@ -895,19 +1267,110 @@ int resampleProcessBatchInterleavedDevice (Resample *const *cxts, int n, const a
     rc = 0;
 out:
     free (args); free (tabs); free (trials); free (owner);
+    LEAVE_DEVICE (lead);
     return rc;
+}
+
+/* what a call would consume / produce, without touching the context */
+static ResampleResult peek_call (Resample *cxt, int nIn, int cap, double ratio)
+{
+    ResampleResult peek;
+    ArtamdPosition pos;
+    int dummy_floor;
+
+    pos.numTaps = cxt->numTaps; pos.numFilters = cxt->numFilters; pos.flags = cxt->flags; pos.inputIndex = cxt->inputIndex;
+    pos.floorActive = cxt->hip->floor_active; pos.outputOffset = cxt->outputOffset; pos.fixedRatio = cxt->fixedRatio;
+    artamdPlanCall (&pos, nIn, cap, ratio, &peek, NULL, 0, &dummy_floor);
+    return peek;
+}
+
+/* a sharded context mirrors the position of its shards (they all hold the same one) */
+static ResampleResult shards_agree (Resample *cxt, const ResampleResult *per_shard)
+{
+    struct artamd_resampler *hip = cxt->hip;
+    const Resample *first = hip->shards [0];
+    ResampleResult res = per_shard [0];
+
+    for (int k = 1; k < hip->nshards; ++k)
+        if (per_shard [k].input_used != res.input_used || per_shard [k].output_generated != res.output_generated ||
+            hip->shards [k]->inputIndex != first->inputIndex || hip->shards [k]->outputOffset != first->outputOffset) {
+            fprintf (stderr, "artamd: sharded context: shard %d disagrees with shard 0 (a launch failed?)\n", k);
+            res.input_used = res.output_generated = 0;
+        }
+    cxt->outputOffset = first->outputOffset; cxt->inputIndex = first->inputIndex;
+    cxt->flags = first->flags | RESAMPLE_MULTITHREADED;
+    return res;
+}
+
+/* Device-pointer call on a sharded context: the caller's buffers live on the context's own device; every shard pulls its
+ * channel slice (strided rows, peer-to-peer over xGMI when the shard sits on another GPU), runs, and pushes its slice of
+ * the output back.  Ordered after the context's stream, and the context's stream continues only when all shards are done.
+ * Planar buffers need no copies at all: a shard's channels are a contiguous run of planes. */
+static ResampleResult sharded_device_call (Resample *cxt, const art_s *d_in, long in_pitch, int nIn, art_s *d_out, long out_pitch,
+                                           int cap, double ratio)
+{
+    struct artamd_resampler *hip = cxt->hip;
+    const int C = cxt->numChannels, prev = arthip_current_device ();
+    const ResampleResult peek = peek_call (cxt, nIn, cap, ratio);
+    ResampleResult per_shard [MAX_DEVICES], res = { 0, 0 };
+    int failed = 0;
+
+    arthip_set_device (hip->device);
+    arthip_event_record (hip->ev_parent, hip->stream);
+
+    for (int k = 0; k < hip->nshards; ++k) {
+        Resample *sh = hip->shards [k];
+        struct artamd_resampler *sp = sh->hip;
+        const int first = hip->shard_first [k], width = sh->numChannels;
+
+        arthip_set_device (sp->device);
+        arthip_stream_wait_event (sp->stream, hip->ev_parent);
+        if (in_pitch || out_pitch)
+            per_shard [k] = enqueue_call (sh, d_in ? d_in + (size_t) first * in_pitch : NULL, in_pitch, nIn,
+                                          d_out + (size_t) first * out_pitch, out_pitch, cap, ratio);
+        else {
+            sp->d_in = grow (sp->d_in, &sp->in_cap, sizeof (art_s) * (size_t) peek.input_used * width);
+            sp->d_out = grow (sp->d_out, &sp->out_cap, sizeof (art_s) * (size_t) peek.output_generated * width);
+            if ((peek.input_used && !sp->d_in) || (peek.output_generated && !sp->d_out)) { failed = 1; per_shard [k] = res; continue; }
+            if (peek.input_used && d_in)
+                arthip_copy2d (sp->d_in, sizeof (art_s) * width, d_in + first, sizeof (art_s) * C, sizeof (art_s) * width, peek.input_used, sp->stream);
+            per_shard [k] = enqueue_call (sh, sp->d_in, 0, nIn, sp->d_out, 0, cap, ratio);
+            arthip_copy2d (d_out + first, sizeof (art_s) * C, sp->d_out, sizeof (art_s) * width, sizeof (art_s) * width,
+                           per_shard [k].output_generated, sp->stream);
+        }
+        arthip_event_record (hip->ev_shard [k], sp->stream);
+    }
+
+    arthip_set_device (hip->device);
+    for (int k = 0; k < hip->nshards; ++k)
+        arthip_stream_wait_event (hip->stream, hip->ev_shard [k]);
+    if (prev >= 0) arthip_set_device (prev);
+
+    res = shards_agree (cxt, per_shard);
+    if (failed) { fprintf (stderr, "artamd: sharded context: device allocation failed: %s\n", arthip_last_error ()); res.input_used = res.output_generated = 0; }
+    return res;
+}
+
+static ResampleResult device_call (Resample *cxt, const art_s *d_in, long in_pitch, int nIn, art_s *d_out, long out_pitch, int cap, double ratio)
+{
+    struct artamd_resampler *hip = cxt->hip;
+    if (hip->nshards) return sharded_device_call (cxt, d_in, in_pitch, nIn, d_out, out_pitch, cap, ratio);
+    ENTER_DEVICE (hip);
+    const ResampleResult res = enqueue_call (cxt, d_in, in_pitch, nIn, d_out, out_pitch, cap, ratio);
+    LEAVE_DEVICE (hip);
+    return res;
 }
 
 ResampleResult resampleProcessInterleavedDevice (Resample *cxt, const artsample_t *d_input, int numInputFrames,
                                                  artsample_t *d_output, int numOutputFrames, double ratio)
 {
-    return enqueue_call (cxt, d_input, 0, numInputFrames, d_output, 0, numOutputFrames, ratio);
+    return device_call (cxt, d_input, 0, numInputFrames, d_output, 0, numOutputFrames, ratio);
 }
 
 ResampleResult resampleProcessPlanarDevice (Resample *cxt, const artsample_t *d_input, long inputPitch, int numInputFrames,
                                             artsample_t *d_output, long outputPitch, int numOutputFrames, double ratio)
 {
-    return enqueue_call (cxt, d_input, inputPitch, numInputFrames, d_output, outputPitch, numOutputFrames, ratio);
+    return device_call (cxt, d_input, inputPitch, numInputFrames, d_output, outputPitch, numOutputFrames, ratio);
 }
 
 ResampleResult resampleProcessAndFlushInterleavedDevice (Resample *cxt, const artsample_t *d_input, int numInputFrames,
@@ -924,59 +1387,144 @@ ResampleResult resampleProcessAndFlushInterleavedDevice (Resample *cxt, const ar
     return res;
 }
 
-/* host-pointer call: how many input frames can this call consume at most / produce at most is known
- * only after planning, so plan on a scratch copy first to size the transfers */
-static ResampleResult host_call (Resample *cxt, const art_s *input, const art_s *const *planes, int nIn,
-                                 art_s *output, art_s *const *out_planes, int cap, double ratio)
+/* ------------------------------------------------------------------------------------------
+ * Host-pointer calls (what ART and artest use).  host_begin stages the call's input in HBM, enqueues the call and starts
+ * the copy back; host_end waits and delivers.  A sharded context begins on all its shards before it ends any, so the
+ * devices work side by side.  The caller's frames are `in_stride` / `out_stride` samples apart (a shard sees its channel
+ * slice of a wider stream: the de-interleaving happens on the way into its HBM).
+ *   up to STAGE_LIMIT bytes: packed by the CPU into page-locked staging, ONE dense DMA each way;
+ *   beyond: straight from / to the caller's memory (strided rows: a 2-D copy), the runtime pipelines the pages.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { ResampleResult res; int staged_out, failed; } HostPending;
+
+static void host_begin (Resample *cxt, const art_s *input, int in_stride, const art_s *const *planes, int nIn,
+                        art_s *output, int out_stride, art_s *const *out_planes, int cap, double ratio, HostPending *pend)
 {
     struct artamd_resampler *hip = cxt->hip;
     const int C = cxt->numChannels;
-    ResampleResult res = { 0, 0 }, peek;
-    ArtamdPosition pos;
-    int dummy_floor;
-
-    pos.numTaps = cxt->numTaps; pos.numFilters = cxt->numFilters; pos.flags = cxt->flags; pos.inputIndex = cxt->inputIndex;
-    pos.floorActive = hip->floor_active; pos.outputOffset = cxt->outputOffset; pos.fixedRatio = cxt->fixedRatio;
-    artamdPlanCall (&pos, nIn, cap, ratio, &peek, NULL, 0, &dummy_floor);
-
+    const ResampleResult peek = peek_call (cxt, nIn, cap, ratio);
     const size_t in_samples = (size_t) peek.input_used * C, out_samples = (size_t) peek.output_generated * C;
+    const char *limit_env = getenv ("ARTAMD_STAGE_LIMIT");
+    const int staged = sizeof (art_s) * (in_samples + out_samples) <= (limit_env && *limit_env ? (size_t) strtoull (limit_env, NULL, 10) : STAGE_LIMIT);
+
+    pend->res.input_used = pend->res.output_generated = 0; pend->staged_out = 0; pend->failed = 1;
 
     hip->d_in = grow (hip->d_in, &hip->in_cap, sizeof (art_s) * in_samples);
     hip->d_out = grow (hip->d_out, &hip->out_cap, sizeof (art_s) * out_samples);
-    if ((in_samples && !hip->d_in) || (out_samples && !hip->d_out)) {
-        fprintf (stderr, "artamd: device allocation failed: %s\n", arthip_last_error ());
-        return res;
+    if (staged) {
+        hip->h_in = grow_pinned (hip->h_in, &hip->h_in_cap, sizeof (art_s) * in_samples);
+        hip->h_out = grow_pinned (hip->h_out, &hip->h_out_cap, sizeof (art_s) * out_samples);
     }
-
-    if (planes || out_planes) {
-        size_t big = in_samples > out_samples ? in_samples : out_samples;
+    else if (planes || out_planes) {
+        const size_t big = in_samples > out_samples ? in_samples : out_samples;
         hip->d_tmp = grow (hip->d_tmp, &hip->tmp_cap, sizeof (art_s) * big);
     }
+    if ((in_samples && !hip->d_in) || (out_samples && !hip->d_out) || (staged && ((in_samples && !hip->h_in) || (out_samples && !hip->h_out))) ||
+        (!staged && (planes || out_planes) && !hip->d_tmp)) {
+        fprintf (stderr, "artamd: staging allocation failed: %s\n", arthip_last_error ());
+        return;
+    }
 
-    if (in_samples) {
+    if (in_samples && staged) {
+        art_s *dst = hip->h_in;
+        if (planes)
+            for (int c = 0; c < C; ++c) {
+                const art_s *src = planes [c];
+                for (unsigned int f = 0; f < peek.input_used; ++f) dst [(size_t) f * C + c] = src [f];
+            }
+        else if (in_stride == C)
+            memcpy (dst, input, sizeof (art_s) * in_samples);
+        else
+            for (unsigned int f = 0; f < peek.input_used; ++f)
+                memcpy (dst + (size_t) f * C, input + (size_t) f * in_stride, sizeof (art_s) * C);
+        arthip_h2d (hip->d_in, hip->h_in, sizeof (art_s) * in_samples, hip->stream);
+    }
+    else if (in_samples) {
         if (planes) {
             for (int c = 0; c < C; ++c)
                 arthip_h2d (hip->d_tmp + (size_t) c * peek.input_used, planes [c], sizeof (art_s) * peek.input_used, hip->stream);
             arthip_interleave (hip->d_in, hip->d_tmp, peek.input_used, (int) peek.input_used, C, hip->stream);
         }
-        else
+        else if (in_stride == C)
             arthip_h2d (hip->d_in, input, sizeof (art_s) * in_samples, hip->stream);
-    }
-
-    res = enqueue_call (cxt, hip->d_in, 0, nIn, hip->d_out, 0, cap, ratio);
-
-    if (res.output_generated) {
-        if (out_planes) {
-            arthip_deinterleave (hip->d_tmp, res.output_generated, hip->d_out, (int) res.output_generated, C, hip->stream);
-            for (int c = 0; c < C; ++c)
-                arthip_d2h (out_planes [c], hip->d_tmp + (size_t) c * res.output_generated, sizeof (art_s) * res.output_generated, hip->stream);
-        }
         else
-            arthip_d2h (output, hip->d_out, sizeof (art_s) * (size_t) res.output_generated * C, hip->stream);
+            arthip_copy2d (hip->d_in, sizeof (art_s) * C, input, sizeof (art_s) * in_stride, sizeof (art_s) * C, peek.input_used, hip->stream);
     }
+
+    pend->res = enqueue_call (cxt, hip->d_in, 0, nIn, hip->d_out, 0, cap, ratio);
+    pend->failed = 0;
+
+    const unsigned int made = pend->res.output_generated;
+    if (!made) return;
+    if (staged) {
+        arthip_d2h (hip->h_out, hip->d_out, sizeof (art_s) * (size_t) made * C, hip->stream);
+        pend->staged_out = 1;
+    }
+    else if (out_planes) {
+        arthip_deinterleave (hip->d_tmp, made, hip->d_out, (int) made, C, hip->stream);
+        for (int c = 0; c < C; ++c)
+            arthip_d2h (out_planes [c], hip->d_tmp + (size_t) c * made, sizeof (art_s) * made, hip->stream);
+    }
+    else if (out_stride == C)
+        arthip_d2h (output, hip->d_out, sizeof (art_s) * (size_t) made * C, hip->stream);
+    else
+        arthip_copy2d (output, sizeof (art_s) * out_stride, hip->d_out, sizeof (art_s) * C, sizeof (art_s) * C, made, hip->stream);
+}
+
+static void host_end (Resample *cxt, art_s *output, int out_stride, art_s *const *out_planes, const HostPending *pend)
+{
+    struct artamd_resampler *hip = cxt->hip;
+    const int C = cxt->numChannels;
+    const unsigned int made = pend->res.output_generated;
 
     arthip_sync (hip->stream);
-    return res;
+    if (!pend->staged_out || !made) return;
+
+    const art_s *src = hip->h_out;
+    if (out_planes)
+        for (int c = 0; c < C; ++c) {
+            art_s *dst = out_planes [c];
+            for (unsigned int f = 0; f < made; ++f) dst [f] = src [(size_t) f * C + c];
+        }
+    else if (out_stride == C)
+        memcpy (output, src, sizeof (art_s) * (size_t) made * C);
+    else
+        for (unsigned int f = 0; f < made; ++f)
+            memcpy (output + (size_t) f * out_stride, src + (size_t) f * C, sizeof (art_s) * C);
+}
+
+static ResampleResult host_call (Resample *cxt, const art_s *input, const art_s *const *planes, int nIn,
+                                 art_s *output, art_s *const *out_planes, int cap, double ratio)
+{
+    struct artamd_resampler *hip = cxt->hip;
+    const int C = cxt->numChannels;
+    HostPending pend [MAX_DEVICES];
+
+    if (!hip->nshards) {
+        ENTER_DEVICE (hip);
+        host_begin (cxt, input, C, planes, nIn, output, C, out_planes, cap, ratio, &pend [0]);
+        host_end (cxt, output, C, out_planes, &pend [0]);
+        LEAVE_DEVICE (hip);
+        return pend [0].res;
+    }
+
+    const int prev = arthip_current_device ();
+    ResampleResult per_shard [MAX_DEVICES];
+
+    for (int k = 0; k < hip->nshards; ++k) {
+        const int first = hip->shard_first [k];
+        arthip_set_device (hip->shards [k]->hip->device);
+        host_begin (hip->shards [k], input ? input + first : NULL, C, planes ? planes + first : NULL, nIn,
+                    output ? output + first : NULL, C, out_planes ? out_planes + first : NULL, cap, ratio, &pend [k]);
+    }
+    for (int k = 0; k < hip->nshards; ++k) {
+        const int first = hip->shard_first [k];
+        arthip_set_device (hip->shards [k]->hip->device);
+        host_end (hip->shards [k], output ? output + first : NULL, C, out_planes ? out_planes + first : NULL, &pend [k]);
+        per_shard [k] = pend [k].res;
+    }
+    if (prev >= 0) arthip_set_device (prev);
+    return shards_agree (cxt, per_shard);
 }
 
 ResampleResult resampleProcessInterleaved (Resample *cxt, const artsample_t *input, int numInputFrames, artsample_t *output, int numOutputFrames, double ratio)

@@ -4,9 +4,12 @@
  * on the host by replaying the reference's scalar position state machine
  * (reference resampler.c:487-537) in closed form, so they are available immediately.
  *
- * One process drives one GPU: contexts bind to the HIP device that is current when they are
- * created (so `torch.cuda.set_device(LOCAL_RANK)` before resampleInit shards channels across the
- * GPUs of a node).
+ * Devices.  An ordinary context lives on the HIP device that is current when it is created and makes
+ * that device current around every call it serves (so `torch.cuda.set_device(LOCAL_RANK)` before
+ * resampleInit gives one process per GPU).  A context created with
+ * RESAMPLE_MULTITHREADED spreads its channels over several devices INSIDE the one context — the
+ * reference's one-worker-per-channel fan-out (reference resampler.c:185-186, :442-470) with GPUs
+ * for threads: see artamdSetDevices below.
  */
 #ifndef ARTAMD_ART_HIP_H
 #define ARTAMD_ART_HIP_H
@@ -24,8 +27,22 @@ extern "C" {
 int artamdDeviceCount (void);                       /* 0 when no usable gfx950 device / HIP runtime */
 const char *artamdVersion (void);
 
+/* Devices that RESAMPLE_MULTITHREADED contexts created from now on spread their channels over (contiguous, balanced
+ * channel slices, one shard per listed device; a device may be listed more than once).  count <= 0 restores the default:
+ * the environment's ARTAMD_DEVICES="0,1,2,..." list, else every visible device.  With a single device the flag has no
+ * effect unless ARTAMD_SHARDS=n forces n shards (several per device: how the sharded path is tested on a one-GPU box).
+ * Every shard has its own stream, history and filter-bank replica; no sample crosses between shards.  Host-pointer calls
+ * de-interleave each shard's channel slice on the way into its HBM; device-pointer calls take buffers on the device the
+ * context was created on and move the slices peer-to-peer.  Returns 0, or -1 for a device that does not exist. */
+int artamdSetDevices (const int *devices, int count);
+int resampleHipGetDevice (Resample *cxt);            /* the context's device (sharded: where device-pointer buffers are expected) */
+int resampleHipNumShards (Resample *cxt);            /* 0 for an ordinary context */
+int resampleHipShardInfo (Resample *cxt, int shard, int *device, int *firstChannel, int *numChannels);   /* 0, or -1: no such shard */
+
 /* ---- resampler ---- */
-void resampleHipSetStream (Resample *cxt, void *hipStream);   /* default: the null stream */
+/* default: the null stream.  Work already enqueued on the previous stream is drained before the switch (history and
+ * scratch buffers are shared between calls); biquadBankSetStream, decimateHipSetStream and stretchHipSetStream do the same. */
+void resampleHipSetStream (Resample *cxt, void *hipStream);
 void resampleHipSynchronize (Resample *cxt);
 /* kernel selection for ablation/tests: 0 = automatic, 1 = general wave-per-output kernel,
  * 2 = MFMA periodic-phase kernel where applicable (falls back to 1 elsewhere) */

@@ -34,7 +34,8 @@ enum {
     SUBSAMPLE_INTERPOLATE   = 0x001,    /* blend the two neighbouring phase filters (needed for arbitrary ratios) */
     BLACKMAN_HARRIS         = 0x002,    /* 4-term Blackman-Harris window; otherwise Hann */
     INCLUDE_LOWPASS         = 0x004,    /* fold a low-pass into the sinc (set automatically when lowpassRatio < 1) */
-    RESAMPLE_MULTITHREADED  = 0x008,    /* accepted, no effect: channels already run in parallel on the GPU */
+    RESAMPLE_MULTITHREADED  = 0x008,    /* spread the channels over the visible GPUs inside this one context (art_hip.h:
+                                           artamdSetDevices / ARTAMD_DEVICES / ARTAMD_SHARDS); no effect with one device */
     NO_FILTER_REDUCTION     = 0x010,    /* fixed-ratio init: keep the full filter count (allows phase shifts) */
     EXTRAPOLATE_ENDPOINTS   = 0x040,    /* LPC-extrapolate before the first / after the last input sample */
     EXTEND_CONVOLUTION_MATH = 0x100,    /* fp64 accumulation in the FIR */

@@ -32,6 +32,12 @@ CTOR = {
     "X_art_147x156_lp": dict(args=(3, 156, 320), kw=dict(flags=BH | INTERP | LOWPASS | EXTRAP, fixed=(96000., 44100., 0)), adv=78.0),
     "X_interp_48": dict(args=(1, 48, 48, 0.0, BH | INTERP | EXTRAP), adv=24.0),
     "X_8ch_988": dict(args=(8, 988, 988, 0.0, BH | INTERP | EXTRAP), adv=494.0),
+    "D_4ch_988": dict(args=(4, 988, 988, 0.0, BH | INTERP), adv=494.0),
+    "D_32ch_988": dict(args=(32, 988, 988, 0.0, BH | INTERP), adv=494.0),
+    "X_short_flush": dict(args=(2, 380, 380, 0.0, BH | INTERP | EXTRAP), adv=190.0),
+    "X_short_flush_fixed": dict(args=(3, 156, 320), kw=dict(flags=BH | INTERP | LOWPASS | EXTRAP, fixed=(96000., 44100., 0)), adv=78.0),
+    "X_late_first": dict(args=(2, 380, 380, 0.0, BH | INTERP | EXTRAP), adv=190.0 + 15 * 380 + 100),
+    "X_late_first_split": dict(args=(2, 380, 380, 0.0, BH | INTERP | EXTRAP), adv=190.0 + 15 * 380 + 40),
 }
 NAMES = list(CTOR)
 

@@ -81,6 +81,22 @@ CONFIGS = {
     "X_interp_48": dict(args=(1, 48, 48, 0.0, BH | INTERP | EXTRAP), adv=24.0, script=SCRIPT_SHORT(R4448), full=True),
     "X_8ch_988": dict(args=(8, 988, 988, 0.0, BH | INTERP | EXTRAP), adv=494.0,
                       script=[(4096, 4962, R4448, False), (4096, 4962, R4448, False), (0, 4962, R4448, True)], full=False),
+    # BASELINE.json configs[3]: 32 channels 44.1k->48k preset -4 (988x988 interpolating), and the 4-channel shard one GPU of 8 owns
+    "D_4ch_988": dict(args=(4, 988, 988, 0.0, BH | INTERP), adv=494.0, script=SCRIPT_WRAP(R4448, 988), full=False),
+    "D_32ch_988": dict(args=(32, 988, 988, 0.0, BH | INTERP), adv=494.0, script=SCRIPT_WRAP(R4448, 988), full=False),
+    # EXTRAPOLATE_ENDPOINTS corners (resampler.c:691-698, :775-791, :812-819): a stream shorter than T/2 whose FIRST output is
+    # produced by the flush call (the prefill then runs over real samples ++ the forward-extrapolated tail) ...
+    "X_short_flush": dict(args=(2, 380, 380, 0.0, BH | INTERP | EXTRAP), adv=190.0,
+                          script=[(60, 500, R4448, False), (40, 500, R4448, False), (0, 2000, R4448, True)], full=True),
+    "X_short_flush_fixed": dict(args=(3, 156, 320), kw=dict(flags=BH | INTERP | LOWPASS | EXTRAP, fixed=(96000., 44100., 0)), adv=78.0,
+                                script=[(50, 500, R9644, False), (0, 7, R9644, True), (0, 500, R9644, True)], full=True),
+    # ... and a first output that comes only after the ring has rewound (position advanced by more than 15*T): the
+    # reference then extrapolates backwards from the samples since the rewind, over real history
+    "X_late_first": dict(args=(2, 380, 380, 0.0, BH | INTERP | EXTRAP), adv=190.0 + 15 * 380 + 100,
+                         script=[(16 * 380 + 500, 4000, R4448, False), (700, 2000, R4448, False), (0, 2000, R4448, True)], full=True),
+    "X_late_first_split": dict(args=(2, 380, 380, 0.0, BH | INTERP | EXTRAP), adv=190.0 + 15 * 380 + 40,
+                               script=[(10 * 380, 4000, R4448, False), (5 * 380 + 7, 4000, R4448, False), (3 * 380, 4000, R4448, False),
+                                       (0, 2000, R4448, True)], full=True),
 }
 
 

@@ -1,0 +1,229 @@
+"""GPU (-m gpu): BASELINE.json configs[3] — a 32-channel 44.1k -> 48k preset -4 stream whose channels shard 4 per GPU — and the
+multi-device context behind the C ABI (RESAMPLE_MULTITHREADED, reference resampler.c:185-186, :442-470).
+
+On the one-GPU box every shard lives on device 0 (ARTAMD_SHARDS=8 forces the shard count): the sharding logic — channel
+slices, per-shard de-interleaving on the way into HBM, per-shard streams, the position mirrored into the parent — is what is
+under test; which device a shard sits on does not change a sample.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import _golden as G
+import audio_resampler_amd as A
+from _hip import HipResampler, tolerance_ok
+from _oracle import OracleResampler, noise, BH, INTERP, PRECISE, EXTRAP
+
+pytestmark = pytest.mark.gpu
+
+STRICT = A.RESAMPLE_STRICT_ORDER
+MT = A.RESAMPLE_MULTITHREADED
+R = 48000 / 44100
+T = 988
+
+
+@pytest.fixture
+def eight_shards(monkeypatch):
+    monkeypatch.setenv("ARTAMD_SHARDS", "8")
+
+
+def _stream(ch, frames, seed_skip=0):
+    x, _ = noise(ch * (frames + seed_skip))
+    return np.ascontiguousarray(x[ch * seed_skip:].reshape(frames, ch))
+
+
+def _run(r, x, blocks, cap):
+    outs, pos = [], 0
+    for n in blocks:
+        u, g, y = r.process(x[pos:pos + n], cap, R)
+        assert u == n
+        outs.append(y.copy())
+        pos += n
+    u, g, y = r.process(None, cap, R, flush=True)
+    outs.append(y.copy())
+    return np.concatenate(outs)
+
+
+@pytest.mark.parametrize("mode", ["strict", "general", "mfma"])
+def test_eight_four_channel_contexts_equal_one_32_channel_context(mode):
+    """slice-then-resample == resample-then-slice for the PRODUCT: 8 HIP contexts of 4 channels (what 8 GPUs would run) against
+    one 32-channel HIP context, bit for bit — strict order, and each fast kernel with itself"""
+    flags, kernel = (BH | INTERP | STRICT, 0) if mode == "strict" else (BH | INTERP, 1 if mode == "general" else 2)
+    frames = 6000 if mode == "strict" else 40000
+    x = _stream(32, frames)
+    blocks = [frames // 3, frames - frames // 3]
+    cap = int(frames * R) + 2000
+    whole = HipResampler(32, T, T, 0.0, flags, kernel=kernel)
+    whole.advance(T / 2)
+    y = _run(whole, x, blocks, cap)
+    if mode != "strict":
+        assert whole.last_kernel() in (1, 2)
+    for s in range(8):
+        part = HipResampler(4, T, T, 0.0, flags, kernel=kernel)
+        part.advance(T / 2)
+        ys = _run(part, np.ascontiguousarray(x[:, 4 * s:4 * s + 4]), blocks, cap)
+        assert ys.shape == (y.shape[0], 4)
+        assert np.array_equal(ys.view(np.uint32), y[:, 4 * s:4 * s + 4].view(np.uint32)), (mode, s)
+
+
+def test_config_d_at_full_block_size_matches_the_oracle_on_a_shard():
+    """the 4-channel shard of configs[3] on the matrix-core path at a bench-sized block, every sample against the
+    double-accumulate oracle (the CG = 4 instantiation at T = 988)"""
+    ch, frames = 4, 150000
+    x = _stream(ch, frames)
+    r = HipResampler(ch, T, T, 0.0, BH | INTERP)
+    o = OracleResampler(ch, T, T, 0.0, BH | INTERP | PRECISE)
+    for b in (r, o):
+        b.advance(T / 2)
+    cap = int(frames * R) + 2000
+    u, g, y = r.process(x, cap, R)
+    uo, go, yo = o.process(x, cap, R, threads=4)
+    assert (u, g) == (uo, go) and r.last_kernel() == 2
+    ok, worst, rms = tolerance_ok(y, yo)
+    assert ok and rms < 2.0e-8, (worst, rms)
+
+
+def _pair(ch, flags, fixed=None, F=T, taps=T):
+    """(ordinary context, RESAMPLE_MULTITHREADED context) with the same parameters"""
+    if fixed is None:
+        return (A.Resampler(ch, taps, F, 0.0, flags), A.Resampler(ch, taps, F, 0.0, flags | MT))
+    return (A.Resampler(ch, taps, F, flags=flags, fixed=fixed), A.Resampler(ch, taps, F, flags=flags | MT, fixed=fixed))
+
+
+def test_multithreaded_flag_alone_changes_nothing_on_one_device(monkeypatch):
+    monkeypatch.delenv("ARTAMD_SHARDS", raising=False)
+    monkeypatch.delenv("ARTAMD_DEVICES", raising=False)
+    if A.lib().artamdDeviceCount() > 1:
+        pytest.skip("several devices visible: the flag shards for real")
+    r = A.Resampler(8, 48, 48, 0.0, BH | INTERP | MT)
+    assert r.shards() == []
+
+
+def test_sharded_context_layout(eight_shards):
+    r = A.Resampler(32, 48, 48, 0.0, BH | INTERP | MT)
+    assert [(f, n) for _, f, n in r.shards()] == [(4 * s, 4) for s in range(8)]       # configs[3]: 4 channels per GPU
+    r7 = A.Resampler(7, 48, 48, 0.0, BH | INTERP | MT)                               # more shards than channels allow: clamped
+    assert [(f, n) for _, f, n in r7.shards()] == [(s, 1) for s in range(7)]
+    r10 = A.Resampler(10, 48, 48, 0.0, BH | INTERP | MT)
+    assert [(f, n) for _, f, n in r10.shards()] == [(0, 2), (2, 2), (4, 1), (5, 1), (6, 1), (7, 1), (8, 1), (9, 1)]
+    import ctypes
+    assert A.lib().artamdSetDevices((ctypes.c_int * 1)(99), 1) == -1
+    assert A.lib().artamdSetDevices(None, 0) == 0
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_sharded_context_host_api_equals_ordinary_context(eight_shards, strict):
+    """art -c32 -m on this library: resampleProcessInterleaved / resampleProcess on ONE context whose channels run as 8 shards"""
+    ch, frames = 32, 9000
+    flags = BH | INTERP | (STRICT if strict else 0)
+    x = _stream(ch, frames)
+    plain, sharded = _pair(ch, flags)
+    assert len(sharded.shards()) == 8 and plain.shards() == []
+    for r in (plain, sharded):
+        r.advance(T / 2)
+    cap = 6000
+    pos = 0
+    for n in (4096, 1, 3000, 1903):
+        ua, ga, ya = plain.process(x[pos:pos + n], cap, R)
+        ub, gb, yb = sharded.process(x[pos:pos + n], cap, R)
+        assert (ua, ga) == (ub, gb) and plain.state() == (sharded.state()[0], sharded.state()[1], sharded.state()[2] & ~MT)
+        assert np.array_equal(ya.view(np.uint32), yb.view(np.uint32))
+        assert plain.position() == sharded.position()
+        pos += ua
+    # planar entry point, then the flush through the planar AndFlush form
+    planes = [np.ascontiguousarray(x[:500, c]) for c in range(ch)]
+    ua, ga, pa = plain.process_planar(planes, cap, R, and_flush=True)
+    ub, gb, pb = sharded.process_planar(planes, cap, R, and_flush=True)
+    assert (ua, ga) == (ub, gb) and ga > 500
+    for c in range(ch):
+        assert np.array_equal(pa[c].view(np.uint32), pb[c].view(np.uint32))
+    # reset re-arms both
+    plain.reset(), sharded.reset()
+    ua, ga, ya = plain.process(x[:2000], cap, R)
+    ub, gb, yb = sharded.process(x[:2000], cap, R)
+    assert (ua, ga) == (ub, gb) and np.array_equal(ya.view(np.uint32), yb.view(np.uint32))
+
+
+@pytest.mark.parametrize("stage_limit", [None, "0"])
+def test_sharded_context_fixed_ratio_extrapolation_and_large_blocks(eight_shards, monkeypatch, stage_limit):
+    """the ART form (fixed ratio, SNAP, low-pass, end-point extrapolation) on 10 channels (uneven shards), and a block large
+    enough to bypass the page-locked staging (strided 2-D copies straight from the caller's buffers; ARTAMD_STAGE_LIMIT=0
+    forces that path for every call and every shard)"""
+    if stage_limit is not None:
+        monkeypatch.setenv("ARTAMD_STAGE_LIMIT", stage_limit)
+    ch = 10
+    x = _stream(ch, 300000)
+    plain, sharded = _pair(ch, BH | INTERP | A.INCLUDE_LOWPASS | EXTRAP | STRICT, fixed=(96000., 44100., 0), F=320, taps=156)
+    for r in (plain, sharded):
+        r.advance(78.0)
+    cap = 200000
+    pos = 0
+    for n in (40, 3000, 280000):            # 280000 x 10 ch x 4 B = 11 MB > the 8 MB staging limit
+        ua, ga, ya = plain.process(x[pos:pos + n], cap, 1.0)
+        ub, gb, yb = sharded.process(x[pos:pos + n], cap, 1.0)
+        assert (ua, ga) == (ub, gb)
+        assert np.array_equal(ya.view(np.uint32), yb.view(np.uint32))
+        pos += ua
+    ua, ga, ya = plain.process(None, cap, 1.0, flush=True)
+    ub, gb, yb = sharded.process(None, cap, 1.0, flush=True)
+    assert (ua, ga) == (ub, gb) and np.array_equal(ya.view(np.uint32), yb.view(np.uint32))
+
+
+def test_sharded_context_device_pointer_calls(eight_shards):
+    """device-resident 32-channel buffers on the context's device: every shard pulls its strided slice, runs on its own stream,
+    pushes its slice back; the context's stream is ordered before and after"""
+    ch, frames = 32, 50000
+    x = _stream(ch, frames)
+    plain, sharded = _pair(ch, BH | INTERP)
+    for r in (plain, sharded):
+        r.advance(T / 2)
+        r.set_kernel(2)
+    cap = int(frames * R) + 2000
+    d_in = torch.from_numpy(x).cuda()
+    outs = []
+    for r in (plain, sharded):
+        d_out = torch.zeros(cap, ch, device="cuda")
+        u, g = r.process_device(d_in, frames, d_out, cap, R, and_flush=True)
+        r.synchronize()
+        torch.cuda.synchronize()
+        outs.append((u, g, d_out[:g].cpu().numpy()))
+    assert outs[0][:2] == outs[1][:2]
+    assert np.array_equal(outs[0][2].view(np.uint32), outs[1][2].view(np.uint32))
+    # planar device buffers: a shard's channels are a contiguous run of planes, no copies
+    plain, sharded = _pair(ch, BH | INTERP | STRICT)
+    pl_in = torch.from_numpy(np.ascontiguousarray(x[:3000].T)).cuda()
+    res = []
+    for r in (plain, sharded):
+        r.advance(T / 2)
+        pl_out = torch.zeros(ch, 4000, device="cuda")
+        u, g = r.process_planar_device(pl_in, 3000, 3000, pl_out, 4000, 4000, R)
+        r.synchronize()
+        torch.cuda.synchronize()
+        res.append((u, g, pl_out[:, :g].cpu().numpy()))
+    assert res[0][:2] == res[1][:2] and res[0][1] > 0
+    assert np.array_equal(res[0][2].view(np.uint32), res[1][2].view(np.uint32))
+
+
+def test_sharded_context_matches_golden_d_32ch(eight_shards):
+    """configs[3] golden (reference-generated) replayed on a sharded context, strict order: every bit"""
+    name = "D_32ch_988"
+    r = G.make(HipResampler, name, STRICT | MT)
+    assert len(r.shards()) == 8
+    y, trace = G.replay(r, name)
+    full, head, tail, csum = G.expected(name, "strict")
+    assert np.array_equal(trace[:, :4], G.load("resample")[name + "/trace"][:, :4])
+    assert np.array_equal(y[:256].view(np.uint32), head.view(np.uint32))
+    assert np.array_equal(y[-256:].view(np.uint32), tail.view(np.uint32))
+    from _oracle import checksum_words
+    assert checksum_words(y) == csum
+
+
+def test_context_uses_its_own_device_whatever_the_caller_selected():
+    """contexts remember their device (here: the only one) and restore the caller's afterwards"""
+    r = A.Resampler(2, 48, 48, 0.0, BH | INTERP)
+    assert A.lib().resampleHipGetDevice(r.p) == torch.cuda.current_device()
+    x = _stream(2, 500)
+    u, g, y = r.process(x, 2000, R)
+    assert u == 500 and g > 0 and torch.cuda.current_device() == A.lib().resampleHipGetDevice(r.p)

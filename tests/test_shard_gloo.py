@@ -31,7 +31,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, hip=False):
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
     from _oracle import OracleResampler, noise, BH, INTERP
@@ -41,7 +41,13 @@ def _worker(rank, world, port, q):
     x, _ = noise(total_ch * 3000)
     x = x.reshape(-1, total_ch)
     mine = scatter_interleaved(torch.from_numpy(x), world, rank).numpy()
-    r = OracleResampler(mine.shape[1], T, 48, 0.0, BH | INTERP)
+    if hip:         # the PRODUCT as the per-rank context: strict order, so the comparison below stays bit for bit
+        import audio_resampler_amd as A
+        from _hip import HipResampler
+        torch.cuda.set_device(rank % torch.cuda.device_count())
+        r = HipResampler(mine.shape[1], T, 48, 0.0, BH | INTERP | A.RESAMPLE_STRICT_ORDER)
+    else:
+        r = OracleResampler(mine.shape[1], T, 48, 0.0, BH | INTERP)
     r.advance(T / 2)
     u, g, y = r.process(mine, 4000, 48000 / 44100, and_flush=True)
     agg = agree_and_aggregate(dist, "cpu", 0.5 + rank, g, mine.shape[1], kernel_ms=1.0 + rank, launches=3)
@@ -57,11 +63,18 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_over_gloo():
+@pytest.mark.gpu
+def test_two_ranks_over_gloo_with_hip_contexts():
+    """the same world-2 run with the HIP library as every rank's context (ranks share the box's GPU(s)): the sharded product
+    equals the un-sharded reference-order stream bit for bit"""
+    test_two_ranks_over_gloo(hip=True)
+
+
+def test_two_ranks_over_gloo(hip=False):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, hip)) for r in range(world)]
     for p in procs:
         p.start()
     agg, frames, same = q.get(timeout=120)
