@@ -127,6 +127,8 @@ def _bind(width):
         "biquadBankApplyInterleavedDevice": (None, [ptr, ptr, C.c_int]),
         "biquadBankRead": (None, [ptr, C.POINTER(Biquad)]),
         "biquadBankFree": (None, [ptr]),
+        "biquadBankRepairs": (C.c_uint, [ptr]),
+        "artamdBiquadRepairs": (C.c_uint, []),
         "decimateHipSetStream": (None, [DP, ptr]),
         "decimateProcessInterleavedLEDevice": (None, [DP, ptr, C.c_int, ptr]),
         "decimateHipClipped": (C.c_long, [DP]),
@@ -360,6 +362,9 @@ def _bind(width):
 
         def set_stream(self, s):
             self.L.biquadBankSetStream(self.p, s)
+
+        def repairs(self):
+            return self.L.biquadBankRepairs(self.p)
 
         def read(self):
             out = (Biquad * self.n)()

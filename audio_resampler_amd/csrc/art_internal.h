@@ -126,6 +126,11 @@ int arthip_decimate_planar (const ArtDecArgs *a, const art_s *d_in, long in_pitc
 int arthip_biquad_chain (Biquad *d_sections, int C, int S, art_s *d_buf, int frames, int stride, void *stream);
 /* every section has order 2, S = 1 or 2, interleaved frames: hand-scheduled kernel */
 int arthip_biquad_order2 (Biquad *d_sections, int C, int S, art_s *d_buf, int frames, int stride, void *stream);   /* stride >= C: values between frames */
+/* bit-exact cascade, parallel over time (speculative chunks + exact verification, pcm_kernels.hip): d_in -> d_out, distinct
+ * buffers; L = chunk length, W = warm-up frames per section; d_states: arthip_biquad_spec_scratch () bytes of scratch */
+size_t arthip_biquad_spec_scratch (int C, int S, int frames, int L);
+int arthip_biquad_spec (Biquad *d_sections, int C, int S, const art_s *d_in, int in_stride, art_s *d_out, int out_stride, int frames,
+                        int L, int W, void *d_states, unsigned int *d_repairs, void *stream);
 /* ---- time stretcher (stretch_kernels.hip) ---- */
 typedef struct {
     art_s *ring [2][2];                  /* [stage][ping-pong] input rings, `room` values each */

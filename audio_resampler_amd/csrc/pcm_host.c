@@ -64,21 +64,95 @@ void biquad_init (Biquad *f, const BiquadCoefficients *c, double gain)
 }
 
 /* ------------------------------------------------------------------------------------------
- * Biquad, host-pointer entry points: a process-wide scratch in HBM, one section, one lane.
- * (Serial by nature; the batched device form below is the one meant for throughput.)
+ * How the cascades run.  A biquad is a serial recurrence through float rounding; the bit-exact form that is parallel over
+ * TIME (pcm_kernels.hip, biquad_spec_kernel) needs to know how fast the recursive part forgets its state: the warm-up W
+ * is the number of frames after which every unit initial state has decayed below 2^-40 (2^-70 for 8-byte samples; + margin).  Filters that do not
+ * forget within SPEC_MAX_WARMUP frames (poles within ~0.97 of the unit circle) and short runs take the serial kernels.
+ * Both forms produce the reference's bits (biquad.c:106-163); ARTAMD_BIQUAD_SERIAL=1 forces the serial one.
+ * ---------------------------------------------------------------------------------------- */
+#define SPEC_MAX_WARMUP 1024
+
+static int forget_length (const Biquad *f)
+{
+    const int order = f->order;
+    int worst = 0;
+
+    if (order < 1 || order > 4) return 0;
+    for (int j = 0; j < order; ++j) {
+        double y [4] = { 0.0, 0.0, 0.0, 0.0 };
+        int last = 0;
+        y [j] = 1.0;
+        for (int n = 1; n <= SPEC_MAX_WARMUP + 64; ++n) {
+            double v = 0.0;
+            for (int k = 1; k <= order; ++k) v -= (double) f->b [k] * y [k - 1];
+            y [3] = y [2]; y [2] = y [1]; y [1] = y [0]; y [0] = v;
+            if (!(fabs (v) <= (ART_WIDE ? 0x1p-70 : 0x1p-40))) last = n;        /* (also catches a blow-up: inf / NaN) */
+        }
+        if (last > worst) worst = last;
+    }
+    return worst > SPEC_MAX_WARMUP ? 0 : worst + 16;
+}
+
+/* chunk length for `sections` sections with warm-up W each: the warm-up is recomputed work, keep it to about a quarter */
+static int spec_chunk (int sections, int W)
+{
+    int L = 4 * sections * W;
+    L = (L + 7) & ~7;
+    if (L < 128) L = 128;
+    if (L > 8192) L = 8192;
+    return L;
+}
+
+static int spec_disabled (void)
+{
+    static int cached = -1;
+    if (cached < 0) { const char *e = getenv ("ARTAMD_BIQUAD_SERIAL"); cached = e && *e && *e != '0'; }
+    return cached;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Biquad, host-pointer entry points (what ART's -p filters call, art.c:1011-1017, :1052-1058: one section of one channel
+ * of an interleaved buffer per call).  Only the channel's own samples travel: gathered by the CPU into page-locked
+ * staging, one DMA each way, the time-parallel kernel on a dense run, scattered back.  Process-wide scratch.
  * ---------------------------------------------------------------------------------------- */
 
 static pthread_mutex_t scratch_lock = PTHREAD_MUTEX_INITIALIZER;
-static art_s *scratch_buf; static size_t scratch_cap;
-static Biquad *scratch_state;
+static struct {
+    art_s *d_in, *d_out; size_t cap;                   /* samples */
+    art_s *h_buf; size_t h_cap;                        /* page-locked, samples */
+    Biquad *d_state, *h_state;
+    void *d_spec; size_t spec_cap;
+    unsigned int *d_repairs;
+    int device;
+} host_scratch = { .device = -1 };
 
 static int scratch_reserve (size_t samples)
 {
-    if (!scratch_state && !(scratch_state = arthip_malloc (sizeof (Biquad)))) return -1;
-    if (samples * sizeof (art_s) > scratch_cap) {
-        arthip_free (scratch_buf);
-        scratch_cap = samples * sizeof (art_s) * 2;
-        if (!(scratch_buf = arthip_malloc (scratch_cap))) { scratch_cap = 0; return -1; }
+    const int device = arthip_current_device ();
+    if (host_scratch.device != device) {                /* first use (or the caller moved to another GPU): start over there */
+        arthip_free (host_scratch.d_in); arthip_free (host_scratch.d_out); arthip_free (host_scratch.d_state);
+        arthip_free (host_scratch.d_spec); arthip_free (host_scratch.d_repairs);
+        arthip_host_free (host_scratch.h_buf); arthip_host_free (host_scratch.h_state);
+        memset (&host_scratch, 0, sizeof (host_scratch));
+        host_scratch.device = device;
+    }
+    if (!host_scratch.d_state && !(host_scratch.d_state = arthip_malloc (sizeof (Biquad)))) return -1;
+    if (!host_scratch.h_state && !(host_scratch.h_state = arthip_host_alloc (sizeof (Biquad)))) return -1;
+    if (!host_scratch.d_repairs) {
+        if (!(host_scratch.d_repairs = arthip_malloc (sizeof (unsigned int)))) return -1;
+        arthip_zero (host_scratch.d_repairs, sizeof (unsigned int), NULL);
+    }
+    if (samples > host_scratch.cap) {
+        arthip_free (host_scratch.d_in); arthip_free (host_scratch.d_out);
+        host_scratch.cap = samples + samples / 2 + 1024;
+        host_scratch.d_in = arthip_malloc (host_scratch.cap * sizeof (art_s));
+        host_scratch.d_out = arthip_malloc (host_scratch.cap * sizeof (art_s));
+        if (!host_scratch.d_in || !host_scratch.d_out) { host_scratch.cap = 0; return -1; }
+    }
+    if (samples > host_scratch.h_cap) {
+        arthip_host_free (host_scratch.h_buf);
+        host_scratch.h_cap = samples + samples / 2 + 1024;
+        if (!(host_scratch.h_buf = arthip_host_alloc (host_scratch.h_cap * sizeof (art_s)))) { host_scratch.h_cap = 0; return -1; }
     }
     return 0;
 }
@@ -86,25 +160,52 @@ static int scratch_reserve (size_t samples)
 static void biquad_run_host (Biquad *f, art_s *buffer, int n, int stride, int sample_form)
 {
     if (n <= 0) return;
-    const size_t span = (size_t)(n - 1) * stride + 1;
 
     pthread_mutex_lock (&scratch_lock);
-    if (arthip_device_count () < 1 || scratch_reserve (span)) {
-        fprintf (stderr, "artamd: biquad needs a HIP device (no CPU path): %s\n", arthip_last_error ());
+    if (arthip_device_count () < 1 || scratch_reserve ((size_t) n)) {
+        /* no CPU evaluation path exists: say so and leave the caller's samples and filter state untouched */
+        fprintf (stderr, "artamd: biquad needs a HIP device and scratch memory (no CPU path): %s\n", arthip_last_error ());
         pthread_mutex_unlock (&scratch_lock);
-        abort ();
+        return;
     }
-    arthip_h2d (scratch_buf, buffer, span * sizeof (art_s), NULL);
-    arthip_h2d (scratch_state, f, sizeof (Biquad), NULL);
-    /* second-order section over a long strided run (ART's -p filters, art.c:1011-1016): the feed-forward / pipelined
-     * kernel with one channel; everything else: the generic one-lane kernel */
-    if (!sample_form && f->order == 2 && n >= 64)
-        arthip_biquad_order2 (scratch_state, 1, 1, scratch_buf, n, stride, NULL);
+
+    art_s *h = host_scratch.h_buf;
+    if (stride == 1) memcpy (h, buffer, sizeof (art_s) * (size_t) n);
+    else for (int i = 0; i < n; ++i) h [i] = buffer [(size_t) i * stride];
+    *host_scratch.h_state = *f;
+    arthip_h2d (host_scratch.d_in, h, sizeof (art_s) * (size_t) n, NULL);
+    arthip_h2d (host_scratch.d_state, host_scratch.h_state, sizeof (Biquad), NULL);
+
+    const int W = (sample_form || spec_disabled ()) ? 0 : forget_length (f);
+    const int L = W ? spec_chunk (1, W) : 0;
+    const art_s *d_result = host_scratch.d_in;
+    int rc;
+    if (W && n >= 2 * L) {
+        const size_t need = arthip_biquad_spec_scratch (1, 1, n, L);
+        if (need > host_scratch.spec_cap) {
+            arthip_free (host_scratch.d_spec);
+            host_scratch.d_spec = arthip_malloc (need + need / 2);
+            host_scratch.spec_cap = host_scratch.d_spec ? need + need / 2 : 0;
+        }
+        rc = host_scratch.d_spec ? arthip_biquad_spec (host_scratch.d_state, 1, 1, host_scratch.d_in, 1, host_scratch.d_out, 1, n, L, W,
+                                                       host_scratch.d_spec, host_scratch.d_repairs, NULL) : -1;
+        d_result = host_scratch.d_out;
+    }
+    else if (!sample_form && f->order == 2 && n >= 64)       /* long run of a narrow filter: the pipelined serial kernel, one channel */
+        rc = arthip_biquad_order2 (host_scratch.d_state, 1, 1, host_scratch.d_in, n, 1, NULL);
     else
-        arthip_biquad_chain (scratch_state, 1, 1, scratch_buf, n, sample_form ? -stride : stride, NULL);
-    arthip_d2h (buffer, scratch_buf, span * sizeof (art_s), NULL);
-    arthip_d2h (f, scratch_state, sizeof (Biquad), NULL);
-    arthip_sync (NULL);
+        rc = arthip_biquad_chain (host_scratch.d_state, 1, 1, host_scratch.d_in, n, sample_form ? -1 : 1, NULL);
+
+    if (rc) fprintf (stderr, "artamd: biquad launch failed: %s\n", arthip_last_error ());
+    else {
+        arthip_d2h (h, d_result, sizeof (art_s) * (size_t) n, NULL);
+        arthip_d2h (host_scratch.h_state, host_scratch.d_state, sizeof (Biquad), NULL);
+        if (!arthip_sync (NULL)) {
+            if (stride == 1) memcpy (buffer, h, sizeof (art_s) * (size_t) n);
+            else for (int i = 0; i < n; ++i) buffer [(size_t) i * stride] = h [i];      /* only this channel's samples are written */
+            *f = *host_scratch.h_state;
+        }
+    }
     pthread_mutex_unlock (&scratch_lock);
 }
 
@@ -119,12 +220,26 @@ artsample_t biquad_apply_sample (Biquad *f, artsample_t input)
     return input;
 }
 
+/* chunks the time-parallel biquad had to recompute since the process started (host-pointer calls; diagnostics) */
+unsigned int artamdBiquadRepairs (void)
+{
+    unsigned int n = 0;
+    pthread_mutex_lock (&scratch_lock);
+    if (host_scratch.d_repairs) { arthip_d2h (&n, host_scratch.d_repairs, sizeof (n), NULL); arthip_sync (NULL); }
+    pthread_mutex_unlock (&scratch_lock);
+    return n;
+}
+
 /* ---- device-resident bank of section chains ---- */
 
 struct artamd_biquad_bank {
     Biquad *d_sections;
     int C, S;
-    int all_order2;                      /* every section is second order: hand-scheduled kernel */
+    int all_order2;                      /* every section is second order: hand-scheduled serial kernel */
+    int warmup;                          /* time-parallel form: warm-up frames per section (0: serial kernels only) */
+    art_s *d_tmp; size_t tmp_cap;        /* the call's input, moved aside (the time-parallel form is not in-place) */
+    void *d_spec; size_t spec_cap;
+    unsigned int *d_repairs;
     void *stream;
 };
 
@@ -135,20 +250,58 @@ BiquadBank *biquadBankCreate (const Biquad *sections, int numChannels, int numSe
         return NULL;
     }
     BiquadBank *b = calloc (1, sizeof (*b));
+    if (!b) return NULL;
     const size_t bytes = sizeof (Biquad) * (size_t) numChannels * numSections;
     b->C = numChannels; b->S = numSections;
     b->all_order2 = numSections <= 2;
-    for (int i = 0; i < numChannels * numSections; ++i)
+    b->warmup = spec_disabled () ? 0 : 1;
+    for (int i = 0; i < numChannels * numSections; ++i) {
         if (sections [i].order != 2) b->all_order2 = 0;
+        if (b->warmup) {
+            /* (channels of one stream share their coefficients: the search runs once per distinct section) */
+            int w = (i >= numSections && !memcmp (sections [i].b, sections [i - numSections].b, sizeof (sections [i].b)) &&
+                     sections [i].order == sections [i - numSections].order) ? b->warmup : forget_length (sections + i);
+            b->warmup = !w ? 0 : w > b->warmup ? w : b->warmup;
+        }
+    }
     b->d_sections = arthip_malloc (bytes);
-    if (!b->d_sections || arthip_h2d (b->d_sections, sections, bytes, NULL) || arthip_sync (NULL)) { biquadBankFree (b); return NULL; }
+    b->d_repairs = arthip_malloc (sizeof (unsigned int));
+    if (!b->d_sections || !b->d_repairs || arthip_h2d (b->d_sections, sections, bytes, NULL) ||
+        arthip_zero (b->d_repairs, sizeof (unsigned int), NULL) || arthip_sync (NULL)) { biquadBankFree (b); return NULL; }
     return b;
 }
 
-void biquadBankSetStream (BiquadBank *b, void *stream) { b->stream = stream; }
+/* (work already enqueued on the old stream uses the bank's state and scratch: drained before the switch) */
+void biquadBankSetStream (BiquadBank *b, void *stream)
+{
+    if (b->stream == stream) return;
+    arthip_sync (b->stream);
+    b->stream = stream;
+}
 
 void biquadBankApplyInterleavedDevice (BiquadBank *b, artsample_t *d_buffer, int numFrames)
 {
+    const int L = b->warmup ? spec_chunk (b->S, b->warmup) : 0;
+
+    if (L && numFrames >= 2 * L) {
+        const size_t samples = (size_t) numFrames * b->C, need = arthip_biquad_spec_scratch (b->C, b->S, numFrames, L);
+        if (samples * sizeof (art_s) > b->tmp_cap) {
+            arthip_free (b->d_tmp);
+            b->tmp_cap = (samples + samples / 2) * sizeof (art_s);
+            if (!(b->d_tmp = arthip_malloc (b->tmp_cap))) b->tmp_cap = 0;
+        }
+        if (need > b->spec_cap) {
+            arthip_free (b->d_spec);
+            b->spec_cap = need + need / 2;
+            if (!(b->d_spec = arthip_malloc (b->spec_cap))) b->spec_cap = 0;
+        }
+        if (b->d_tmp && b->d_spec) {
+            arthip_d2d (b->d_tmp, d_buffer, samples * sizeof (art_s), b->stream);
+            if (!arthip_biquad_spec (b->d_sections, b->C, b->S, b->d_tmp, b->C, d_buffer, b->C, numFrames, L, b->warmup, b->d_spec, b->d_repairs, b->stream))
+                return;
+        }
+        fprintf (stderr, "artamd: time-parallel biquad unavailable (%s): serial kernel\n", arthip_last_error ());
+    }
     if (b->all_order2 && numFrames >= 64)
         arthip_biquad_order2 (b->d_sections, b->C, b->S, d_buffer, numFrames, b->C, b->stream);
     else
@@ -161,9 +314,18 @@ void biquadBankRead (BiquadBank *b, Biquad *sections)
     arthip_sync (b->stream);
 }
 
+/* chunks the time-parallel form had to recompute for this bank so far (synchronises; diagnostics) */
+unsigned int biquadBankRepairs (BiquadBank *b)
+{
+    unsigned int n = 0;
+    arthip_d2h (&n, b->d_repairs, sizeof (n), b->stream);
+    arthip_sync (b->stream);
+    return n;
+}
+
 void biquadBankFree (BiquadBank *b)
 {
-    if (b) { arthip_free (b->d_sections); free (b); }
+    if (b) { arthip_sync (b->stream); arthip_free (b->d_sections); arthip_free (b->d_tmp); arthip_free (b->d_spec); arthip_free (b->d_repairs); free (b); }
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -290,7 +452,13 @@ static void dec_args (Decimate *cxt, ArtDecArgs *a)
     a->feedback = hip->d_feedback; a->gens = hip->d_gens; a->gens_next = hip->d_gens_alt; a->shapers = hip->d_shapers; a->clipped = hip->d_clipped;
 }
 
-void decimateHipSetStream (Decimate *cxt, void *stream) { cxt->hip->stream = stream; }
+/* (the shaper / dither state is shared between calls: the old stream is drained before the switch) */
+void decimateHipSetStream (Decimate *cxt, void *stream)
+{
+    if (cxt->hip->stream == stream) return;
+    arthip_sync (cxt->hip->stream);
+    cxt->hip->stream = stream;
+}
 
 static void dec_swap_if (Decimate *cxt, int rc)
 {

@@ -10,6 +10,7 @@
 // reference.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <type_traits>
 #include "art_internal.h"
 
 namespace {
@@ -103,6 +104,189 @@ __global__ void biquad_chain_kernel (Biquad *sections, int C, int S, art_s *buf,
 #pragma unroll
     for (int s = 0; s < MAX_CHAIN; ++s)
         if (s < S) store_section (sections [(size_t) c * S + s], r [s], frames, sample_form != 0);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Bit-exact biquad cascade, parallel over TIME (biquad_spec_kernel + biquad_commit_kernel).
+//
+// The recurrence rounds after every operation (reference biquad.c:138-146), so it cannot be re-associated; but a
+// STABLE filter forgets its state: two runs over the same input that start from different states converge
+// geometrically, and once their rounded states coincide at one sample they coincide for ever.  So every chunk of L
+// frames is computed by its own lane in the reference's exact operation order, started WARM-UP frames early from a
+// zero state (section s starts (S - s) W frames early, so that it is fed converged outputs of section s - 1), and
+// records the state it reached at its chunk's first frame and the state it left at its last.  Chunk 0 starts from the
+// carried-in state and is exact; chunk k is exact iff chunk k - 1 is exact and the state chunk k reached after its
+// warm-up equals, bit for bit, the state chunk k - 1 left.  The commit kernel checks every boundary in parallel; in the
+// (rare) case of a mismatch one lane recomputes from the exact state until it rejoins a speculative trajectory — in the
+// worst case everything, serially, so the result is exact whatever the filter.  W comes from the decay of the
+// recursive part (host side); filters too narrow to forget within the cap take the serial kernels instead.
+// Input and output are separate buffers (a chunk's warm-up reads frames its predecessor writes).
+// ---------------------------------------------------------------------------------------------------
+struct SpecState { art_s x [4], y [4]; };           // one section's delay lines, newest first
+
+template <int S>
+__device__ __forceinline__ bool same_state (const SpecState *a, const SpecState *b)
+{
+    bool same = true;
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // bit patterns, not values: -0.0 and 0.0 carry on differently through a multiply by a negative coefficient
+            same = same && __builtin_bit_cast (typename std::conditional<sizeof (art_s) == 4, uint32_t, uint64_t>::type, a [s].x [k]) ==
+                           __builtin_bit_cast (typename std::conditional<sizeof (art_s) == 4, uint32_t, uint64_t>::type, b [s].x [k]);
+            same = same && __builtin_bit_cast (typename std::conditional<sizeof (art_s) == 4, uint32_t, uint64_t>::type, a [s].y [k]) ==
+                           __builtin_bit_cast (typename std::conditional<sizeof (art_s) == 4, uint32_t, uint64_t>::type, b [s].y [k]);
+        }
+    return same;
+}
+
+template <int S>
+__device__ __forceinline__ void get_state (SpecState *dst, const SectionRegs *r)
+{
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { dst [s].x [k] = r [s].x [k]; dst [s].y [k] = r [s].y [k]; }
+}
+
+template <int S>
+__device__ __forceinline__ void put_state (SectionRegs *r, const SpecState *src)
+{
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { r [s].x [k] = src [s].x [k]; r [s].y [k] = src [s].y [k]; }
+}
+
+// frames [from, to) of channel c through all S sections (every section live), exact order; writes `out`
+template <int S>
+__device__ __forceinline__ void spec_run (SectionRegs *r, const art_s *in, int stride, art_s *out, int out_stride, int c, int from, int to)
+{
+    constexpr int U = 8;                                // loads of U frames fly ahead of the dependent chain
+    int n = from;
+    for (; n + U <= to; n += U) {
+        art_s v [U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v [u] = in [(size_t)(n + u) * stride + c];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) v [u] = step_buffer_order (r [s], v [u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) out [(size_t)(n + u) * out_stride + c] = v [u];
+    }
+    for (; n < to; ++n) {
+        art_s v = in [(size_t) n * stride + c];
+#pragma unroll
+        for (int s = 0; s < S; ++s) v = step_buffer_order (r [s], v);
+        out [(size_t) n * out_stride + c] = v;
+    }
+}
+
+// task = (chunk k, channel c), c fastest: the lanes of a wave read neighbouring channels of a few chunks
+template <int S>
+__global__ __launch_bounds__ (256)
+void biquad_spec_kernel (const Biquad *sections, int C, int K, int L, int W, const art_s *in, int stride, art_s *out, int out_stride,
+                         int frames, SpecState *starts, SpecState *ends)
+{
+    const long task = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (task >= (long) C * K) return;
+    const int c = (int)(task % C), k = (int)(task / C);
+    const int first = k * L, last = min (first + L, frames);
+
+    SectionRegs r [S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) load_section (r [s], sections [(size_t) c * S + s]);
+
+    const int begin = first - S * W;
+    if (begin > 0) {
+        // speculative start: silence behind every section; section s joins (S - s) W frames before the chunk
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { r [s].x [q] = 0; r [s].y [q] = 0; }
+        for (int n = begin; n < first; ++n) {
+            art_s v = in [(size_t) n * stride + c];
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+                if (n >= first - (S - s) * W) v = step_buffer_order (r [s], v);
+        }
+    }
+    else if (first > 0) {
+        // close to the start of the call: run from the carried-in state through frames [0, first) — exact, nothing stored
+        for (int n = 0; n < first; ++n) {
+            art_s v = in [(size_t) n * stride + c];
+#pragma unroll
+            for (int s = 0; s < S; ++s) v = step_buffer_order (r [s], v);
+        }
+    }
+
+    SpecState st [S];
+    get_state<S> (st, r);
+#pragma unroll
+    for (int s = 0; s < S; ++s) starts [((size_t) c * K + k) * S + s] = st [s];
+
+    spec_run<S> (r, in, stride, out, out_stride, c, first, last);
+
+    get_state<S> (st, r);
+#pragma unroll
+    for (int s = 0; s < S; ++s) ends [((size_t) c * K + k) * S + s] = st [s];
+}
+
+// One workgroup per channel: every boundary checked in parallel; lane 0 repairs from the first mismatch (rare), then the
+// channel's final state goes back into `sections`.  repairs: running count of chunks recomputed (diagnostics).
+template <int S>
+__global__ __launch_bounds__ (256)
+void biquad_commit_kernel (Biquad *sections, int C, int K, int L, const art_s *in, int stride, art_s *out, int out_stride, int frames,
+                           const SpecState *starts, SpecState *ends, unsigned char *bad, unsigned int *repairs)
+{
+    const int c = blockIdx.x, tid = threadIdx.x;
+    __shared__ int s_first_bad;
+    if (tid == 0) s_first_bad = K;
+    __syncthreads ();
+    const SpecState *st = starts + (size_t) c * K * S;
+    SpecState *en = ends + (size_t) c * K * S;
+    unsigned char *flags = bad + (size_t) c * K;
+    for (int k = 1 + tid; k < K; k += blockDim.x) {
+        const bool ok = same_state<S> (st + (size_t) k * S, en + (size_t)(k - 1) * S);
+        flags [k] = ok ? 0 : 1;
+        if (!ok) atomicMin (&s_first_bad, k);
+    }
+    __syncthreads ();
+    if (tid != 0) return;
+
+    SectionRegs r [S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) load_section (r [s], sections [(size_t) c * S + s]);
+
+    int k = s_first_bad;
+    unsigned int redone = 0;
+    while (k < K) {
+        // chunk k again, from the exact state its predecessor left
+        put_state<S> (r, en + (size_t)(k - 1) * S);
+        const int first = k * L, last = min (first + L, frames);
+        spec_run<S> (r, in, stride, out, out_stride, c, first, last);
+        SpecState now [S];
+        get_state<S> (now, r);
+#pragma unroll
+        for (int s = 0; s < S; ++s) en [(size_t) k * S + s] = now [s];
+        ++redone;
+        if (k + 1 >= K) break;
+        if (same_state<S> (now, st + (size_t)(k + 1) * S)) {
+            // rejoined the speculative trajectory: everything up to the next recorded mismatch stands
+            int next = k + 2;
+            while (next < K && !flags [next]) ++next;
+            k = next;
+        }
+        else ++k;
+    }
+    if (redone) atomicAdd (repairs, redone);
+
+    put_state<S> (r, en + (size_t)(K - 1) * S);
+#pragma unroll
+    for (int s = 0; s < S; ++s) store_section (sections [(size_t) c * S + s], r [s], frames, false);
 }
 
 __device__ __forceinline__ uint32_t lcg (uint32_t r) { return ((r << 4) - r) ^ 1u; }
@@ -1035,6 +1219,35 @@ static int channels_per_workgroup (int C)
 }
 
 extern "C" {
+
+// The time-parallel bit-exact cascade (biquad_spec_kernel): `d_in` -> `d_out` (distinct buffers), frames x C with the given
+// strides; W = warm-up frames per section (host: decay of the recursive part), L = chunk length.  d_states: scratch of
+// arthip_biquad_spec_scratch (C, S, frames, L) bytes.  d_repairs: device counter (chunks that had to be recomputed).
+size_t arthip_biquad_spec_scratch (int C, int S, int frames, int L)
+{
+    const size_t K = (size_t)((frames + L - 1) / L);
+    return (size_t) C * K * S * sizeof (SpecState) * 2 + (((size_t) C * K + 255) & ~(size_t) 255);
+}
+
+int arthip_biquad_spec (Biquad *d_sections, int C, int S, const art_s *d_in, int in_stride, art_s *d_out, int out_stride, int frames,
+                        int L, int W, void *d_states, unsigned int *d_repairs, void *stream)
+{
+    if (frames <= 0) return 0;
+    if (S < 1 || S > MAX_CHAIN || L < 1) return -1;
+    const int K = (frames + L - 1) / L;
+    SpecState *starts = (SpecState *) d_states, *ends = starts + (size_t) C * K * S;
+    unsigned char *bad = (unsigned char *)(ends + (size_t) C * K * S);
+    const long tasks = (long) C * K;
+    const dim3 grid ((unsigned int)((tasks + 255) / 256)), block (256);
+    hipStream_t st = (hipStream_t) stream;
+#define SPEC_GO(SS) do { \
+        hipLaunchKernelGGL (biquad_spec_kernel<SS>, grid, block, 0, st, (const Biquad *) d_sections, C, K, L, W, d_in, in_stride, d_out, out_stride, frames, starts, ends); \
+        hipLaunchKernelGGL (biquad_commit_kernel<SS>, dim3 (C), block, 0, st, d_sections, C, K, L, d_in, in_stride, d_out, out_stride, frames, \
+                            (const SpecState *) starts, ends, bad, d_repairs); } while (0)
+    switch (S) { case 1: SPEC_GO (1); break; case 2: SPEC_GO (2); break; case 3: SPEC_GO (3); break; default: SPEC_GO (4); }
+#undef SPEC_GO
+    return hipGetLastError () == hipSuccess ? 0 : -1;
+}
 
 int arthip_biquad_order2 (Biquad *d_sections, int C, int S, art_s *d_buf, int frames, int stride, void *stream)
 {

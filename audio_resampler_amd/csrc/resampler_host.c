@@ -9,12 +9,14 @@
  * without a device the init functions fail loudly.
  */
 #define _USE_MATH_DEFINES
+#define _POSIX_C_SOURCE 200809L
 #include <limits.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "art_internal.h"
 
@@ -1397,6 +1399,19 @@ ResampleResult resampleProcessAndFlushInterleavedDevice (Resample *cxt, const ar
  * ---------------------------------------------------------------------------------------- */
 typedef struct { ResampleResult res; int staged_out, failed; } HostPending;
 
+/* ARTAMD_HOST_TRACE=1: where a host-pointer call spends its time (host clock, accumulated, printed by resampleFree) */
+static int trace_on = -1;
+static double trace_acc [8]; static long trace_calls;
+static inline double trace_now (void) { struct timespec ts; clock_gettime (CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
+#define TRACE_MARK(slot) do { if (trace_on > 0) { const double now_ = trace_now (); trace_acc [slot] += now_ - trace_t_; trace_t_ = now_; } } while (0)
+static void trace_report (void)
+{
+    if (trace_on > 0 && trace_calls)
+        fprintf (stderr, "artamd host trace, us per call over %ld calls: plan+grow %.1f | pack %.1f | H2D enqueue %.1f | plan+launch %.1f | D2H enqueue %.1f | "
+                 "wait %.1f | unpack %.1f\n", trace_calls, trace_acc [0] / trace_calls, trace_acc [1] / trace_calls, trace_acc [2] / trace_calls,
+                 trace_acc [3] / trace_calls, trace_acc [4] / trace_calls, trace_acc [5] / trace_calls, trace_acc [6] / trace_calls);
+}
+
 static void host_begin (Resample *cxt, const art_s *input, int in_stride, const art_s *const *planes, int nIn,
                         art_s *output, int out_stride, art_s *const *out_planes, int cap, double ratio, HostPending *pend)
 {
@@ -1408,6 +1423,9 @@ static void host_begin (Resample *cxt, const art_s *input, int in_stride, const 
     const int staged = sizeof (art_s) * (in_samples + out_samples) <= (limit_env && *limit_env ? (size_t) strtoull (limit_env, NULL, 10) : STAGE_LIMIT);
 
     pend->res.input_used = pend->res.output_generated = 0; pend->staged_out = 0; pend->failed = 1;
+    if (trace_on < 0) { const char *e = getenv ("ARTAMD_HOST_TRACE"); trace_on = e && *e && *e != '0'; if (trace_on) atexit (trace_report); }
+    double trace_t_ = trace_on > 0 ? trace_now () : 0.0;
+    trace_calls += trace_on > 0;
 
     hip->d_in = grow (hip->d_in, &hip->in_cap, sizeof (art_s) * in_samples);
     hip->d_out = grow (hip->d_out, &hip->out_cap, sizeof (art_s) * out_samples);
@@ -1425,6 +1443,7 @@ static void host_begin (Resample *cxt, const art_s *input, int in_stride, const 
         return;
     }
 
+    TRACE_MARK (0);
     if (in_samples && staged) {
         art_s *dst = hip->h_in;
         if (planes)
@@ -1437,6 +1456,7 @@ static void host_begin (Resample *cxt, const art_s *input, int in_stride, const 
         else
             for (unsigned int f = 0; f < peek.input_used; ++f)
                 memcpy (dst + (size_t) f * C, input + (size_t) f * in_stride, sizeof (art_s) * C);
+        TRACE_MARK (1);
         arthip_h2d (hip->d_in, hip->h_in, sizeof (art_s) * in_samples, hip->stream);
     }
     else if (in_samples) {
@@ -1451,8 +1471,10 @@ static void host_begin (Resample *cxt, const art_s *input, int in_stride, const 
             arthip_copy2d (hip->d_in, sizeof (art_s) * C, input, sizeof (art_s) * in_stride, sizeof (art_s) * C, peek.input_used, hip->stream);
     }
 
+    TRACE_MARK (2);
     pend->res = enqueue_call (cxt, hip->d_in, 0, nIn, hip->d_out, 0, cap, ratio);
     pend->failed = 0;
+    TRACE_MARK (3);
 
     const unsigned int made = pend->res.output_generated;
     if (!made) return;
@@ -1469,6 +1491,7 @@ static void host_begin (Resample *cxt, const art_s *input, int in_stride, const 
         arthip_d2h (output, hip->d_out, sizeof (art_s) * (size_t) made * C, hip->stream);
     else
         arthip_copy2d (output, sizeof (art_s) * out_stride, hip->d_out, sizeof (art_s) * C, sizeof (art_s) * C, made, hip->stream);
+    TRACE_MARK (4);
 }
 
 static void host_end (Resample *cxt, art_s *output, int out_stride, art_s *const *out_planes, const HostPending *pend)
@@ -1477,7 +1500,9 @@ static void host_end (Resample *cxt, art_s *output, int out_stride, art_s *const
     const int C = cxt->numChannels;
     const unsigned int made = pend->res.output_generated;
 
+    double trace_t_ = trace_on > 0 ? trace_now () : 0.0;
     arthip_sync (hip->stream);
+    TRACE_MARK (5);
     if (!pend->staged_out || !made) return;
 
     const art_s *src = hip->h_out;
@@ -1491,6 +1516,7 @@ static void host_end (Resample *cxt, art_s *output, int out_stride, art_s *const
     else
         for (unsigned int f = 0; f < made; ++f)
             memcpy (output + (size_t) f * out_stride, src + (size_t) f * C, sizeof (art_s) * C);
+    TRACE_MARK (6);
 }
 
 static ResampleResult host_call (Resample *cxt, const art_s *input, const art_s *const *planes, int nIn,

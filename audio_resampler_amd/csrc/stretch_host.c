@@ -157,7 +157,13 @@ int stretchGetOutputCapacity (Stretch *cxt, int max_num_samples, double max_rati
     return frames;
 }
 
-void stretchHipSetStream (Stretch *cxt, void *hipStream) { cxt->hip->stream = hipStream; }
+/* (rings and state are shared between calls: the old stream is drained before the switch) */
+void stretchHipSetStream (Stretch *cxt, void *hipStream)
+{
+    if (cxt->hip->stream == hipStream) return;
+    arthip_sync (cxt->hip->stream);
+    cxt->hip->stream = hipStream;
+}
 
 static int device_call (Stretch *cxt, const art_s *d_in, int frames, art_s *d_out, double ratio, int flush)
 {

@@ -10,9 +10,12 @@ i.e. the whole hot path (host position planning, FIR kernel, history roll) for o
 `--block-frames` input frames x C channels, with the input already in HBM when timing starts.
 
 Multi-GPU (`--gpus N`, launched by torch.distributed.run): channels shard across ranks — every rank
-owns an independent 8-channel slice of an 8N-channel stream (its own context, filter-bank replica and
-history in its own HBM).  No data-path collective exists or is needed; RCCL is used
-only for the timing barrier and the max-over-ranks reduction.  Weak scaling: per-GPU work is fixed.
+owns a contiguous channel slice of ONE stream (its own context, filter-bank replica and history in its
+own HBM).  No data-path collective exists or is needed; RCCL is used only for the
+timing barrier and the max-over-ranks reduction.
+  --scaling weak   (default) 8 channels per GPU, the stream has 8N channels; N = 1 is the metric's config
+  --scaling strong ONE 32-channel stream (--total-channels), 32/N channels per GPU: BASELINE.json configs[3]
+                   (4 channels per GPU at N = 8)
 
 Prints ONE JSON line on rank 0.
 """
@@ -80,12 +83,24 @@ def cpu_baseline(channels, seconds_budget=12.0):
                                     f"{dt:.1f} s wall; 988x988 interpolating, one thread per channel"}
 
 
+def stream_slice(block, lo, hi):
+    """channels [lo, hi) of THE synthetic stream, interleaved [block, hi - lo]: channel c of the stream is artest's noise generator
+    started from seed + 2c — every rank cuts its slice out of the same stream, whatever the number of ranks"""
+    from audio_resampler_amd.synth import noise, SEED
+    cols = [noise(block, state=(SEED + 2 * c) | 1)[0] for c in range(lo, hi)]
+    return np.ascontiguousarray(np.stack(cols, axis=1))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--channels", type=int, default=8, help="channels per GPU")
+    ap.add_argument("--channels", type=int, default=8, help="weak scaling: channels per GPU")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --channels per GPU, the stream has channels x N (default; N = 1 is BASELINE.json's metric config); "
+                         "strong: ONE stream of --total-channels, total/N per GPU (BASELINE.json configs[3]: 32 channels, 4 per GPU at N = 8)")
+    ap.add_argument("--total-channels", type=int, default=32, help="strong scaling: channels of the stream")
     ap.add_argument("--block-frames", type=int, default=1 << 20, help="input frames per call")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 general, 2 MFMA")
     ap.add_argument("--preroll-ms", type=float, default=200.0, help="untimed device pre-roll before the warmup steps (clock ramp); 0 = none")
@@ -118,14 +133,18 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    Cn, block = args.channels, args.block_frames
+    from audio_resampler_amd.shard import agree_and_aggregate, channel_slice
+    block = args.block_frames
+    total_ch = args.total_channels if args.scaling == "strong" else args.channels * world
+    lo, hi = channel_slice(total_ch, world, rank)
+    Cn = hi - lo
+    if Cn < 1:
+        raise SystemExit(f"bench.py: {total_ch} channels cannot be shared among {world} ranks")
     ratio = DST / SRC
     cap = int(math.floor((block + TAPS // 2) * ratio + 10))
 
-    # this rank's channel slice of the stream: artest's noise generator, rank-decorrelated by skipping ahead
-    from audio_resampler_amd.synth import noise, SEED
-    x, _ = noise(block * Cn, state=(SEED + 2 * rank) | 1)
-    d_in = torch.from_numpy(x.reshape(block, Cn)).cuda()
+    # this rank's channel slice of the ONE stream
+    d_in = torch.from_numpy(stream_slice(block, lo, hi)).cuda()
     d_out = torch.empty(cap, Cn, device="cuda", dtype=torch.float32)
 
     rs = A.Resampler(Cn, TAPS, FILTERS, 0.0, A.BLACKMAN_HARRIS | A.SUBSAMPLE_INTERPOLATE)
@@ -140,79 +159,104 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Device pre-roll (NOT part of the W warmup steps, never timed): MI355X raises its clocks over the first tens of
-    # milliseconds of sustained load — measured on this workload: 0.213 ms per kernel in the first 5 ms, 0.179 ms after
-    # 100 ms — so a K of a few dozen 0.2 ms steps would otherwise time the ramp, not the steady state the metric means.
-    # Reported in the JSON line ("preroll_ms"); --preroll-ms 0 disables it.
+    def timed_region():
+        """W untimed warmup steps, then EXACTLY K steps between barrier + synchronize on both sides"""
+        for _ in range(args.warmup):
+            used, made = rs.process_device(d_in, block, d_out, cap, ratio)
+            assert used == block and made < cap
+        barrier()
+        rs.set_timing(True)
+        frames = 0
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            used, made = rs.process_device(d_in, block, d_out, cap, ratio)
+            frames += made
+        barrier()
+        dt = time.perf_counter() - t0
+        kernel_ms, launches = rs.read_timing()
+        rs.set_timing(False)
+        return dt, frames, kernel_ms, launches
+
+    # From cold first (reported as value_cold): MI355X raises its clocks over the first tens of milliseconds of sustained load —
+    # measured on this workload: 0.213 ms per kernel in the first 5 ms, 0.179 ms after 100 ms — so a K of a few dozen 0.2 ms
+    # steps from cold times the ramp, not the steady state the metric means.
+    cold = timed_region()
+    # Device pre-roll (NOT part of the W warmup steps, never timed), then the run `value` reports.  Disclosed in the JSON line
+    # ("preroll_ms"); --preroll-ms 0 disables it (value == a second cold-ish run then).
     if args.preroll_ms > 0:
         t_pre = time.perf_counter()
         while (time.perf_counter() - t_pre) * 1e3 < args.preroll_ms:
             for _ in range(8):
                 rs.process_device(d_in, block, d_out, cap, ratio)
             torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        used, made = rs.process_device(d_in, block, d_out, cap, ratio)
-        assert used == block and made < cap
-    barrier()
-    rs.set_timing(True)
-    out_frames = 0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        used, made = rs.process_device(d_in, block, d_out, cap, ratio)
-        out_frames += made
-    barrier()
-    dt = time.perf_counter() - t0
-    kernel_ms, launches = rs.read_timing()
+    dt, out_frames, kernel_ms, launches = timed_region()
     kernel_used = rs.last_kernel()
 
-    from audio_resampler_amd.shard import agree_and_aggregate
-    agg = agree_and_aggregate(dist, "cuda" if backend == "nccl" else "cpu", dt, out_frames, Cn, kernel_ms, launches)
+    dev = "cuda" if backend == "nccl" else "cpu"
+    agg = agree_and_aggregate(dist, dev, dt, out_frames, Cn, kernel_ms, launches)
+    agg_cold = agree_and_aggregate(dist, dev, cold[0], cold[1], Cn, cold[2], cold[3])
     dt_max, samples_total = agg["seconds_max"], agg["samples_total"]
-    assert agg["frames_consistent"], "ranks disagree on the number of generated frames"
+    assert agg["frames_consistent"] and agg_cold["frames_consistent"], "ranks disagree on the number of generated frames"
 
     if rank == 0:
-        # roofline of the dominant kernel (the FIR), from HIP events recorded around its launches on its stream
+        # Roofline of the dominant kernel (the FIR), from HIP events recorded around its launches on its stream.
+        # The matrix-core kernel folds the lerp into ONE effective row per phase (the lerp is linear), so per output sample it
+        # EXECUTES 2 x Kpad flop on the matrix cores (Kpad = the tile's K columns: 1024 for T = 988; 2 x T of them useful) —
+        # that, over the f32-MFMA peak, is `frac` (<= 1 by construction).  The reference FORMULATION (two T-tap dot products +
+        # lerp = 4T+3 flop, SURVEY.md 8(d)) at the same speed is reported separately and may exceed the peak.
         per_launch_samples = out_frames * Cn / max(launches, 1)
         avg_ms = kernel_ms / max(launches, 1)
-        tflops = per_launch_samples * FLOP_PER_SAMPLE / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        gbs = per_launch_samples * BYTES_PER_SAMPLE / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        kpad = ((TAPS + 31 + 31) // 32) * 32
+        executed_per_sample = 2 * kpad if kernel_used == 2 else FLOP_PER_SAMPLE
+        rate = per_launch_samples / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
+        tflops_exec = rate * executed_per_sample / 1e12
+        tflops_useful = rate * (2 * TAPS if kernel_used == 2 else FLOP_PER_SAMPLE) / 1e12
+        tflops_ref_form = rate * FLOP_PER_SAMPLE / 1e12
+        gbs = rate * BYTES_PER_SAMPLE / 1e9
         # HBM traffic of the dominant kernel is a PMC measurement (tools/pmc.sh: separate rocprofv3 --pmc passes, FETCH_SIZE
         # with the gfx950 wide-read correction + WRITE_SIZE); it cannot be taken inside this process, so the committed
         # per-launch figure is reported when — and only when — this run is the workload it was measured on.
         traffic = None
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
-            w = tr["workload"]
-            if kernel_used == 2 and (w["block_frames"], w["channels"], w["taps"]) == (block, Cn, TAPS) and launches == args.steps:
-                traffic = tr["traffic_bytes_per_launch"]
-        except Exception:
-            pass
+        for name in ("r2_traffic.json", "r1_traffic.json"):
+            try:
+                tr = json.load(open(os.path.join(ROOT, "profiles", name)))
+                w = tr["workload"]
+                if kernel_used == 2 and (w["block_frames"], w["channels"], w["taps"]) == (block, Cn, TAPS) and launches == args.steps:
+                    traffic = tr["traffic_bytes_per_launch"]
+                break
+            except Exception:
+                continue
+        mode = (f"weak scaling: {Cn} channels per GPU" if args.scaling == "weak"
+                else f"STRONG scaling: one {total_ch}-channel stream, {total_ch}/{world} channels per GPU")
         line = {
             "metric": "Msamples/s (out) 44.1k->48k preset -4, 8ch float32",
             "value": round(samples_total / dt_max / 1e6, 2),
             "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "preroll_ms": args.preroll_ms,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "preroll_ms": args.preroll_ms,
+            "value_cold": round(agg_cold["samples_total"] / agg_cold["seconds_max"] / 1e6, 2),
+            "value_cold_note": "the same W warmup + K timed steps run first, from cold clocks, before the untimed pre-roll",
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{Cn * world}-channel stream ({Cn} ch/GPU), 44100->48000 Hz, preset -4 = 988 filters x 988 taps "
-                                   f"Blackman-Harris interpolating (artest -4 -c8), float32 interleaved, {block} input frames per call, "
-                                   f"device-resident in/out, resampleProcessInterleavedDevice",
-                       "channels_per_gpu": Cn, "block_frames": block, "taps": TAPS, "filters": FILTERS,
+            "config": {"workload": f"{mode}; ranks take contiguous channel slices of ONE {total_ch}-channel stream; 44100->48000 Hz, "
+                                   f"preset -4 = 988 filters x 988 taps Blackman-Harris interpolating (artest -4 -c8), float32 interleaved, "
+                                   f"{block} input frames per call, device-resident in/out, resampleProcessInterleavedDevice",
+                       "stream_channels": total_ch, "channels_per_gpu": Cn, "block_frames": block, "taps": TAPS, "filters": FILTERS,
                        "fir_kernel": {1: "general", 2: "mfma"}.get(kernel_used, str(kernel_used)),
-                       "parallelism": f"channel-shard x{world}, no data-path collective"},
-            "roofline": {"bound": "mfma", "achieved": round(tflops, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(tflops / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
+                       "parallelism": f"channel-shard x{world}, no data-path collective",
+                       "accuracy": "default mode: |y - fp64-accumulate| <= 2^-23 max(1,|y|) (2 ulp on < 0.1 % of samples when |y| > 1, as the "
+                                   "reference's own float build); RESAMPLE_STRICT_ORDER is bit-exact"},
+            "roofline": {"bound": "mfma", "achieved": round(tflops_exec, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tflops_exec / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "bytes/launch (HBM, PMC)", "algorithmic_bytes_per_launch": int(per_launch_samples * BYTES_PER_SAMPLE),
                          "kernel": "fir", "avg_kernel_ms": round(avg_ms, 4), "launches": launches,
-                         "flop_per_sample": FLOP_PER_SAMPLE, "bytes_per_sample": round(BYTES_PER_SAMPLE, 3),
-                         # the MFMA kernel folds the lerp into one effective row per phase: it EXECUTES 2*Kpad flop per
-                         # sample on the matrix cores (Kpad = 1024 columns for T = 988), half the algorithmic count
-                         "executed_mfma_TFLOPs": round(tflops * (2 * 1024) / FLOP_PER_SAMPLE, 3) if kernel_used == 2 else None,
-                         "executed_frac": round(tflops * (2 * 1024) / FLOP_PER_SAMPLE / PEAK_FP32_TFLOPS, 4) if kernel_used == 2 else None,
-                         "note": "achieved/frac use the ALGORITHMIC 4T+3 flop per sample of the reference formulation (SURVEY 8d); the kernel "
-                                 "blends the two interpolation rows once per phase (lerp is linear), so frac can exceed 1 while the matrix "
-                                 "cores run at executed_frac of their f32 peak",
+                         "flop_per_sample_executed": executed_per_sample, "bytes_per_sample": round(BYTES_PER_SAMPLE, 3),
+                         "useful_frac": round(tflops_useful / PEAK_FP32_TFLOPS, 4),
+                         "algorithmic_vs_reference_formulation": round(tflops_ref_form / PEAK_FP32_TFLOPS, 4),
+                         "note": "achieved/frac = flop the kernel EXECUTES on the matrix cores (2 x Kpad per sample, lerp folded into one "
+                                 "row per phase) over the f32-MFMA peak; useful_frac counts only the 2 x T non-padding columns; "
+                                 "algorithmic_vs_reference_formulation prices the same samples/s at the reference's 4T+3 flop per "
+                                 "sample (SURVEY 8d) and is not a roofline fraction",
                          "hbm_algorithmic_GBps": round(gbs, 2), "hbm_frac": round(gbs / PEAK_HBM_GBS, 5)},
         }
         if world == 1 and not args.no_cpu_baseline:

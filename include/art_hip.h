@@ -104,6 +104,11 @@ void biquadBankSetStream (BiquadBank *bank, void *hipStream);
 void biquadBankApplyInterleavedDevice (BiquadBank *bank, artsample_t *d_buffer, int numFrames);
 void biquadBankRead (BiquadBank *bank, Biquad *sections);      /* synchronises; copies state back */
 void biquadBankFree (BiquadBank *bank);
+/* Long runs of filters that forget their state within 1,024 frames are computed parallel over TIME, still bit for bit the
+ * reference's recurrence: chunks start from a warm-up, every chunk boundary is verified exactly and a mismatch recomputed
+ * (pcm_kernels.hip, biquad_spec_kernel).  These report how many chunks had to be recomputed so far (normally 0). */
+unsigned int biquadBankRepairs (BiquadBank *bank);   /* synchronises */
+unsigned int artamdBiquadRepairs (void);             /* the host-pointer calls (biquad_apply_buffer) of this process */
 
 /* ---- decimator, device pointers ---- */
 void decimateHipSetStream (Decimate *cxt, void *hipStream);

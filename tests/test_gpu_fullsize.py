@@ -102,6 +102,24 @@ def test_bench_line_keeps_its_contract():
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # a roofline fraction: what the matrix cores execute over their peak, never above 1; the reference-formulation figure is separate
+    assert 0.0 < r["frac"] <= 1.0 and r["useful_frac"] <= r["frac"] and "algorithmic_vs_reference_formulation" in r
+    assert "value_cold" in d and d["value_cold"] > 0
     # value is whole-job samples over the timed region: consistent with ms_per_step and the workload's size
     per_step = d["value"] * 1e6 * d["ms_per_step"] * 1e-3
     assert abs(per_step - (1 << 20) * 8 * 48000 / 44100) / per_step < 0.01
+
+
+def test_bench_strong_mode_is_one_32_channel_stream():
+    """--scaling strong: ONE 32-channel stream (BASELINE.json configs[3]) cut 32/N per GPU; on one GPU the rank owns all 32"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--scaling", "strong", "--steps", "3", "--warmup", "1",
+                          "--preroll-ms", "0", "--block-frames", "262144", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["config"]["stream_channels"] == 32 and d["config"]["channels_per_gpu"] == 32
+    assert "STRONG" in d["config"]["workload"] and d["config"]["fir_kernel"] == "mfma" and d["roofline"]["frac"] <= 1.0
+    per_step = d["value"] * 1e6 * d["ms_per_step"] * 1e-3
+    assert abs(per_step - 262144 * 32 * 48000 / 44100) / per_step < 0.01

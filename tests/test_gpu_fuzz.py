@@ -39,9 +39,6 @@ def random_session(seed):
         kind = int(rng.integers(0, 12))
         n = int(rng.integers(0, 8 * T + 50)) if kind < 8 else int(rng.integers(14 * T, 19 * T)) if kind < 10 else int(rng.integers(0, 4))
         cap = int(rng.integers(1, 12 * T + 64)) if kind != 3 else int(rng.integers(1, 12))
-        if first and extrap:          # documented corner: the first output must come from an ordinary call, before any ring rewind
-            n, cap = max(n, 2 * T + 16), max(cap, 64)
-            n = min(n, 12 * T)
         first = False
         r = ratio * (1 + rng.uniform(-2e-4, 2e-4)) if (kind == 5 and mode == 0) else ratio
         calls.append(("run", n, cap, r))
