@@ -601,9 +601,13 @@ Resample *resampleFixedRatioInit (int numChannels, int numTaps, int maxFilters, 
     return cxt;
 }
 
+static int trace_on = -1;
+static void trace_report (void);
+
 void resampleFree (Resample *cxt)
 {
     if (!cxt) return;
+    trace_report ();                        /* (ARTAMD_HOST_TRACE: per-context figures) */
 
     struct artamd_resampler *hip = cxt->hip;
 
@@ -1400,16 +1404,17 @@ ResampleResult resampleProcessAndFlushInterleavedDevice (Resample *cxt, const ar
 typedef struct { ResampleResult res; int staged_out, failed; } HostPending;
 
 /* ARTAMD_HOST_TRACE=1: where a host-pointer call spends its time (host clock, accumulated, printed by resampleFree) */
-static int trace_on = -1;
 static double trace_acc [8]; static long trace_calls;
 static inline double trace_now (void) { struct timespec ts; clock_gettime (CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
 #define TRACE_MARK(slot) do { if (trace_on > 0) { const double now_ = trace_now (); trace_acc [slot] += now_ - trace_t_; trace_t_ = now_; } } while (0)
 static void trace_report (void)
 {
-    if (trace_on > 0 && trace_calls)
+    if (trace_on > 0 && trace_calls) {
         fprintf (stderr, "artamd host trace, us per call over %ld calls: plan+grow %.1f | pack %.1f | H2D enqueue %.1f | plan+launch %.1f | D2H enqueue %.1f | "
                  "wait %.1f | unpack %.1f\n", trace_calls, trace_acc [0] / trace_calls, trace_acc [1] / trace_calls, trace_acc [2] / trace_calls,
                  trace_acc [3] / trace_calls, trace_acc [4] / trace_calls, trace_acc [5] / trace_calls, trace_acc [6] / trace_calls);
+        memset (trace_acc, 0, sizeof (trace_acc)); trace_calls = 0;
+    }
 }
 
 static void host_begin (Resample *cxt, const art_s *input, int in_stride, const art_s *const *planes, int nIn,
