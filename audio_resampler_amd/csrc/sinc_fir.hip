@@ -437,6 +437,7 @@ struct MfmaGeom {
     // the head of the call as ONE contiguous array (history ++ first input frames, MF_HEAD_PAD zero frames in front): tiles that
     // reach into the history stage from it exactly as all others stage from `in` (written by mfma_prepare_kernel)
     float *head; int head_frames;
+    int *tile_w0;                         // [slot_tiles] linear index of K column 0 of each slot tile in period 0 of the launch (streaming kernel)
 };
 
 typedef unsigned int u32x4 __attribute__ ((ext_vector_type (4)));
@@ -475,6 +476,7 @@ void mfma_prepare_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
     if (tid == 0) {
         g.canon_ip [st * R + row] = p.ip; g.canon_fi [st * R + row] = p.fi; g.canon_frac [st * R + row] = p.frac;
         if (st == 0 && row == 0) a.fix_count [0] = 0;       // per-launch count of off-pattern outputs (the main kernel follows in-stream)
+        if (row == 0 && g.tile_w0) g.tile_w0 [st] = p0.ip - a.T / 2 + 1;
     }
     const float *h0 = a.bank + (size_t) p.fi * a.T;
     const int shift = p.ip - p0.ip;
@@ -637,11 +639,7 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
                 // select, not left to wrap as a negative number — the compiler may split an offset into register + immediate,
                 // and the hardware's range check does not wrap that sum to 32 bits (a "negative" base plus a positive
                 // immediate would be rejected although the true offset is valid).
-#ifdef ABL_BL1     // ablation: the same number of X loads, all inside 16 KB (vL1D hits) — separates issue cost from L2->L1 bandwidth
-                const unsigned int oi = ((unsigned int)((lin - a.H) * CG + cv * VEC) * 4u) & 0x3ff0u;
-#else
                 const unsigned int oi = lin >= a.H ? (unsigned int)((lin - a.H) * CG + cv * VEC) * 4u : 0xfffffff0u;
-#endif
                 VecLoad<VEC>::load (&rb [u * VEC], rs_in, oi);
                 if (touches_hist) {
                     float hv [VEC];
@@ -729,23 +727,13 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int m = 0; m < NT; ++m) {
-#ifndef ABL_NOMFMA
                         acc [m] = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [m] [q], bv [q], acc [m], 0, 0, 0);
-#else
-                        acc [m] [q] += av [m] [q] * bv [q];
-#endif
                     }
             }
 #pragma unroll
             for (int m = 0; m < NT; ++m) {
-#ifndef ABL_NOFLUSH
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sum [m] [r] = sum [m] [r] + (double) acc [m] [r];
-#else
-#pragma unroll
-                for (int r = 0; r < 16; ++r) asm volatile ("" :: "v" (acc [m] [r]));
-                sum [m] [0] = sum [m] [0] + (double) acc [m] [0];
-#endif
             }
         }
         else {
@@ -836,10 +824,8 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
                 fetch (0, ra0, rb0); commit (0, 0, ra0, rb0); fetch (1, ra0, rb0);
                 __syncthreads ();
                 for (int chunk = 0; chunk < nchunks; ++chunk) {
-#ifndef ABL_NOLOAD
                     commit (chunk + 1, (chunk & 1) ^ 1, ra0, rb0);       // past-the-end chunks: loads return 0 / LDS unread
                     fetch (chunk + 2, ra0, rb0);
-#endif
                     __syncthreads ();
                 }
                 return;
@@ -954,6 +940,299 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
                 const size_t n = (size_t) n_tile + (size_t) jl * g.P + i;
                 a.out [n * a.C + ch_base + c] = direct_sample<INTERP> (a, INT_MIN, locate<INTERP> (a, segs, (unsigned int) n), ch_base + c);
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Streaming form of the matrix-core kernel: PERSISTENT workgroups, for REGULAR launches.
+//
+// fir_mfma_kernel spends 14 of its 59 us per tile outside the K loop — the per-output position replay in front of it, the
+// branchy store loop behind it, the pipeline filling up again for every tile — while three workgroups per CU cover only part
+// of that for each other.  Here a workgroup takes a strided list of tiles of its XCD (same XCD-contiguous order as the
+// one-tile-per-workgroup grid) and the two roles never stop between tiles:
+//   * the staging waves run ONE chunk stream across all of the workgroup's tiles (chunk c+2 of the flattened sequence is
+//     in flight, c+1 is being committed, while the matrix waves consume c): the first chunks of the next tile are staged
+//     while the last ones of the current tile are multiplied;
+//   * the matrix waves finish a tile with 16 conversions and 16 buffer stores (addresses: one per-lane offset + immediates,
+//     tile base and range check in the buffer resource: out-of-range rows are dropped by the hardware) and go straight on.
+// What makes the position replay unnecessary is decided on the HOST, per launch (mfma_launch_is_regular): every output's
+// position differs from its slot's canonical lattice position by less than MF_PHASE_TOL filter steps — a bound on the
+// reference's own fp64 arithmetic (two roundings of n/ratio, one of the addition), so all outputs would have taken the
+// status-0 path of fir_mfma_kernel — and, in nearest-filter mode, no slot sits close enough to a half step for a period to
+// round to another filter.  Launches that fail the test (calls beyond a few million frames, drifting ratios do not get here
+// at all) run fir_mfma_kernel.  Same tiles, same K order, same flush schedule: the two kernels produce identical bits.
+// ---------------------------------------------------------------------------------------------------
+template <bool INTERP, int CG>
+__global__ __launch_bounds__ (2 * MF_THREADS) __attribute__ ((amdgpu_waves_per_eu (6)))
+void fir_mfma_stream_kernel (ArtFirArgs a, MfmaGeom g, int wgs_per_xcd)
+{
+    constexpr int THREADS = 2 * MF_THREADS;
+    constexpr int PPW = MF_COLS / CG > MF_MAX_PPW ? MF_MAX_PPW : MF_COLS / CG;
+    constexpr int NCOLS = PPW * CG;
+    __shared__ __attribute__ ((aligned (16))) float As_ [2] [32 * MF_LD];
+    __shared__ __attribute__ ((aligned (16))) float Bs_ [2] [MF_COLS * MF_LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool loader = wave >= 4;
+    const int pt = tid & (MF_THREADS - 1);
+
+    const unsigned int stream_blocks = 8u * (unsigned int) wgs_per_xcd;
+    if (blockIdx.x >= stream_blocks) {                        // extra workgroups: the history roll (as in fir_mfma_kernel)
+        if (a.roll_dst) {
+            const int e = (int)(blockIdx.x - stream_blocks) * THREADS + tid;
+            if (e < a.H * a.C) {
+                const int f = e / a.C, c = e - f * a.C, lin = a.roll_appended + f;
+                float v = 0.0f;
+                if (lin < a.H) v = a.hist [(size_t) lin * a.C + c];
+                else if (a.in && lin - a.H < a.in_frames) v = a.in [(size_t)(lin - a.H) * a.C + c];
+                a.roll_dst [e] = v;
+            }
+        }
+        return;
+    }
+
+    const int xcd = blockIdx.x & 7, rank = blockIdx.x >> 3;
+    const int tiles_per_xcd = g.groups_per_xcd * g.slot_tiles;
+    const int nchunks = g.ktot / MF_KC;
+
+    // tile `within` of this XCD's list -> (slot tile, period group); false past the last valid tile (validity is monotone)
+    auto tile_at = [&] (int within, int &st, int &jg) -> bool {
+        if (within >= tiles_per_xcd) return false;
+        st = within % g.slot_tiles; jg = xcd * g.groups_per_xcd + within / g.slot_tiles;
+        if (jg >= g.period_groups) return false;
+        return a.n_begin + (unsigned int)(jg * PPW) * g.P + (unsigned int)(st * 32) < a.n_end;
+    };
+
+    if (NCOLS < MF_COLS)                                      // unused columns stay zero for the whole kernel
+        for (int e = tid; e < (MF_COLS - NCOLS) * MF_LD; e += THREADS)
+            for (int b = 0; b < 2; ++b) Bs_ [b] [NCOLS * MF_LD + e] = 0.0f;
+
+    if (loader) {
+        constexpr int VEC = CG >= 4 ? 4 : (CG == 2 ? 2 : 1);
+        constexpr int VPF = CG / VEC, VPP = MF_KC * VPF, NB = (PPW * VPP) / MF_THREADS;
+        constexpr unsigned int A_STEP = MF_KC * 4u, B_STEP = MF_KC * CG * 4u;
+        const int a_row = pt >> 3, a_kseg = (pt & 7) * 4;
+        const unsigned int a_off0 = (unsigned int)(a_row * g.ktot + a_kseg) * 4u;
+        const int adst = a_row * MF_LD + a_kseg;
+        unsigned int boff [NB]; int bdst [NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int v = pt + u * MF_THREADS;
+            const int jl = v / VPP, rem = v % VPP, kk = rem / VPF, cv = rem % VPF;
+            boff [u] = (unsigned int)((jl * g.Q + kk) * CG + cv * VEC) * 4u;       // (the tile's window origin sits in the resource base)
+            bdst [u] = (jl * CG + cv * VEC) * MF_LD + kk;
+        }
+        float ra0 [4], rb0 [NB * VEC];
+
+        // the fetch stream: tile being fetched, its bases, the chunk to fetch next (all uniform)
+        int f_within = rank, f_chunk = 0;
+        bool f_live = false;
+        const char *fa_base = nullptr, *fb_base = nullptr;
+        unsigned int fa_bytes = 0, fb_bytes = 0;
+        auto open_tile = [&] () {
+            int st, jg;
+            f_live = tile_at (f_within, st, jg);
+            if (!f_live) return;
+            const int w0 = g.tile_w0 [st] + jg * PPW * g.Q;
+            const bool touches_hist = w0 < a.H;              // (first period group of a call: staged from the gathered head)
+            const int origin = touches_hist ? -MF_HEAD_PAD : a.H;
+            const char *base = touches_hist ? reinterpret_cast<const char *> (g.head) : reinterpret_cast<const char *> (a.in);
+            const size_t total = touches_hist ? (size_t) g.head_frames * a.C * 4 : (size_t) a.in_frames * a.C * 4;
+            size_t skip = (size_t) max (w0 - origin, 0) * CG * 4;
+            if (skip > total) skip = total;
+            fb_base = base + skip; fb_bytes = (unsigned int)(total - skip);
+            fa_base = reinterpret_cast<const char *> (g.eff + (size_t) st * 32 * g.ktot);
+            fa_bytes = (unsigned int)((size_t) 32 * g.ktot * 4);
+        };
+        auto fetch_next = [&] () {
+            if (f_live) {
+                const unsigned int sa = min ((unsigned int) f_chunk * A_STEP, fa_bytes), sb = min ((unsigned int) f_chunk * B_STEP, fb_bytes);
+                const __amdgpu_buffer_rsrc_t ra_ = make_rsrc (fa_base + sa, fa_bytes - sa), rb_ = make_rsrc (fb_base + sb, fb_bytes - sb);
+                VecLoad<4>::load (ra0, ra_, a_off0);
+#pragma unroll
+                for (int u = 0; u < NB; ++u) VecLoad<VEC>::load (&rb0 [u * VEC], rb_, boff [u]);
+                if (++f_chunk == nchunks) { f_chunk = 0; f_within += wgs_per_xcd; open_tile (); }
+            }
+        };
+        auto commit = [&] (auto buf_tag) {
+            constexpr int BUF = decltype (buf_tag)::value;
+            f32x4 v; v [0] = ra0 [0]; v [1] = ra0 [1]; v [2] = ra0 [2]; v [3] = ra0 [3];
+            *reinterpret_cast<f32x4 *> (&As_ [BUF] [adst]) = v;
+#pragma unroll
+            for (int u = 0; u < NB; ++u)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) Bs_ [BUF] [bdst [u] + e * MF_LD] = rb0 [u * VEC + e];
+        };
+
+        // chunks this workgroup will consume in total (the matrix waves count the same way)
+        int my_tiles = 0;
+        { int st, jg; for (int w = rank; tile_at (w, st, jg); w += wgs_per_xcd) ++my_tiles; }
+        const int total = my_tiles * nchunks;
+        if (total == 0) return;
+
+        open_tile ();
+        fetch_next (); commit (std::integral_constant<int, 0> {}); fetch_next ();
+        __syncthreads ();
+        for (int q = 0; q < total; q += 2) {
+            commit (std::integral_constant<int, 1> {}); fetch_next ();       // (past the end: registers are stale, the LDS is not read)
+            __syncthreads ();
+            if (q + 1 < total) {
+                commit (std::integral_constant<int, 0> {}); fetch_next ();
+                __syncthreads ();
+            }
+        }
+        return;
+    }
+
+    // ---- matrix waves ----
+    int my_tiles = 0;
+    { int st, jg; for (int w = rank; tile_at (w, st, jg); w += wgs_per_xcd) ++my_tiles; }
+    if (my_tiles == 0) return;
+
+    const int arow = (lane & 31) * MF_LD + 4 * (lane >> 5);
+    const int brow = (wave * 32 + (lane & 31)) * MF_LD + 4 * (lane >> 5);
+    const int col = wave * 32 + (lane & 31);
+    const bool col_live = col < NCOLS;
+    const int jl = col / CG, c = col - jl * CG;
+    // output offset of this lane inside a tile: (period jl, slot 4 * (lane >> 5), channel c); the row's own 0..3 / +8 / +16 / +24
+    // slots are immediates of the store
+    const unsigned int out_off = (unsigned int)((jl * g.P + 4 * (lane >> 5)) * CG + c) * 4u;
+
+    const int lo_band = g.band_lo / MF_KC, hi_band = (g.band_hi + MF_KC - 1) / MF_KC;
+    int near_lo = lo_band - MF_PAIR_TAPS / MF_KC, near_hi = hi_band + MF_PAIR_TAPS / MF_KC;
+    if (near_lo < 0) near_lo = 0;
+    if (near_hi > nchunks) near_hi = nchunks;
+    near_lo &= ~1;
+
+    double sum [16];
+
+    // one tile's K loop.  PAR: parity of the tile's first chunk in the workgroup's chunk stream (= its LDS buffer).
+    auto tile_k_loop = [&] (auto par_tag) {
+        constexpr int PAR = decltype (par_tag)::value;
+        auto mfma16 = [&] (auto fresh_tag, f32x16 &acc, int buf) {
+            const float *As = As_ [buf ^ PAR], *Bs = Bs_ [buf ^ PAR];
+#pragma unroll
+            for (int grp = 0; grp < MF_KC / 8; ++grp) {
+                const f32x4 bv = *reinterpret_cast<const f32x4 *> (&Bs [brow + grp * 8]);
+                const f32x4 av = *reinterpret_cast<const f32x4 *> (&As [arow + grp * 8]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (decltype (fresh_tag)::value && grp == 0 && q == 0) {
+                        f32x16 z;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) z [r] = 0.0f;
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [q], bv [q], z, 0, 0, 0);
+                    }
+                    else acc = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [q], bv [q], acc, 0, 0, 0);
+                }
+                if (grp == 1) __builtin_amdgcn_sched_barrier (0);       // operands of two groups at a time (registers)
+            }
+        };
+        auto runs = [&] (auto n_tag, int from, int to) {        // [from, to): a multiple of N chunks, from even; N chunks per flush
+            constexpr int N = decltype (n_tag)::value;
+            for (int chunk = from; chunk < to; chunk += N) {
+                f32x16 acc;
+                mfma16 (std::true_type {}, acc, 0);
+#pragma unroll
+                for (int q = 1; q < N; ++q) {
+                    __syncthreads ();
+                    mfma16 (std::false_type {}, acc, q & 1);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum [r] = sum [r] + (double) acc [r];
+                __syncthreads ();
+            }
+        };
+        auto singles = [&] (int from, int to) {
+            for (int chunk = from; chunk < to; ++chunk) {
+                const float *As = As_ [(chunk & 1) ^ PAR], *Bs = Bs_ [(chunk & 1) ^ PAR];
+                const int k0 = chunk * MF_KC;
+                const bool band = k0 < g.band_hi && k0 + MF_KC > g.band_lo;
+                if (!band) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc [r] = 0.0f;
+#pragma unroll
+                    for (int grp = 0; grp < MF_KC / 8; ++grp) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4 *> (&Bs [brow + grp * 8]);
+                        const f32x4 av = *reinterpret_cast<const f32x4 *> (&As [arow + grp * 8]);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [q], bv [q], acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sum [r] = sum [r] + (double) acc [r];
+                }
+                else {
+#pragma unroll
+                    for (int grp = 0; grp < MF_KC / 8; ++grp) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4 *> (&Bs [brow + grp * 8]);
+                        const f32x4 av = *reinterpret_cast<const f32x4 *> (&As [arow + grp * 8]);
+#pragma unroll
+                        for (int q = 0; q < 4; q += 2) {
+                            f32x16 acc;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc [r] = 0.0f;
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [q], bv [q], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [q + 1], bv [q + 1], acc, 0, 0, 0);
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) sum [r] = sum [r] + (double) acc [r];
+                        }
+                    }
+                }
+                __syncthreads ();
+            }
+        };
+        const std::integral_constant<int, 2> two; const std::integral_constant<int, 4> four;
+        // the same walk as fir_mfma_kernel: quads far left of the band, pairs, singles through the band, pairs, quads, leftovers
+        int quad_lo = (lo_band - MF_QUAD_TAPS / MF_KC) & ~3;  if (quad_lo < 0) quad_lo = 0;  if (quad_lo > near_lo) quad_lo = near_lo & ~3;
+        runs (four, 0, quad_lo);
+        runs (two, quad_lo, quad_lo + ((near_lo - quad_lo) & ~1));
+        const int tail_from = near_hi + (near_hi & 1);
+        singles (quad_lo + ((near_lo - quad_lo) & ~1), tail_from < nchunks ? tail_from : nchunks);
+        if (tail_from < nchunks) {
+            int quad_from = hi_band + MF_QUAD_TAPS / MF_KC;  quad_from += quad_from & 1;  if (quad_from < tail_from) quad_from = tail_from;
+            if (quad_from > nchunks) quad_from = tail_from + ((nchunks - tail_from) & ~1);
+            runs (two, tail_from, quad_from);
+            const int quad_to = quad_from + ((nchunks - quad_from) & ~3);
+            runs (four, quad_from, quad_to);
+            const int pair_to = quad_to + ((nchunks - quad_to) & ~1);
+            runs (two, quad_to, pair_to);
+            singles (pair_to, nchunks);
+        }
+    };
+
+    __syncthreads ();                                        // the staging waves have committed chunk 0
+    int parity = 0;
+    for (int within = rank, t = 0; t < my_tiles; within += wgs_per_xcd, ++t) {
+        int st, jg;
+        (void) tile_at (within, st, jg);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum [r] = 0.0;
+
+        if (parity) tile_k_loop (std::integral_constant<int, 1> {});
+        else tile_k_loop (std::integral_constant<int, 0> {});
+        parity ^= nchunks & 1;
+
+        // ---- the tile's outputs: C/D layout of 32x32: row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31
+        const unsigned int n_tile = a.n_begin + (unsigned int)(jg * PPW) * g.P + (unsigned int)(st * 32);
+        const int rows_valid = min (32, g.P - st * 32);
+        const size_t left = (size_t)(a.n_end - n_tile) * CG * 4;
+        const __amdgpu_buffer_rsrc_t rs_out = make_rsrc (a.out + (size_t) n_tile * CG, left > 0xffffff00ull ? 0xffffff00u : (unsigned int) left);
+        const bool pass_through_possible = !INTERP && !a.lowpass;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i_const = (r & 3) + 8 * (r >> 2);      // compile-time part of the slot
+            float y = (float) sum [r];
+            const int i = i_const + 4 * (lane >> 5);
+            if (pass_through_possible) {
+                // nearest-filter mode, the position falls exactly on an input sample: the reference copies it (resampler.c:1166-1170)
+                const int fi = g.canon_fi [st * 32 + min (i, rows_valid - 1)];
+                if ((fi % a.F) == 0)
+                    y = load_frame (a, INT_MIN, g.canon_ip [st * 32 + min (i, rows_valid - 1)] + (jg * PPW + jl) * g.Q + fi / a.F, c);
+            }
+            if (col_live && i < rows_valid)                  // (frames at or past n_end: out of the resource's range, dropped)
+                __builtin_amdgcn_raw_buffer_store_b32 (__float_as_uint (y), rs_out, (int)(out_off + (unsigned int)(i_const * CG) * 4u), 0, 0);
         }
     }
 }
@@ -1349,6 +1628,36 @@ static int run_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_
     return launch_general<1> (a, segs, st);
 }
 
+#if !ART_WIDE
+// May fir_mfma_stream_kernel run this launch (it never replays an output's position)?  Every output n of the launch sits at
+// fl (base_e + fl (n / ratio)) (reference resampler.c:526, :1149); with ratio = fl (P / Q) the lattice the tiles assume is
+// base_e + n Q / P, and the three roundings in between move a position by at most
+//     dev = frames * 2^-52 + 2e-12   input frames   (frames = input frames from the start of the call; ring positions < 2^14)
+// — canonical slots included, so two positions of one slot differ by at most 2 dev.  Interpolating: that is inside
+// MF_PHASE_TOL filter steps, i.e. every output would have passed fir_mfma_kernel's own test.  Nearest-filter mode: the
+// rounded filter index must be the same in every period, so no slot may sit within 2 dev of a half step.
+static bool mfma_launch_is_regular (const ArtFirArgs *a, const ArtSegTable *segs)
+{
+    const double frames = (double) a->n_end / a->ratio + a->T + 2.0;
+    const double dev_steps = 2.0 * (frames * 0x1p-52 + 2e-12) * a->F;
+    if (!(dev_steps <= MF_PHASE_TOL)) return false;
+    if (a->interpolate) return true;
+    for (int i = 0; i < a->period_out; ++i) {
+        const unsigned int n = a->n_begin + (unsigned int) i;
+        if (n >= a->n_end) break;
+        int e = 0;
+        while (e + 1 < segs->count && segs->first [e + 1] <= n) ++e;
+        const double step = n ? (double) n / a->ratio : 0.0;
+        const double off = segs->base [e] + step;
+        double fr = off - floor (off);
+        fr = fr * (double) a->F;
+        const double t = fr + 0.5, d = t - floor (t);
+        if (d < dev_steps + 1e-9 || 1.0 - d < dev_steps + 1e-9) return false;
+    }
+    return true;
+}
+#endif
+
 // does this call take the matrix-core path (arthip_fir), or the general kernel?  One rule, also asked by the batched entry
 // point, which only gathers calls the general kernel would have run anyway.
 static bool takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref)
@@ -1503,12 +1812,13 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
             g.canon_frac = (double *)(base + ((eff_bytes + 15) & ~(size_t) 15));
             g.canon_ip = (int *)(g.canon_frac + rows);
             g.canon_fi = g.canon_ip + rows;
-            if (!base || (size_t)((char *)(g.canon_fi + rows) - base) > a->scratch_bytes) goto general_path;
+            g.tile_w0 = g.canon_fi + rows;
+            if (!base || (size_t)((char *)(g.tile_w0 + g.slot_tiles) - base) > a->scratch_bytes) goto general_path;
             g.head = nullptr; g.head_frames = 0;
             if (ws && !wide) {
                 // the call's head as one contiguous array: everything a tile whose window starts inside the history can read
                 // (+ the two chunks the staging runs ahead)
-                const size_t used = (((size_t)((char *)(g.canon_fi + rows) - base)) + 255) & ~(size_t) 255;
+                const size_t used = (((size_t)((char *)(g.tile_w0 + g.slot_tiles) - base)) + 255) & ~(size_t) 255;
                 g.head_frames = MF_HEAD_PAD + a->H + (g.ppw - 1) * g.Q + g.ktot + 3 * MF_KC;
                 if (used + (size_t) g.head_frames * a->C * sizeof (float) > a->scratch_bytes) goto general_path;
                 g.head = (float *)(base + used);
@@ -1521,6 +1831,25 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
         if (a->interpolate) hipLaunchKernelGGL (mfma_prepare_kernel<true>, dim3 (g.slot_tiles, g.tile_rows), dim3 (256), 0, st, *a, *segs, g);
         else hipLaunchKernelGGL (mfma_prepare_kernel<false>, dim3 (g.slot_tiles, g.tile_rows), dim3 (256), 0, st, *a, *segs, g);
         if (a->ev_start) arthip_event_record (a->ev_start, stream);
+
+        // Regular launches (all but very long calls and nearest-filter phases on a half step) stream their tiles through
+        // persistent workgroups: three per CU, each with an equal share of its XCD's tile list.  kernel_pref 5 pins the
+        // one-tile-per-workgroup kernel (identical results; comparisons, tests).
+        if (ws && !wide && kernel_pref != 5 && (size_t) a->n_end * a->C * 4 < 0xffff0000ull && mfma_launch_is_regular (a, segs)) {
+            const int tiles_per_xcd = g.groups_per_xcd * g.slot_tiles;
+            const int resident = 96;                                        // 32 CUs per XCD x 3 workgroups (80 VGPRs, 46 KB of LDS)
+            const int rounds = (tiles_per_xcd + resident - 1) / resident;
+            const int wgs_per_xcd = (tiles_per_xcd + rounds - 1) / rounds;
+            const dim3 sgrid ((unsigned int)(8 * wgs_per_xcd) + roll_blocks);
+#define MS_GO(I, CGT) hipLaunchKernelGGL ((fir_mfma_stream_kernel<I, CGT>), sgrid, dim3 (2 * MF_THREADS), 0, st, *a, g, wgs_per_xcd)
+            if (a->interpolate) switch (cgt) { case 32: MS_GO (true, 32); break; case 16: MS_GO (true, 16); break; case 8: MS_GO (true, 8); break;
+                                                case 4: MS_GO (true, 4); break; case 2: MS_GO (true, 2); break; default: MS_GO (true, 1); }
+            else                switch (cgt) { case 32: MS_GO (false, 32); break; case 16: MS_GO (false, 16); break; case 8: MS_GO (false, 8); break;
+                                                case 4: MS_GO (false, 4); break; case 2: MS_GO (false, 2); break; default: MS_GO (false, 1); }
+#undef MS_GO
+            if (a->ev_stop) arthip_event_record (a->ev_stop, stream);
+            return hipGetLastError () == hipSuccess ? (ART_KERNEL_MFMA | (a->roll_dst ? ART_FIR_ROLLED : 0)) : -1;
+        }
 #define MF_GO(I, CGT) do { if (wide && CGT) hipLaunchKernelGGL ((fir_mfma_kernel<I, CGT, (CGT != 0), (CGT != 0 ? 2 : 1)>), grid, dim3 (2 * MF_THREADS), 0, st, *a, *segs, g); \
                            else if (ws && CGT) hipLaunchKernelGGL ((fir_mfma_kernel<I, CGT, (CGT != 0), 1>), grid, dim3 (2 * MF_THREADS), 0, st, *a, *segs, g); \
                            else hipLaunchKernelGGL ((fir_mfma_kernel<I, CGT, false, 1>), grid, dim3 (MF_THREADS), 0, st, *a, *segs, g); } while (0)

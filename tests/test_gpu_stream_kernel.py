@@ -1,0 +1,83 @@
+"""GPU (-m gpu): the persistent ("streaming") form of the matrix-core kernel (sinc_fir.hip, fir_mfma_stream_kernel) against the
+one-tile-per-workgroup kernel it replaces for regular launches (kernel preference 5 pins the latter): the same tiles, K order
+and flush schedule, so every bit must agree — over channel counts (all compiled column groups), tap counts with odd and
+even chunk counts, nearest-filter mode with and without pass-through samples, small and multi-launch calls, streaming across
+calls (history seam) and flushes."""
+import numpy as np
+import pytest
+
+import audio_resampler_amd as A
+from _hip import HipResampler, tolerance_ok
+from _oracle import OracleResampler, noise, BH, INTERP, LOWPASS, PRECISE
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # (channels, taps, filters, src, dst, fixed, flags, blocks)
+    (8, 988, 988, 44100, 48000, False, BH | INTERP, (70000, 50000, 131072)),          # headline shape (32 chunks)
+    (4, 988, 988, 44100, 48000, False, BH | INTERP, (90000, 90000)),                  # config D's per-GPU shard
+    (2, 380, 380, 44100, 48000, False, BH | INTERP, (200000, 100001)),                # config B: 13 chunks (odd: buffer parity flips per tile)
+    (1, 380, 380, 44100, 48000, False, BH | INTERP, (300000,)),                       # mono: 64 periods per tile, half the columns idle
+    (16, 156, 156, 44100, 48000, False, BH | INTERP, (60000, 60000)),
+    (32, 988, 988, 44100, 48000, False, BH | INTERP, (30000, 30000)),                 # config D on one GPU
+    (2, 380, 380, 44100, 48000, True, BH | INTERP | LOWPASS, (150000, 150000)),       # ART form: 160 x 380 nearest filter, SNAP, low-pass
+    (8, 988, 988, 96000, 44100, True, BH | INTERP | LOWPASS, (140000, 140000)),       # config C's resampler: 147 x 988 nearest filter
+    (2, 380, 320, 44100, 48000, False, BH, (120000, 120000)),                         # nearest filter, no low-pass: pass-through samples (F = 2P)
+    (2, 64, 160, 48000, 44100, False, BH, (250000,)),                                 # short filter, 3 chunks, P = 147
+    (8, 988, 988, 44100, 48000, False, BH | INTERP, (2000, 3000, 500, 9000)),         # small calls: fewer tiles than workgroups
+]
+
+
+def _play(r, x, blocks, ratio, fixed):
+    outs, pos = [], 0
+    for n in blocks:
+        cap = int(n * ratio) + 4000
+        u, g, y = r.process(x[pos:pos + n], cap, 0.0 if fixed else ratio)
+        assert u == n
+        assert r.last_kernel() == 2, "the matrix-core path must be the one under test"
+        outs.append(y.copy())
+        pos += n
+    u, g, y = r.process(None, 8000, ratio, flush=True)
+    outs.append(y.copy())
+    return np.concatenate(outs)
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"c{c[0]}_t{c[1]}_f{c[2]}_{c[3]}to{c[4]}{'_fixed' if c[5] else ''}_{len(c[7])}calls")
+def test_streaming_kernel_equals_tile_kernel_bit_for_bit(case):
+    ch, T, F, src, dst, fixed, flags, blocks = case
+    ratio = dst / src
+    total = sum(blocks)
+    x, _ = noise(total * ch, state=0xFACADE5EED | 1)
+    x = x.reshape(total, ch)
+
+    def make(kernel):
+        r = HipResampler(ch, T, F, flags=flags, fixed=(float(src), float(dst), 0), kernel=kernel) if fixed else HipResampler(ch, T, F, 0.0, flags, kernel=kernel)
+        r.advance(T / 2)
+        return r
+
+    y_stream = _play(make(2), x, blocks, ratio, fixed)
+    y_tile = _play(make(5), x, blocks, ratio, fixed)
+    assert y_stream.shape == y_tile.shape
+    assert np.array_equal(y_stream.view(np.uint32), y_tile.view(np.uint32))
+
+
+def test_streaming_kernel_long_call_with_many_ring_epochs_matches_oracle():
+    """one call of 2.2 M frames x 2 channels: > 128 ring epochs (several launches, n_begin > 0) — against the
+    double-accumulate oracle and the tile kernel"""
+    ch, T, frames = 2, 988, 2200000
+    ratio = 48000 / 44100
+    x, _ = noise(frames * ch)
+    x = x.reshape(frames, ch)
+    outs = []
+    for kernel in (2, 5):
+        r = HipResampler(ch, T, T, 0.0, BH | INTERP, kernel=kernel)
+        r.advance(T / 2)
+        u, g, y = r.process(x, int(frames * ratio) + 4000, ratio)
+        assert u == frames and r.last_kernel() == 2
+        outs.append(y)
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    o = OracleResampler(ch, T, T, 0.0, BH | INTERP | PRECISE)
+    o.advance(T / 2)
+    uo, go, yo = o.process(x[:400000], int(400000 * ratio) + 4000, ratio, threads=2)
+    ok, worst, rms = tolerance_ok(outs[0][:go], yo)
+    assert ok and rms < 2.0e-8, (worst, rms)
