@@ -18,7 +18,7 @@ typedef artsample_t art_s;   /* the sample type of this build */
 extern "C" {
 #endif
 
-#define ART_MAX_SEGS 128         /* ring-epoch segments per kernel launch (passed by value) */
+#define ART_MAX_SEGS 192         /* ring-epoch segments per kernel launch (passed by value: 16 B each, kernel arguments stay below 4 KB) */
 
 /* numeric modes of the FIR */
 enum { ART_MODE_FAST = 0,        /* f32 FMA accumulation, any order (default) */

@@ -418,7 +418,6 @@ constexpr int MF_MAX_PPW = 64;            // periods per workgroup (C = 2)
 // half a float ulp).  The reference's own position arithmetic is quantised to ~1e-7 steps after 1M frames.
 constexpr double MF_PHASE_TOL = 2e-6;
 constexpr int MF_HEAD_PAD = 64;
-constexpr int MF_PAIR_TAPS = 32, MF_QUAD_TAPS = 160;     // distance from the central band beyond which 2 / 4 chunks share a flush
 
 struct MfmaGeom {
     int P, Q;                             // outputs / inputs per period
@@ -437,7 +436,10 @@ struct MfmaGeom {
     // the head of the call as ONE contiguous array (history ++ first input frames, MF_HEAD_PAD zero frames in front): tiles that
     // reach into the history stage from it exactly as all others stage from `in` (written by mfma_prepare_kernel)
     float *head; int head_frames;
-    int *tile_w0;                         // [slot_tiles] linear index of K column 0 of each slot tile in period 0 of the launch (streaming kernel)
+    // per slot tile, 3 ints: [0] linear index of K column 0 in period 0 of the launch; [1] the tile's pass-through row (nearest-
+    // filter mode without a low-pass: the one slot per period whose position falls exactly on an input sample), -1 if none;
+    // [2] that sample's linear index in period 0 (streaming kernel)
+    int *tile_w0;
 };
 
 typedef unsigned int u32x4 __attribute__ ((ext_vector_type (4)));
@@ -476,7 +478,19 @@ void mfma_prepare_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
     if (tid == 0) {
         g.canon_ip [st * R + row] = p.ip; g.canon_fi [st * R + row] = p.fi; g.canon_frac [st * R + row] = p.frac;
         if (st == 0 && row == 0) a.fix_count [0] = 0;       // per-launch count of off-pattern outputs (the main kernel follows in-stream)
-        if (row == 0 && g.tile_w0) g.tile_w0 [st] = p0.ip - a.T / 2 + 1;
+        if (row == 0 && g.tile_w0) g.tile_w0 [3 * st] = p0.ip - a.T / 2 + 1;
+    }
+    if (row == 0 && g.tile_w0) {
+        // (positions i Q / P + const are whole numbers for exactly one slot per period, and a tile never spans two periods)
+        __shared__ int s_pass [2];
+        if (tid == 0) { s_pass [0] = -1; s_pass [1] = 0; }
+        __syncthreads ();
+        if (!INTERP && !a.lowpass && tid < rows_valid) {
+            const Pos q = locate<INTERP> (a, segs, a.n_begin + st * R + tid);
+            if ((q.fi % a.F) == 0) { s_pass [0] = tid; s_pass [1] = q.ip + q.fi / a.F; }
+        }
+        __syncthreads ();
+        if (tid == 0) { g.tile_w0 [3 * st + 1] = s_pass [0]; g.tile_w0 [3 * st + 2] = s_pass [1]; }
     }
     const float *h0 = a.bank + (size_t) p.fi * a.T;
     const int shift = p.ip - p0.ip;
@@ -506,6 +520,104 @@ void mfma_prepare_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
             g.head [e] = v;
         }
     }
+}
+
+// The K walk of one 32-slot x 128-column tile, shared by both matrix-core kernels (sum += A[32 x K] * X[K x cols], per wave its 32
+// columns), chunk by chunk in K order as the staging waves deliver them; one workgroup barrier per chunk.
+// Where the f32 accumulator is flushed into the fp64 sums decides the accuracy — and every flush is 32 vector instructions
+// beside the matrix pipe.  Measured on the CPU model of this chain (tools/sim/flush_schemes.py: noise, full-scale sines, square
+// waves, DC through all five slot tiles, against the fp64 dot product and the reference's own float loop): what matters is
+// that no f32 partial sum carries a row's CENTRAL taps for long — the band (the chunks holding any row's central taps) is
+// flushed every 4 k, the chunk on either side of it on its own — while everything left of that can share ONE accumulator
+// and everything right of it one per four chunks with no measurable change (rms 0.98 x the reference float loop's either
+// way; flushing the band every 8 k instead: 1.23 x and out of tolerance).
+// PAR: parity of the tile's first chunk in the workgroup's chunk stream (which LDS buffer holds chunk 0).
+// (Tried, same box, same run: a frame-major X tile in LDS — the staging waves then write whole dwordx4 loads, 5 LDS writes per
+// chunk and thread instead of 9, the matrix waves pick their k's with ds_read2_b32 — 0.1547 vs 0.1541 ms: the staging waves' LDS
+// writes are not what the matrix waves wait for.  Raised wave priority for either role: no change.)
+template <int PAR>
+__device__ __forceinline__ void mf_k_walk (const float (*As_) [32 * MF_LD], const float (*Bs_) [MF_COLS * MF_LD], int arow, int brow,
+                                           int nchunks, int band_lo, int band_hi, double (&sum) [16])
+{
+    auto b_of = [&] (const float *Bs, int grp) -> f32x4 { return *reinterpret_cast<const f32x4 *> (&Bs [brow + grp * 8]); };
+    const int lo_band = band_lo / MF_KC, hi_band = (band_hi + MF_KC - 1) / MF_KC;       // band chunks [lo_band, hi_band)
+    const int left_end = lo_band > 1 ? lo_band - 1 : 0;                                 // [0, left_end): one accumulator
+    const int right_from = hi_band + 1 < nchunks ? hi_band + 1 : nchunks;               // [right_from, nchunks): one per four chunks
+
+    auto chunk_into = [&] (auto buf_tag, f32x16 &acc) {          // 16 MFMAs of the chunk in LDS buffer BUF ^ PAR, onto acc
+        constexpr int BUF = decltype (buf_tag)::value ^ PAR;
+        const float *As = As_ [BUF], *Bs = Bs_ [BUF];
+#pragma unroll
+        for (int grp = 0; grp < MF_KC / 8; ++grp) {
+            const f32x4 bv = b_of (Bs, grp);
+            const f32x4 av = *reinterpret_cast<const f32x4 *> (&As [arow + grp * 8]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [q], bv [q], acc, 0, 0, 0);
+            if (grp == 1) __builtin_amdgcn_sched_barrier (0);       // operands of two groups at a time (registers)
+        }
+    };
+    auto flush = [&] (f32x16 &acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sum [r] = sum [r] + (double) acc [r]; acc [r] = 0.0f; }
+    };
+    // chunks [from, to) onto one accumulator, flushed every `every` chunks (0: once at the end)
+    auto run = [&] (int from, int to, int every) {
+        if (from >= to) return;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc [r] = 0.0f;
+        int chunk = from, held = 0;
+        auto after = [&] () { if (every && ++held == every) { flush (acc); held = 0; } __syncthreads (); };
+        if (chunk & 1) { chunk_into (std::integral_constant<int, 1> {}, acc); after (); ++chunk; }
+        for (; chunk + 2 <= to; chunk += 2) {
+            chunk_into (std::integral_constant<int, 0> {}, acc); after ();
+            chunk_into (std::integral_constant<int, 1> {}, acc); after ();
+        }
+        if (chunk < to) { chunk_into (std::integral_constant<int, 0> {}, acc); after (); }
+        if (!every || held) flush (acc);
+    };
+    // chunks [from, to) of the band and its two neighbours: band chunks flushed every 4 k, the others once
+    auto centre = [&] (int from, int to) {
+        for (int chunk = from; chunk < to; ++chunk) {
+            const float *As = As_ [((chunk & 1) ^ PAR)], *Bs = Bs_ [((chunk & 1) ^ PAR)];
+            const int k0 = chunk * MF_KC;
+            if (k0 < band_hi && k0 + MF_KC > band_lo) {
+#pragma unroll
+                for (int grp = 0; grp < MF_KC / 8; ++grp) {
+                    const f32x4 bv = b_of (Bs, grp);
+                    const f32x4 av = *reinterpret_cast<const f32x4 *> (&As [arow + grp * 8]);
+#pragma unroll
+                    for (int q = 0; q < 4; q += 2) {
+                        f32x16 acc;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc [r] = 0.0f;
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [q], bv [q], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [q + 1], bv [q + 1], acc, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sum [r] = sum [r] + (double) acc [r];
+                    }
+                }
+            }
+            else {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc [r] = 0.0f;
+#pragma unroll
+                for (int grp = 0; grp < MF_KC / 8; ++grp) {
+                    const f32x4 bv = b_of (Bs, grp);
+                    const f32x4 av = *reinterpret_cast<const f32x4 *> (&As [arow + grp * 8]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [q], bv [q], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum [r] = sum [r] + (double) acc [r];
+            }
+            __syncthreads ();
+        }
+    };
+    run (0, left_end, 0);
+    centre (left_end, right_from);
+    run (right_from, nchunks, 4);
 }
 
 // CG > 0: the stream has exactly CG channels (compile-time index math, vector loads);  CG == 0: any count.
@@ -832,74 +944,7 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
             }
         }
         __syncthreads ();
-        if (MT == 1) {
-            // Every fp64 flush is vector-unit work that takes issue slots from the matrix pipe, and far from the central
-            // band the partial sums are tiny: there FOUR chunks (beyond MF_QUAD_TAPS from the band) or TWO (beyond
-            // MF_PAIR_TAPS) share one f32 accumulator before it is flushed; near the band one chunk per flush, inside it
-            // a flush every 4 k.  The K range is walked by plain loops with ONE shape of body each — the compiler
-            // allocates registers per loop, and any mixed-shape loop went over the 80 registers (§7).  Error probe
-            // (tools/err_probe.py: full-scale DC, square, sines, noise): worst case and rms unchanged.
-            const int lo_band = g.band_lo / MF_KC, hi_band = (g.band_hi + MF_KC - 1) / MF_KC;      // band chunks [lo_band, hi_band)
-            int near_lo = lo_band - MF_PAIR_TAPS / MF_KC, near_hi = hi_band + MF_PAIR_TAPS / MF_KC;         // single-flush chunks around it
-            if (near_lo < 0) near_lo = 0;
-            if (near_hi > nchunks) near_hi = nchunks;
-            near_lo &= ~1;                                                                        // pairs start on even chunks
-            auto mfma16 = [&] (auto fresh_tag, f32x16 &acc, int buf) {
-                const float *As = As_ [buf], *Bs = Bs_ [buf];
-#pragma unroll
-                for (int grp = 0; grp < MF_KC / 8; ++grp) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4 *> (&Bs [brow + grp * 8]);
-                    const f32x4 av = *reinterpret_cast<const f32x4 *> (&As [arow + grp * 8]);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        if (decltype (fresh_tag)::value && grp == 0 && q == 0) {
-                            f32x16 z;
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) z [r] = 0.0f;
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [q], bv [q], z, 0, 0, 0);
-                        }
-                        else acc = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [q], bv [q], acc, 0, 0, 0);
-                    }
-                    if (grp == 1) __builtin_amdgcn_sched_barrier (0);       // operands of two groups at a time (registers)
-                }
-            };
-            auto runs = [&] (auto n_tag, int from, int to) {        // [from, to): a multiple of N chunks, from even; N chunks per flush
-                constexpr int N = decltype (n_tag)::value;
-                for (int chunk = from; chunk < to; chunk += N) {
-                    f32x16 acc;
-                    mfma16 (std::true_type {}, acc, 0);
-#pragma unroll
-                    for (int q = 1; q < N; ++q) {
-                        __syncthreads ();
-                        mfma16 (std::false_type {}, acc, q & 1);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sum [0] [r] = sum [0] [r] + (double) acc [r];
-                    __syncthreads ();
-                }
-            };
-            auto singles = [&] (int from, int to) {
-                for (int chunk = from; chunk < to; ++chunk) { matrix_chunk (chunk, chunk & 1); __syncthreads (); }
-            };
-            const std::integral_constant<int, 2> two; const std::integral_constant<int, 4> four;
-            // left of the band: quads while at least MF_QUAD_TAPS taps away, then pairs, then singles into and through the band
-            int quad_lo = (lo_band - MF_QUAD_TAPS / MF_KC) & ~3;  if (quad_lo < 0) quad_lo = 0;  if (quad_lo > near_lo) quad_lo = near_lo & ~3;
-            runs (four, 0, quad_lo);
-            runs (two, quad_lo, quad_lo + ((near_lo - quad_lo) & ~1));
-            const int tail_from = near_hi + (near_hi & 1);
-            singles (quad_lo + ((near_lo - quad_lo) & ~1), tail_from < nchunks ? tail_from : nchunks);
-            if (tail_from < nchunks) {
-                // right of it: pairs up to MF_QUAD_TAPS taps away, quads beyond, whatever is left one by one
-                int quad_from = hi_band + MF_QUAD_TAPS / MF_KC;  quad_from += quad_from & 1;  if (quad_from < tail_from) quad_from = tail_from;
-                if (quad_from > nchunks) quad_from = tail_from + ((nchunks - tail_from) & ~1);
-                runs (two, tail_from, quad_from);
-                const int quad_to = quad_from + ((nchunks - quad_from) & ~3);
-                runs (four, quad_from, quad_to);
-                const int pair_to = quad_to + ((nchunks - quad_to) & ~1);
-                runs (two, quad_to, pair_to);
-                singles (pair_to, nchunks);
-            }
-        }
+        if constexpr (MT == 1 && WS) mf_k_walk<0> (As_, Bs_, arow, brow, nchunks, g.band_lo, g.band_hi, sum [0]);
         else
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             matrix_chunk (chunk, chunk & 1);
@@ -963,7 +1008,9 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
 // round to another filter.  Launches that fail the test (calls beyond a few million frames, drifting ratios do not get here
 // at all) run fir_mfma_kernel.  Same tiles, same K order, same flush schedule: the two kernels produce identical bits.
 // ---------------------------------------------------------------------------------------------------
-template <bool INTERP, int CG>
+// PASS: nearest-filter mode without a low-pass — outputs that fall exactly on an input sample are copied through (its own
+// instantiation: the extra loads of that epilogue cost the common ones a spilled register otherwise).
+template <bool INTERP, int CG, bool PASS>
 __global__ __launch_bounds__ (2 * MF_THREADS) __attribute__ ((amdgpu_waves_per_eu (6)))
 void fir_mfma_stream_kernel (ArtFirArgs a, MfmaGeom g, int wgs_per_xcd)
 {
@@ -1034,7 +1081,7 @@ void fir_mfma_stream_kernel (ArtFirArgs a, MfmaGeom g, int wgs_per_xcd)
             int st, jg;
             f_live = tile_at (f_within, st, jg);
             if (!f_live) return;
-            const int w0 = g.tile_w0 [st] + jg * PPW * g.Q;
+            const int w0 = g.tile_w0 [3 * st] + jg * PPW * g.Q;
             const bool touches_hist = w0 < a.H;              // (first period group of a call: staged from the gathered head)
             const int origin = touches_hist ? -MF_HEAD_PAD : a.H;
             const char *base = touches_hist ? reinterpret_cast<const char *> (g.head) : reinterpret_cast<const char *> (a.in);
@@ -1091,116 +1138,15 @@ void fir_mfma_stream_kernel (ArtFirArgs a, MfmaGeom g, int wgs_per_xcd)
     if (my_tiles == 0) return;
 
     const int arow = (lane & 31) * MF_LD + 4 * (lane >> 5);
-    const int brow = (wave * 32 + (lane & 31)) * MF_LD + 4 * (lane >> 5);
     const int col = wave * 32 + (lane & 31);
     const bool col_live = col < NCOLS;
     const int jl = col / CG, c = col - jl * CG;
+    const int brow = col * MF_LD + 4 * (lane >> 5);
     // output offset of this lane inside a tile: (period jl, slot 4 * (lane >> 5), channel c); the row's own 0..3 / +8 / +16 / +24
     // slots are immediates of the store
     const unsigned int out_off = (unsigned int)((jl * g.P + 4 * (lane >> 5)) * CG + c) * 4u;
 
-    const int lo_band = g.band_lo / MF_KC, hi_band = (g.band_hi + MF_KC - 1) / MF_KC;
-    int near_lo = lo_band - MF_PAIR_TAPS / MF_KC, near_hi = hi_band + MF_PAIR_TAPS / MF_KC;
-    if (near_lo < 0) near_lo = 0;
-    if (near_hi > nchunks) near_hi = nchunks;
-    near_lo &= ~1;
-
     double sum [16];
-
-    // one tile's K loop.  PAR: parity of the tile's first chunk in the workgroup's chunk stream (= its LDS buffer).
-    auto tile_k_loop = [&] (auto par_tag) {
-        constexpr int PAR = decltype (par_tag)::value;
-        auto mfma16 = [&] (auto fresh_tag, f32x16 &acc, int buf) {
-            const float *As = As_ [buf ^ PAR], *Bs = Bs_ [buf ^ PAR];
-#pragma unroll
-            for (int grp = 0; grp < MF_KC / 8; ++grp) {
-                const f32x4 bv = *reinterpret_cast<const f32x4 *> (&Bs [brow + grp * 8]);
-                const f32x4 av = *reinterpret_cast<const f32x4 *> (&As [arow + grp * 8]);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (decltype (fresh_tag)::value && grp == 0 && q == 0) {
-                        f32x16 z;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) z [r] = 0.0f;
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [q], bv [q], z, 0, 0, 0);
-                    }
-                    else acc = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [q], bv [q], acc, 0, 0, 0);
-                }
-                if (grp == 1) __builtin_amdgcn_sched_barrier (0);       // operands of two groups at a time (registers)
-            }
-        };
-        auto runs = [&] (auto n_tag, int from, int to) {        // [from, to): a multiple of N chunks, from even; N chunks per flush
-            constexpr int N = decltype (n_tag)::value;
-            for (int chunk = from; chunk < to; chunk += N) {
-                f32x16 acc;
-                mfma16 (std::true_type {}, acc, 0);
-#pragma unroll
-                for (int q = 1; q < N; ++q) {
-                    __syncthreads ();
-                    mfma16 (std::false_type {}, acc, q & 1);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sum [r] = sum [r] + (double) acc [r];
-                __syncthreads ();
-            }
-        };
-        auto singles = [&] (int from, int to) {
-            for (int chunk = from; chunk < to; ++chunk) {
-                const float *As = As_ [(chunk & 1) ^ PAR], *Bs = Bs_ [(chunk & 1) ^ PAR];
-                const int k0 = chunk * MF_KC;
-                const bool band = k0 < g.band_hi && k0 + MF_KC > g.band_lo;
-                if (!band) {
-                    f32x16 acc;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc [r] = 0.0f;
-#pragma unroll
-                    for (int grp = 0; grp < MF_KC / 8; ++grp) {
-                        const f32x4 bv = *reinterpret_cast<const f32x4 *> (&Bs [brow + grp * 8]);
-                        const f32x4 av = *reinterpret_cast<const f32x4 *> (&As [arow + grp * 8]);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [q], bv [q], acc, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sum [r] = sum [r] + (double) acc [r];
-                }
-                else {
-#pragma unroll
-                    for (int grp = 0; grp < MF_KC / 8; ++grp) {
-                        const f32x4 bv = *reinterpret_cast<const f32x4 *> (&Bs [brow + grp * 8]);
-                        const f32x4 av = *reinterpret_cast<const f32x4 *> (&As [arow + grp * 8]);
-#pragma unroll
-                        for (int q = 0; q < 4; q += 2) {
-                            f32x16 acc;
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) acc [r] = 0.0f;
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [q], bv [q], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32 (av [q + 1], bv [q + 1], acc, 0, 0, 0);
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) sum [r] = sum [r] + (double) acc [r];
-                        }
-                    }
-                }
-                __syncthreads ();
-            }
-        };
-        const std::integral_constant<int, 2> two; const std::integral_constant<int, 4> four;
-        // the same walk as fir_mfma_kernel: quads far left of the band, pairs, singles through the band, pairs, quads, leftovers
-        int quad_lo = (lo_band - MF_QUAD_TAPS / MF_KC) & ~3;  if (quad_lo < 0) quad_lo = 0;  if (quad_lo > near_lo) quad_lo = near_lo & ~3;
-        runs (four, 0, quad_lo);
-        runs (two, quad_lo, quad_lo + ((near_lo - quad_lo) & ~1));
-        const int tail_from = near_hi + (near_hi & 1);
-        singles (quad_lo + ((near_lo - quad_lo) & ~1), tail_from < nchunks ? tail_from : nchunks);
-        if (tail_from < nchunks) {
-            int quad_from = hi_band + MF_QUAD_TAPS / MF_KC;  quad_from += quad_from & 1;  if (quad_from < tail_from) quad_from = tail_from;
-            if (quad_from > nchunks) quad_from = tail_from + ((nchunks - tail_from) & ~1);
-            runs (two, tail_from, quad_from);
-            const int quad_to = quad_from + ((nchunks - quad_from) & ~3);
-            runs (four, quad_from, quad_to);
-            const int pair_to = quad_to + ((nchunks - quad_to) & ~1);
-            runs (two, quad_to, pair_to);
-            singles (pair_to, nchunks);
-        }
-    };
 
     __syncthreads ();                                        // the staging waves have committed chunk 0
     int parity = 0;
@@ -1210,8 +1156,8 @@ void fir_mfma_stream_kernel (ArtFirArgs a, MfmaGeom g, int wgs_per_xcd)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sum [r] = 0.0;
 
-        if (parity) tile_k_loop (std::integral_constant<int, 1> {});
-        else tile_k_loop (std::integral_constant<int, 0> {});
+        if (parity) mf_k_walk<1> (As_, Bs_, arow, brow, nchunks, g.band_lo, g.band_hi, sum);
+        else mf_k_walk<0> (As_, Bs_, arow, brow, nchunks, g.band_lo, g.band_hi, sum);
         parity ^= nchunks & 1;
 
         // ---- the tile's outputs: C/D layout of 32x32: row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31
@@ -1219,17 +1165,15 @@ void fir_mfma_stream_kernel (ArtFirArgs a, MfmaGeom g, int wgs_per_xcd)
         const int rows_valid = min (32, g.P - st * 32);
         const size_t left = (size_t)(a.n_end - n_tile) * CG * 4;
         const __amdgpu_buffer_rsrc_t rs_out = make_rsrc (a.out + (size_t) n_tile * CG, left > 0xffffff00ull ? 0xffffff00u : (unsigned int) left);
-        const bool pass_through_possible = !INTERP && !a.lowpass;
+        const int pass_row = PASS ? g.tile_w0 [3 * st + 1] : -1, pass_lin = PASS ? g.tile_w0 [3 * st + 2] : 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i_const = (r & 3) + 8 * (r >> 2);      // compile-time part of the slot
             float y = (float) sum [r];
             const int i = i_const + 4 * (lane >> 5);
-            if (pass_through_possible) {
+            if constexpr (PASS) {
                 // nearest-filter mode, the position falls exactly on an input sample: the reference copies it (resampler.c:1166-1170)
-                const int fi = g.canon_fi [st * 32 + min (i, rows_valid - 1)];
-                if ((fi % a.F) == 0)
-                    y = load_frame (a, INT_MIN, g.canon_ip [st * 32 + min (i, rows_valid - 1)] + (jg * PPW + jl) * g.Q + fi / a.F, c);
+                if (pass_row == i) y = load_frame (a, INT_MIN, pass_lin + (jg * PPW + jl) * g.Q, c);
             }
             if (col_live && i < rows_valid)                  // (frames at or past n_end: out of the resource's range, dropped)
                 __builtin_amdgcn_raw_buffer_store_b32 (__float_as_uint (y), rs_out, (int)(out_off + (unsigned int)(i_const * CG) * 4u), 0, 0);
@@ -1813,12 +1757,12 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
             g.canon_ip = (int *)(g.canon_frac + rows);
             g.canon_fi = g.canon_ip + rows;
             g.tile_w0 = g.canon_fi + rows;
-            if (!base || (size_t)((char *)(g.tile_w0 + g.slot_tiles) - base) > a->scratch_bytes) goto general_path;
+            if (!base || (size_t)((char *)(g.tile_w0 + 3 * g.slot_tiles) - base) > a->scratch_bytes) goto general_path;
             g.head = nullptr; g.head_frames = 0;
             if (ws && !wide) {
                 // the call's head as one contiguous array: everything a tile whose window starts inside the history can read
                 // (+ the two chunks the staging runs ahead)
-                const size_t used = (((size_t)((char *)(g.tile_w0 + g.slot_tiles) - base)) + 255) & ~(size_t) 255;
+                const size_t used = (((size_t)((char *)(g.tile_w0 + 3 * g.slot_tiles) - base)) + 255) & ~(size_t) 255;
                 g.head_frames = MF_HEAD_PAD + a->H + (g.ppw - 1) * g.Q + g.ktot + 3 * MF_KC;
                 if (used + (size_t) g.head_frames * a->C * sizeof (float) > a->scratch_bytes) goto general_path;
                 g.head = (float *)(base + used);
@@ -1838,15 +1782,22 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
         if (ws && !wide && kernel_pref != 5 && (size_t) a->n_end * a->C * 4 < 0xffff0000ull && mfma_launch_is_regular (a, segs)) {
             const int tiles_per_xcd = g.groups_per_xcd * g.slot_tiles;
             const int resident = 96;                                        // 32 CUs per XCD x 3 workgroups (80 VGPRs, 46 KB of LDS)
-            const int rounds = (tiles_per_xcd + resident - 1) / resident;
+            // a static share per workgroup costs up to one tile time at the end: worth it from three rounds on, or when the
+            // second of two rounds is nearly full (measured: 4 channels x 1M frames = 139 tiles per XCD, one tile per
+            // workgroup 0.095 ms, two 0.110; 8 channels = 280 tiles, three per workgroup 0.167, one 0.171)
+            int rounds = (tiles_per_xcd + resident - 1) / resident;
+            if (rounds == 2 && tiles_per_xcd < 170) rounds = 1;
+            { static const int k_env = [] { const char *e = getenv ("ARTAMD_TILES_PER_WG"); return e && *e ? atoi (e) : 0; } (); if (k_env > 0) rounds = k_env; }
             const int wgs_per_xcd = (tiles_per_xcd + rounds - 1) / rounds;
             const dim3 sgrid ((unsigned int)(8 * wgs_per_xcd) + roll_blocks);
-#define MS_GO(I, CGT) hipLaunchKernelGGL ((fir_mfma_stream_kernel<I, CGT>), sgrid, dim3 (2 * MF_THREADS), 0, st, *a, g, wgs_per_xcd)
+#define MS_GO_(I, CGT, PS) hipLaunchKernelGGL ((fir_mfma_stream_kernel<I, CGT, PS>), sgrid, dim3 (2 * MF_THREADS), 0, st, *a, g, wgs_per_xcd)
+#define MS_GO(I, CGT) do { if (!I && !a->lowpass) MS_GO_ (false, CGT, true); else MS_GO_ (I, CGT, false); } while (0)
             if (a->interpolate) switch (cgt) { case 32: MS_GO (true, 32); break; case 16: MS_GO (true, 16); break; case 8: MS_GO (true, 8); break;
                                                 case 4: MS_GO (true, 4); break; case 2: MS_GO (true, 2); break; default: MS_GO (true, 1); }
             else                switch (cgt) { case 32: MS_GO (false, 32); break; case 16: MS_GO (false, 16); break; case 8: MS_GO (false, 8); break;
                                                 case 4: MS_GO (false, 4); break; case 2: MS_GO (false, 2); break; default: MS_GO (false, 1); }
 #undef MS_GO
+#undef MS_GO_
             if (a->ev_stop) arthip_event_record (a->ev_stop, stream);
             return hipGetLastError () == hipSuccess ? (ART_KERNEL_MFMA | (a->roll_dst ? ART_FIR_ROLLED : 0)) : -1;
         }
