@@ -6,6 +6,19 @@
 
 static thread_local char g_err[256] = "no error";
 
+// Small transfers between page-locked host memory and HBM as a KERNEL (the GPU reads / writes the host pages over PCIe
+// itself): for the few hundred kilobytes of an ART-sized block the copy engines' fixed cost per command (~10 us each way on
+// this stack) is most of a call, a launch in the same stream costs 2-4 us.
+__global__ void copy_words_kernel (uint4 *dst, const uint4 *src, size_t quads, unsigned int *dst_tail, const unsigned int *src_tail, int tail_words,
+                                   unsigned int *dst2, const unsigned int *src2, int words2)
+{
+    const size_t stride = (size_t) gridDim.x * blockDim.x;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += stride) dst [i] = src [i];
+    if (blockIdx.x == 0 && (int) threadIdx.x < tail_words) dst_tail [threadIdx.x] = src_tail [threadIdx.x];
+    if (blockIdx.x == gridDim.x - 1)                      // a second, short range (a filter's state beside its samples)
+        for (int i = threadIdx.x; i < words2; i += blockDim.x) dst2 [i] = src2 [i];
+}
+
 static int fail (hipError_t e, const char *what)
 {
     if (e == hipSuccess) return 0;
@@ -45,6 +58,24 @@ int arthip_d2h (void *d, const void *s, size_t n, void *st) { return n ? fail (h
 int arthip_d2d (void *d, const void *s, size_t n, void *st) { return n ? fail (hipMemcpyAsync (d, s, n, hipMemcpyDeviceToDevice, (hipStream_t) st), "D2D") : 0; }
 int arthip_zero (void *d, size_t n, void *st) { return n ? fail (hipMemsetAsync (d, 0, n, (hipStream_t) st), "memset") : 0; }
 int arthip_sync (void *st) { return fail (hipStreamSynchronize ((hipStream_t) st), "sync"); }
+
+// dst / src: one of them page-locked host memory (hipHostMalloc: mapped, same address on the device), both 16-byte aligned,
+// bytes a multiple of 4
+int arthip_copy_by_kernel (void *dst, const void *src, size_t bytes, void *st) { return arthip_copy2_by_kernel (dst, src, bytes, nullptr, nullptr, 0, st); }
+
+// ... plus a second short range (dst2 / src2: 4-byte aligned, bytes2 a multiple of 4) in the same launch
+int arthip_copy2_by_kernel (void *dst, const void *src, size_t bytes, void *dst2, const void *src2, size_t bytes2, void *st)
+{
+    if (!bytes && !bytes2) return 0;
+    const size_t quads = bytes / 16; const int tail = (int)((bytes % 16) / 4);
+    unsigned int blocks = (unsigned int)((quads + 255) / 256);
+    if (blocks > 512) blocks = 512;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL (copy_words_kernel, dim3 (blocks), dim3 (256), 0, (hipStream_t) st, (uint4 *) dst, (const uint4 *) src, quads,
+                        (unsigned int *) dst + quads * 4, (const unsigned int *) src + quads * 4, tail,
+                        (unsigned int *) dst2, (const unsigned int *) src2, (int)(bytes2 / 4));
+    return fail (hipGetLastError (), "copy kernel");
+}
 
 int arthip_set_device (int device) { return fail (hipSetDevice (device), "hipSetDevice"); }
 

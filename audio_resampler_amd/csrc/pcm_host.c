@@ -173,8 +173,15 @@ static void biquad_run_host (Biquad *f, art_s *buffer, int n, int stride, int sa
     if (stride == 1) memcpy (h, buffer, sizeof (art_s) * (size_t) n);
     else for (int i = 0; i < n; ++i) h [i] = buffer [(size_t) i * stride];
     *host_scratch.h_state = *f;
-    arthip_h2d (host_scratch.d_in, h, sizeof (art_s) * (size_t) n, NULL);
-    arthip_h2d (host_scratch.d_state, host_scratch.h_state, sizeof (Biquad), NULL);
+    /* samples and filter state travel in one launch each way (a copy kernel over the page-locked buffers; beyond a megabyte
+     * the copy engines) */
+    const int by_kernel = sizeof (art_s) * (size_t) n <= ((size_t) 1 << 20);
+    if (by_kernel)
+        arthip_copy2_by_kernel (host_scratch.d_in, h, sizeof (art_s) * (size_t) n, host_scratch.d_state, host_scratch.h_state, sizeof (Biquad), NULL);
+    else {
+        arthip_h2d (host_scratch.d_in, h, sizeof (art_s) * (size_t) n, NULL);
+        arthip_h2d (host_scratch.d_state, host_scratch.h_state, sizeof (Biquad), NULL);
+    }
 
     const int W = (sample_form || spec_disabled ()) ? 0 : forget_length (f);
     const int L = W ? spec_chunk (1, W) : 0;
@@ -198,8 +205,12 @@ static void biquad_run_host (Biquad *f, art_s *buffer, int n, int stride, int sa
 
     if (rc) fprintf (stderr, "artamd: biquad launch failed: %s\n", arthip_last_error ());
     else {
-        arthip_d2h (h, d_result, sizeof (art_s) * (size_t) n, NULL);
-        arthip_d2h (host_scratch.h_state, host_scratch.d_state, sizeof (Biquad), NULL);
+        if (by_kernel)
+            arthip_copy2_by_kernel (h, d_result, sizeof (art_s) * (size_t) n, host_scratch.h_state, host_scratch.d_state, sizeof (Biquad), NULL);
+        else {
+            arthip_d2h (h, d_result, sizeof (art_s) * (size_t) n, NULL);
+            arthip_d2h (host_scratch.h_state, host_scratch.d_state, sizeof (Biquad), NULL);
+        }
         if (!arthip_sync (NULL)) {
             if (stride == 1) memcpy (buffer, h, sizeof (art_s) * (size_t) n);
             else for (int i = 0; i < n; ++i) buffer [(size_t) i * stride] = h [i];      /* only this channel's samples are written */

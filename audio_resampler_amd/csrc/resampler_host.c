@@ -26,9 +26,13 @@
 
 #define HIST_FRAMES(T) ((T) + (T) / 2)      /* frames of history kept in HBM between calls */
 
-/* host-pointer calls up to this many bytes (in + out) go through page-locked staging buffers (one dense DMA each way, no
- * bounce through the runtime's own buffers); larger ones are copied straight from / to the caller's memory */
-#define STAGE_LIMIT ((size_t) 8 << 20)          /* (environment ARTAMD_STAGE_LIMIT=bytes overrides: tests force either path) */
+/* host-pointer calls up to this many bytes (in + out) go through page-locked staging buffers — the input by a copy kernel, the
+ * output written there by the FIR kernels themselves, no copy-engine command at all —; larger ones are copied straight
+ * from / to the caller's memory */
+#define KERNEL_COPY_LIMIT ((size_t) 1 << 20)     /* staged transfers up to this size are made by a copy kernel, not a copy-engine command */
+#define STAGE_LIMIT ((size_t) 3 << 19)          /* 1.5 MB: measured on MI355X hosts, 8 ch x 988 taps: 16,384-frame calls 107 -> 92 us staged, 65,536-frame
+                                                 * calls 176 us direct vs 235-378 staged (the CPU's own copies into and out of the staging cost more than
+                                                 * the runtime's pipelined pageable path saves).  Environment ARTAMD_STAGE_LIMIT=bytes overrides (tests) */
 
 struct BankEntry;
 struct artamd_resampler {
@@ -1462,7 +1466,8 @@ static void host_begin (Resample *cxt, const art_s *input, int in_stride, const 
             for (unsigned int f = 0; f < peek.input_used; ++f)
                 memcpy (dst + (size_t) f * C, input + (size_t) f * in_stride, sizeof (art_s) * C);
         TRACE_MARK (1);
-        arthip_h2d (hip->d_in, hip->h_in, sizeof (art_s) * in_samples, hip->stream);
+        if (sizeof (art_s) * in_samples <= KERNEL_COPY_LIMIT) arthip_copy_by_kernel (hip->d_in, hip->h_in, sizeof (art_s) * in_samples, hip->stream);
+        else arthip_h2d (hip->d_in, hip->h_in, sizeof (art_s) * in_samples, hip->stream);
     }
     else if (in_samples) {
         if (planes) {
@@ -1477,14 +1482,17 @@ static void host_begin (Resample *cxt, const art_s *input, int in_stride, const 
     }
 
     TRACE_MARK (2);
-    pend->res = enqueue_call (cxt, hip->d_in, 0, nIn, hip->d_out, 0, cap, ratio);
+    /* small staged calls: the FIR kernels write their output straight into the page-locked buffer (it is mapped into the
+     * device's address space; one launch and its dependency gap less than copying it out afterwards) */
+    const int direct_out = staged && sizeof (art_s) * out_samples <= KERNEL_COPY_LIMIT;
+    pend->res = enqueue_call (cxt, hip->d_in, 0, nIn, direct_out ? hip->h_out : hip->d_out, 0, cap, ratio);
     pend->failed = 0;
     TRACE_MARK (3);
 
     const unsigned int made = pend->res.output_generated;
     if (!made) return;
     if (staged) {
-        arthip_d2h (hip->h_out, hip->d_out, sizeof (art_s) * (size_t) made * C, hip->stream);
+        if (!direct_out) arthip_d2h (hip->h_out, hip->d_out, sizeof (art_s) * (size_t) made * C, hip->stream);
         pend->staged_out = 1;
     }
     else if (out_planes) {

@@ -1869,7 +1869,19 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
 general_path:
 #endif
     if (a->ev_start) arthip_event_record (a->ev_start, stream);
-    if (run_general (*a, *segs, st)) return -1;
+    if (run_general (*a, *segs, st)) {
+        // The tile's input span does not fit the LDS (ratios below ~1/4000 with long filters: thousands of input frames per
+        // output).  The reference accepts any positive ratio, and a caller that loops until its input is consumed must not
+        // see "nothing done": one lane per output sample reading HBM directly (the strict-order kernel: reference source
+        // order, float or double accumulator as the mode asks) — slow, correct, and only ever reached by such ratios.
+        const size_t total = (size_t)(a->n_end - a->n_begin) * a->C;
+        const dim3 grid ((unsigned int)((total + 255) / 256));
+        const int precise = (a->mode & 3) == ART_MODE_PRECISE;
+        if (a->interpolate) hipLaunchKernelGGL (fir_strict_kernel<true>, grid, dim3 (256), 0, st, *a, *segs, precise);
+        else hipLaunchKernelGGL (fir_strict_kernel<false>, grid, dim3 (256), 0, st, *a, *segs, precise);
+        if (a->ev_stop) arthip_event_record (a->ev_stop, stream);
+        return hipGetLastError () == hipSuccess ? ART_KERNEL_GENERAL : -1;        // (no history roll rode along: the host launches it)
+    }
     if (a->ev_stop) arthip_event_record (a->ev_stop, stream);
     return hipGetLastError () == hipSuccess ? (ART_KERNEL_GENERAL | (a->roll_dst ? ART_FIR_ROLLED : 0)) : -1;
 }

@@ -371,3 +371,28 @@ def test_biquad_bank_pipeline_geometries_bit_exact(ch, nsec):
             a, b = state[k * nsec + s], osecs[k][s]
             hist = lambda q, arr: [arr[(q.index - i) & 3] for i in range(4)]
             assert hist(a, a.x) == hist(b, b.x) and hist(a, a.y) == hist(b, b.y), (k, s)
+
+
+def test_extreme_downsampling_ratio_whose_span_does_not_fit_the_lds():
+    """ratio 1/7000 with 988 taps x 8 channels: one output's window and the next are 7000 frames apart — more than a
+    workgroup's LDS holds.  The reference accepts any positive ratio; the library must still consume the input and produce the
+    outputs (a caller looping on input_used must not spin): evaluated by the direct, one-lane-per-sample kernel."""
+    ch, T = 8, 988
+    ratio = 1.0 / 7000.0
+    x, _ = noise(ch * 40000)
+    x = x.reshape(-1, ch)
+    r = HipResampler(ch, T, T, 0.0, BH | INTERP)
+    o = OracleResampler(ch, T, T, 0.0, BH | INTERP | PRECISE)
+    s = HipResampler(ch, T, T, 0.0, BH | INTERP | STRICT)
+    os_ = OracleResampler(ch, T, T, 0.0, BH | INTERP)
+    for b in (r, o, s, os_):
+        b.advance(T / 2)
+    for blk in (x[:25000], x[25000:]):
+        u, g, y = r.process(blk, 64, ratio)
+        uo, go, yo = o.process(blk, 64, ratio)
+        assert (u, g) == (uo, go) and u == len(blk) and (g > 0 or len(blk) < 7000)
+        ok, worst, rms = tolerance_ok(y, yo)
+        assert ok, (worst, rms)
+        us, gs, ys = s.process(blk, 64, ratio)
+        _, _, yos = os_.process(blk, 64, ratio)
+        assert (us, gs) == (uo, go) and np.array_equal(ys.view(np.uint32), yos.view(np.uint32))
