@@ -1,10 +1,42 @@
+#!/bin/bash
+# Regenerate the measurement evidence of a round on the GPU box (via gpurun): bench line, rocprofv3 kernel statistics and PMC
+# passes (separate runs; --pmc never together with --stats) for the headline kernel and for every other kernel the library ships.
+# usage: bash tools/refresh_evidence.sh [tag]      -> gpurun_out/<tag>/...   then: python tools/roofline_report.py gpurun_out/<tag> profiles r2
 set -u
-R=$PWD
-mkdir -p gpurun_out/final2
-python bench.py --steps 100 --warmup 10 > gpurun_out/final2/bench.json 2> gpurun_out/final2/bench.err
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final2/prof -o final -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/final2/prof.log 2>&1 )
-bash tools/pmc.sh final2/pmc > gpurun_out/final2/pmc.log 2>&1
-python tools/pmc_summary.py gpurun_out/final2/pmc > gpurun_out/final2/pmc_summary.txt 2>&1
-python tools/bench_wide.py --block 1048576 --steps 20 > gpurun_out/final2/wide.jsonl 2>/dev/null
-python tools/bench_configs.py > gpurun_out/final2/configs.jsonl 2> gpurun_out/final2/configs.err
-find gpurun_out/final2 -name "*stats*" | head; tail -c 600 gpurun_out/final2/bench.json
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+TAG=${1:-evidence}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+python $R/bench.py --steps 100 --warmup 10 > $OUT/bench100.json 2> $OUT/bench100.err
+python $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
+prof() {   # name, command...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o $name -- "$@" > $OUT/$name.stats.log 2>&1
+}
+pmc() {    # name, pass, counters..., then -- command
+  local name=$1 pass=$2; shift 2
+  local ctr=()
+  while [ "$1" != "--" ]; do ctr+=("$1"); shift; done; shift
+  rocprofv3 --kernel-trace --pmc "${ctr[@]}" --output-format csv -d $OUT/pmc -o ${name}_$pass -- "$@" > $OUT/${name}_$pass.pmc.log 2>&1
+}
+allpasses() {  # name, command...
+  local name=$1; shift
+  pmc $name p1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM_RD -- "$@"
+  pmc $name p3 FETCH_SIZE GRBM_GUI_ACTIVE -- "$@"
+  pmc $name p4 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- "$@"
+}
+BENCH="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+prof headline $BENCH
+allpasses headline python $R/bench.py --steps 3 --warmup 1 --preroll-ms 60 --no-cpu-baseline
+pmc headline p2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS -- python $R/bench.py --steps 3 --warmup 1 --preroll-ms 60 --no-cpu-baseline
+for c in general_E general_P general_A wide biquad biquad_serial decimate strict; do
+  python $R/tools/profile_case.py $c > $OUT/case_$c.json 2> $OUT/case_$c.err
+  prof $c python $R/tools/profile_case.py $c 12
+  allpasses $c python $R/tools/profile_case.py $c 4
+done
+python $R/tools/bench_configs.py --steps 30 > $OUT/configs.jsonl 2> $OUT/configs.err
+python $R/tools/bench_wide.py --block 1048576 --steps 20 > $OUT/wide.jsonl 2>/dev/null
+ARTAMD_HOST_TRACE=1 python $R/tools/bench_host_api.py > $OUT/host_api.txt 2>&1
+python $R/tools/art_timing.py 60 > $OUT/art_timing.txt 2>&1
+ls $OUT $OUT/prof $OUT/pmc | head -80
