@@ -1,0 +1,454 @@
+// fir_general.hip — the any-ratio kernels of the windowed-sinc interpolator (gfx950): the wave-per-frame-group general kernel
+// (default and EXTEND_CONVOLUTION_MATH modes, single and batched launches), the strict-order kernel (RESAMPLE_STRICT_ORDER: the
+// reference's C source order, bit for bit), and the small data movers (history roll, planar <-> interleaved).
+//
+// Reference semantics restated (not translated): reference resampler.c:1135-1181 (subsample_*), :1033-1057 (apply_filter*).
+// Compiled with -ffp-contract=off: the only fused multiply-adds are the explicit ones of the default mode.
+#include "fir_common.hip.h"
+
+namespace {
+
+constexpr int GEN_THREADS = 256;
+constexpr int GEN_MAX_TILE = 32;
+
+// General kernel: one workgroup per tile of consecutive output frames; the tile's input span is
+// staged once in LDS (coalesced frame-major reads), then each wave evaluates whole output frames:
+// lanes stride the taps, every lane feeds CG channels and both interpolation rows from one LDS read.
+// G: lanes that share one output frame (64 = a whole wave, or 16: four output frames per wave side by side — the cross-lane
+// reduction and the per-output bookkeeping are then paid once per FOUR outputs, which is most of the cost when taps x
+// channels is small).  G depends on the tap count only, never on the tile, so a frame's value does not depend on how a
+// call is cut up.
+template <int CG, bool INTERP, bool PRECISE, int G>
+__device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const ArtSegTable &segs, int tile, unsigned int bx, unsigned int by)
+{
+    constexpr int SUBS = 64 / G;
+    using Acc = typename std::conditional<PRECISE || ART_WIDE, double, float>::type;   // 8-byte samples accumulate in double
+    extern __shared__ __attribute__ ((aligned (16))) art_s xs [];
+    __shared__ int s_ip [GEN_MAX_TILE], s_fi [GEN_MAX_TILE];
+    __shared__ double s_frac [GEN_MAX_TILE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane / G, l = lane % G;       // output within the wave, lane within the output's group
+    const int ch0 = by * CG;
+    const int half = a.T / 2;
+    // Blocks [0, workers) evaluate one tile of outputs each; any
+    // further blocks (x only, y == 0) roll the history for the next call (reads hist ++ in, writes the OTHER history
+    // buffer: independent of everything else in flight) — one launch less per call.
+    const unsigned int workers = (a.n_end - a.n_begin + (unsigned int) tile - 1) / (unsigned int) tile;
+    if (bx >= workers) {
+        if (by) return;
+        const int e = (int)(bx - workers) * GEN_THREADS + tid;
+        if (e < a.H * a.C) {
+            const int f = e / a.C, c = e - f * a.C, lin = a.roll_appended + f;
+            art_s v = 0;
+            if (lin < a.H) v = a.hist [(size_t) lin * a.C + c];
+            else if (a.in) { const int gi = lin - a.H; v = a.in_pitch ? a.in [(size_t) c * a.in_pitch + gi] : a.in [(size_t) gi * a.C + c]; }
+            a.roll_dst [e] = v;
+        }
+        return;
+    }
+  {
+    const unsigned int n0 = a.n_begin + bx * (unsigned int) tile;
+    const int cnt = (int) min ((unsigned int) tile, a.n_end - n0);
+
+    __syncthreads ();
+    if (tid < cnt) {
+        Pos p = locate<INTERP> (a, segs, n0 + tid);
+        s_ip [tid] = p.ip; s_fi [tid] = p.fi; s_frac [tid] = p.frac;
+    }
+    __syncthreads ();
+
+    const int lin_lo = s_ip [0] - half + 1;
+    const int span = s_ip [cnt - 1] + half + 1 - lin_lo;
+
+    for (int e = tid; e < span * CG; e += GEN_THREADS) {
+        int f = e / CG, c = e - f * CG;
+        xs [e] = load_frame (a, segs.lin_floor, lin_lo + f, ch0 + c);
+    }
+    __syncthreads ();
+
+    for (int i0 = wave * SUBS; i0 < cnt; i0 += (GEN_THREADS / 64) * SUBS) {
+        const bool live = i0 + sub < cnt;                       // (a dead group recomputes the tile's last frame and drops it)
+        const int i = live ? i0 + sub : cnt - 1;
+        const int ip = s_ip [i], fi = s_fi [i];
+        const art_s *x = xs + (size_t)(ip - half + 1 - lin_lo) * CG;
+        art_s result [CG];
+
+        if (!INTERP && !a.lowpass && (fi % a.F) == 0) {
+            // exact sample hit in nearest-filter mode: the reference copies the sample through
+#pragma unroll
+            for (int c = 0; c < CG; ++c) result [c] = x [(size_t)(half - 1 + fi / a.F) * CG + c];
+        }
+        else {
+            const art_s *h0 = a.bank + (size_t) fi * a.T;
+            const art_s *h1 = h0 + a.T;
+            Acc acc0 [CG], acc1 [CG];
+#pragma unroll
+            for (int c = 0; c < CG; ++c) { acc0 [c] = 0; acc1 [c] = 0; }
+
+            // Taps are visited in mirrored pairs from the window edges towards the centre (as the
+            // reference does): partial sums stay small until the dominant central taps arrive, which
+            // keeps the float accumulation error at or below the reference's.
+            for (int p = l; p < half; p += G) {
+#pragma unroll
+                for (int side = 0; side < 2; ++side) {
+                    const int k = side ? a.T - 1 - p : p;
+                    const art_s c0 = h0 [k];
+                    const art_s c1 = INTERP ? h1 [k] : 0.0f;
+#pragma unroll
+                    for (int c = 0; c < CG; ++c) {
+                        const art_s v = x [(size_t) k * CG + c];
+                        if (PRECISE) {
+                            acc0 [c] = acc0 [c] + (Acc) c0 * (Acc) v;
+                            if (INTERP) acc1 [c] = acc1 [c] + (Acc) c1 * (Acc) v;
+                        }
+                        else {
+                            acc0 [c] = fused ((Acc) c0, (Acc) v, acc0 [c]);
+                            if (INTERP) acc1 [c] = fused ((Acc) c1, (Acc) v, acc1 [c]);
+                        }
+                    }
+                }
+            }
+
+            // interleave rows per channel: value index 2c (+1) = row fi (fi+1) of channel c
+            constexpr int NV = INTERP ? 2 * CG : CG;
+            double part [NV];
+#pragma unroll
+            for (int c = 0; c < CG; ++c) {
+                if (INTERP) { part [2 * c] = (double) acc0 [c]; part [2 * c + 1] = (double) acc1 [c]; }
+                else part [c] = (double) acc0 [c];
+            }
+            reduce_level<NV, G / 2> (part, lane);
+
+            static_assert (NV <= G, "one lane group must hold every value");
+            constexpr int GROUP = G / NV;                        // lanes holding the same reduced value
+            const double mine = part [0];
+            const double frac = s_frac [i];
+            art_s y;
+            if (INTERP) {
+                // the lane group of row fi fetches row fi+1 from the neighbouring group; fp64 lerp, un-fused
+                const double s1 = __shfl_xor (mine, GROUP);
+                const double left = mine * (1.0 - frac);
+                const double right = s1 * frac;
+                y = (art_s)(left + right);
+            }
+            else
+                y = (art_s) mine;
+
+            const int owner = INTERP ? (l / GROUP) >> 1 : l / GROUP;
+            const bool writer = live && (l % GROUP) == 0 && (!INTERP || ((l / GROUP) & 1) == 0);
+            if (writer && ch0 + owner < a.C) {
+                const size_t n = n0 + i;
+                if (a.out_pitch) a.out [(size_t)(ch0 + owner) * a.out_pitch + n] = y;
+                else a.out [n * a.C + ch0 + owner] = y;
+            }
+            continue;
+        }
+
+#pragma unroll
+        for (int c = 0; c < CG; ++c)
+            if (live && l == c && ch0 + c < a.C) {
+                const size_t n = n0 + i;
+                if (a.out_pitch) a.out [(size_t)(ch0 + c) * a.out_pitch + n] = result [c];
+                else a.out [n * a.C + ch0 + c] = result [c];
+            }
+    }
+  }
+}
+
+template <int CG, bool INTERP, bool PRECISE, int G>
+__global__ __launch_bounds__ (GEN_THREADS)
+void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile)
+{
+    fir_general_body<CG, INTERP, PRECISE, G> (a, segs, tile, blockIdx.x, blockIdx.y);
+}
+
+
+// Many independent streams, one launch: blockIdx.z picks a stream's call (its arguments sit in a table in device memory,
+// exactly what the single-stream launch would have passed by value), x / y are that call's own grid.  Same body, same
+// tile geometry => the samples are identical to n separate launches.
+constexpr int BATCH_SEGS = 4;                       // ring-epoch segments a batched call may have (small blocks have 1 or 2)
+struct FirBatchItem {
+    ArtFirArgs a;
+    int seg_count, lin_floor;
+    unsigned int first [BATCH_SEGS]; int lin_base [BATCH_SEGS]; double base [BATCH_SEGS];
+    int tile; unsigned int blocks_x, blocks_y; int pad;
+};
+
+template <int CG, bool INTERP, bool PRECISE, int G>
+__global__ __launch_bounds__ (GEN_THREADS)
+void fir_general_batch_kernel (const FirBatchItem *items)
+{
+    __shared__ ArtSegTable s_tab;                   // the table the body expects, rebuilt from the item's few entries
+    const FirBatchItem &it = items [blockIdx.z];
+    if (blockIdx.x >= it.blocks_x || blockIdx.y >= it.blocks_y) return;
+    if (threadIdx.x < BATCH_SEGS) {
+        s_tab.first [threadIdx.x] = it.first [threadIdx.x]; s_tab.lin_base [threadIdx.x] = it.lin_base [threadIdx.x];
+        s_tab.base [threadIdx.x] = it.base [threadIdx.x];
+    }
+    if (threadIdx.x == 0) { s_tab.count = it.seg_count; s_tab.lin_floor = it.lin_floor; }
+    __syncthreads ();
+    fir_general_body<CG, INTERP, PRECISE, G> (it.a, s_tab, it.tile, blockIdx.x, blockIdx.y);
+}
+
+// Strict kernel: one lane per output sample, taps visited in the reference's source order
+// (pairs from both ends towards the middle, sample-type accumulator; or in order with a double accumulator),
+// no fused operations.  Bit-identical to the reference compiled with -O2 -ffp-contract=off.
+template <bool INTERP>
+__global__ __launch_bounds__ (256)
+void fir_strict_kernel (ArtFirArgs a, ArtSegTable segs, int precise)
+{
+    const size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned int n = a.n_begin + (unsigned int)(idx / a.C);
+    const int ch = (int)(idx % a.C);
+    if (n >= a.n_end) return;
+
+    const Pos p = locate<INTERP> (a, segs, n);
+    const int T = a.T, half = T / 2, w = p.ip - half + 1;
+    art_s y;
+
+    auto dot = [&] (const art_s *h) -> double {
+        if (precise) {
+            double acc = 0.0;
+            for (int k = 0; k < T; ++k) {
+                double prod = (double) h [k] * (double) load_frame (a, segs.lin_floor, w + k, ch);
+                acc = acc + prod;
+            }
+            return acc;
+        }
+        art_s acc = 0.0f;
+        for (int lo = 0, hi = T - 1; lo < hi; ++lo, --hi) {
+            art_s pl = h [lo] * load_frame (a, segs.lin_floor, w + lo, ch);
+            art_s ph = h [hi] * load_frame (a, segs.lin_floor, w + hi, ch);
+            art_s pair = pl + ph;
+            acc = acc + pair;
+        }
+        return (double) acc;
+    };
+
+    if (INTERP) {
+        double s0 = dot (a.bank + (size_t) p.fi * T);
+        double s1 = dot (a.bank + (size_t)(p.fi + 1) * T);
+        double left = s0 * (1.0 - p.frac);
+        double right = s1 * p.frac;
+        y = (art_s)(left + right);
+    }
+    else if (!a.lowpass && (p.fi % a.F) == 0)
+        y = load_frame (a, segs.lin_floor, p.ip + p.fi / a.F, ch);
+    else
+        y = (art_s) dot (a.bank + (size_t) p.fi * T);
+
+    if (a.out_pitch) a.out [(size_t) ch * a.out_pitch + n] = y;
+    else a.out [(size_t) n * a.C + ch] = y;
+}
+
+__global__ void roll_history_kernel (art_s *dst, const art_s *hist, const art_s *in, long in_pitch, int appended, int H, int C)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= H * C) return;
+    const int f = e / C, c = e - f * C, lin = appended + f;
+    art_s v = 0.0f;
+    if (lin < H) v = hist [(size_t) lin * C + c];
+    else if (in) { const int g = lin - H; v = in_pitch ? in [(size_t) c * in_pitch + g] : in [(size_t) g * C + c]; }
+    dst [e] = v;
+}
+
+__global__ void interleave_kernel (art_s *dst, const art_s *src, long pitch, int frames, int C)
+{
+    const size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t) frames * C) return;
+    const size_t f = e / C; const int c = (int)(e - f * C);
+    dst [e] = src [(size_t) c * pitch + f];
+}
+
+__global__ void deinterleave_kernel (art_s *dst, long pitch, const art_s *src, int frames, int C)
+{
+    const size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t) frames * C) return;
+    const size_t f = e / C; const int c = (int)(e - f * C);
+    dst [(size_t) c * pitch + f] = src [e];
+}
+
+// tile size, LDS bytes and grid of one general-kernel launch (shared by the single and the batched launch)
+template <int CG>
+bool general_geometry (const ArtFirArgs &a, int *tile_out, size_t *lds_out, dim3 *grid_out, unsigned int crowd = 1)
+{
+    // tile size: as many consecutive outputs as keep the staged span within the LDS budget
+    const int lds_budget = 64 * 1024;
+    const int max_span = lds_budget / ((int) sizeof (art_s) * CG);
+    int tile = (int) floor ((max_span - a.T - 3) * a.ratio);
+    if (tile > GEN_MAX_TILE) tile = GEN_MAX_TILE;
+    // small calls: prefer many small tiles (each wave walks its tile's outputs serially, so latency ~ tile/4
+    // outputs) over staging efficiency, until there are about four workgroups per CU
+    // (`crowd` = launches of this size sharing the grid — the batched entry point: many streams fill the chip together, so
+    // each keeps larger tiles.  An output's value does not depend on the tile it is computed in.)
+    const unsigned int total_outputs = a.n_end - a.n_begin;
+    while (tile > 4 && (unsigned long long)((total_outputs + tile - 1) / tile) * crowd < 1024u) tile >>= 1;
+    if (tile < 1) tile = 1;
+    long span = a.T + (long) ceil (tile / a.ratio) + 3;
+    size_t lds = (size_t) span * CG * sizeof (art_s);
+    if (lds > 160 * 1024 - 1024) return false;              // absurd ratio/taps combination
+    const unsigned int total = a.n_end - a.n_begin;
+    const unsigned int roll_blocks = a.roll_dst ? (unsigned int)((a.H * a.C + GEN_THREADS - 1) / GEN_THREADS) : 0u;
+    *tile_out = tile; *lds_out = lds;
+    *grid_out = dim3 ((total + tile - 1) / tile + roll_blocks, (a.C + CG - 1) / CG);
+    return true;
+}
+
+template <int CG>
+int launch_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st)
+{
+    int tile; size_t lds; dim3 grid;
+    if (!general_geometry<CG> (a, &tile, &lds, &grid)) return -1;
+    const bool precise = (a.mode & 3) == ART_MODE_PRECISE;
+
+#define GO(I, P) do { const int gg = general_group (a.T); if (gg == 16) GO_ (I, P, 16); else if (gg == 32) GO_ (I, P, 32); else GO_ (I, P, 64); } while (0)
+#define GO_(I, P, GG) do { auto k = fir_general_kernel<CG, I, P, GG>; \
+        if (lds > 48 * 1024) (void) hipFuncSetAttribute ((const void *) k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
+        hipLaunchKernelGGL (k, grid, dim3 (GEN_THREADS), lds, st, a, segs, tile); } while (0)
+    if (a.interpolate) { if (precise) GO (true, true); else GO (true, false); }
+    else               { if (precise) GO (false, true); else GO (false, false); }
+#undef GO
+#undef GO_
+    return 0;
+}
+
+template <int CG>
+int batch_variant (const ArtFirArgs *a, const ArtSegTable *segs, const int *which, int count, bool interp, bool precise, int group,
+                          FirBatchItem *host, FirBatchItem *dev, hipStream_t st)
+{
+    size_t lds_max = 0; unsigned int gx = 0, gy = 0;
+    for (int k = 0; k < count; ++k) {
+        const int i = which [k];
+        int tile; size_t lds; dim3 grid;
+        if (!general_geometry<CG> (a [i], &tile, &lds, &grid, (unsigned int) count)) return -1;
+        if (segs [i].count > BATCH_SEGS) return -1;
+        host [k].a = a [i]; host [k].seg_count = segs [i].count; host [k].lin_floor = segs [i].lin_floor;
+        for (int q = 0; q < BATCH_SEGS; ++q) {
+            const bool used = q < segs [i].count;
+            host [k].first [q] = used ? segs [i].first [q] : 0u; host [k].lin_base [q] = used ? segs [i].lin_base [q] : 0; host [k].base [q] = used ? segs [i].base [q] : 0.0;
+        }
+        host [k].tile = tile; host [k].blocks_x = grid.x; host [k].blocks_y = grid.y; host [k].pad = 0;
+        if (lds > lds_max) lds_max = lds;
+        if (grid.x > gx) gx = grid.x;
+        if (grid.y > gy) gy = grid.y;
+    }
+    if (hipMemcpyAsync (dev, host, sizeof (FirBatchItem) * (size_t) count, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+#define GOB(I, P) do { if (group == 16) GOB_ (I, P, 16); else if (group == 32) GOB_ (I, P, 32); else GOB_ (I, P, 64); } while (0)
+#define GOB_(I, P, GG) do { auto k = fir_general_batch_kernel<CG, I, P, GG>; \
+        if (lds_max > 48 * 1024) (void) hipFuncSetAttribute ((const void *) k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_max); \
+        hipLaunchKernelGGL (k, dim3 (gx, gy, (unsigned int) count), dim3 (GEN_THREADS), lds_max, st, (const FirBatchItem *) dev); } while (0)
+    if (interp) { if (precise) GOB (true, true); else GOB (true, false); }
+    else        { if (precise) GOB (false, true); else GOB (false, false); }
+#undef GOB
+#undef GOB_
+    return hipGetLastError () == hipSuccess ? 0 : -1;
+}
+
+
+} // namespace
+
+// the general kernel on one call (default / precise mode); -1 when the tile's input span cannot fit the LDS
+int artfir_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st)
+{
+    if (a.C > 4) return launch_general<8> (a, segs, st);
+    if (a.C > 2) return launch_general<4> (a, segs, st);
+    if (a.C == 2) return launch_general<2> (a, segs, st);
+    return launch_general<1> (a, segs, st);
+}
+
+// one lane per output sample, reference source order; precise: double accumulator (reference apply_filter_precise)
+void artfir_strict (const ArtFirArgs &a, const ArtSegTable &segs, int precise, hipStream_t st)
+{
+    const size_t total = (size_t)(a.n_end - a.n_begin) * a.C;
+    const dim3 grid ((unsigned int)((total + 255) / 256));
+    if (a.interpolate) hipLaunchKernelGGL (fir_strict_kernel<true>, grid, dim3 (256), 0, st, a, segs, precise);
+    else hipLaunchKernelGGL (fir_strict_kernel<false>, grid, dim3 (256), 0, st, a, segs, precise);
+}
+
+int artfir_general_group (int taps) { return general_group (taps); }
+
+extern "C" {
+
+// n general-kernel calls of independent streams as ONE launch per kernel variant (column group x interpolation x
+// accumulator type; streams of one service normally share it).  d_table: device scratch of at least
+// n * arthip_fir_batch_item_bytes () bytes.  Returns 0, or -1 (nothing usable was launched for some item).
+size_t arthip_fir_batch_item_bytes (void) { return sizeof (FirBatchItem); }
+int arthip_fir_batch_max_segments (void) { return BATCH_SEGS; }
+
+int arthip_fir_batch (const ArtFirArgs *a, const ArtSegTable *segs, int n, void *d_table, void *stream)
+{
+    hipStream_t st = (hipStream_t) stream;
+    if (n <= 0) return 0;
+    // pinned staging (per calling thread, kept): the table goes to the device without the runtime's bounce through its own
+    // pinned buffers.  Two tables take turns, each guarded by an event recorded after the copies out of it: the call
+    // returns without waiting for the stream, and the host plans the next tick while this one runs.
+    struct Staging { FirBatchItem *host; size_t cap; hipEvent_t ev; bool pending; };
+    static thread_local Staging tl [2] = { { nullptr, 0, nullptr, false }, { nullptr, 0, nullptr, false } };
+    static thread_local int tl_turn = 0;
+    Staging &sg = tl [tl_turn ^= 1];
+    if (sg.pending) { (void) hipEventSynchronize (sg.ev); sg.pending = false; }
+    if (!sg.ev && hipEventCreateWithFlags (&sg.ev, hipEventDisableTiming) != hipSuccess) { sg.ev = nullptr; return -1; }
+    if ((size_t) n > sg.cap) {
+        if (sg.host) (void) hipHostFree (sg.host);
+        sg.cap = (size_t) n + (size_t) n / 2 + 64;
+        if (hipHostMalloc ((void **) &sg.host, sizeof (FirBatchItem) * sg.cap, hipHostMallocDefault) != hipSuccess) { sg.host = nullptr; sg.cap = 0; return -1; }
+    }
+    FirBatchItem *host = sg.host;
+    int *which = (int *) malloc (sizeof (int) * (size_t) n);
+    if (!which) return -1;
+    int rc = 0, done = 0;
+    // group by kernel variant; each group takes its own slice of the table (the copies are asynchronous, the slices must
+    // not be reused inside one call)
+    for (int cgi = 0; cgi < 4 && !rc; ++cgi)
+        for (int v = 0; v < 12 && !rc; ++v) {
+            const bool interp = (v & 1) != 0, precise = (v & 2) != 0;
+            const int group = 16 << (v >> 2);                     // 16, 32, 64 lanes per output frame
+            int count = 0;
+            for (int i = 0; i < n; ++i) {
+                const int cls = a [i].C > 4 ? 3 : a [i].C > 2 ? 2 : a [i].C == 2 ? 1 : 0;
+                if (cls == cgi && (a [i].interpolate != 0) == interp && (((a [i].mode & 3) == ART_MODE_PRECISE) == precise) &&
+                    general_group (a [i].T) == group && a [i].n_end > a [i].n_begin)
+                    which [count++] = i;
+            }
+            if (!count) continue;
+            FirBatchItem *hslice = host + done, *dslice = (FirBatchItem *) d_table + done;
+            switch (cgi) {
+                case 3: rc = batch_variant<8> (a, segs, which, count, interp, precise, group, hslice, dslice, st); break;
+                case 2: rc = batch_variant<4> (a, segs, which, count, interp, precise, group, hslice, dslice, st); break;
+                case 1: rc = batch_variant<2> (a, segs, which, count, interp, precise, group, hslice, dslice, st); break;
+                default: rc = batch_variant<1> (a, segs, which, count, interp, precise, group, hslice, dslice, st); break;
+            }
+            done += count;
+        }
+    // the host table must outlive the asynchronous copies out of it: marked here, waited for before its next turn
+    if (hipEventRecord (sg.ev, st) == hipSuccess) sg.pending = true;
+    else if (hipStreamSynchronize (st) != hipSuccess) rc = -1;
+    free (which);
+    return rc;
+}
+
+int arthip_roll_history (art_s *new_hist, const art_s *hist, const art_s *in, long in_pitch, int appended, int H, int C, void *stream)
+{
+    const int total = H * C;
+    hipLaunchKernelGGL (roll_history_kernel, dim3 ((total + 255) / 256), dim3 (256), 0, (hipStream_t) stream, new_hist, hist, in, in_pitch, appended, H, C);
+    return hipGetLastError () == hipSuccess ? 0 : -1;
+}
+
+int arthip_interleave (art_s *dst, const art_s *src, long pitch, int frames, int C, void *stream)
+{
+    const size_t total = (size_t) frames * C;
+    if (!total) return 0;
+    hipLaunchKernelGGL (interleave_kernel, dim3 ((unsigned int)((total + 255) / 256)), dim3 (256), 0, (hipStream_t) stream, dst, src, pitch, frames, C);
+    return hipGetLastError () == hipSuccess ? 0 : -1;
+}
+
+int arthip_deinterleave (art_s *dst, long pitch, const art_s *src, int frames, int C, void *stream)
+{
+    const size_t total = (size_t) frames * C;
+    if (!total) return 0;
+    hipLaunchKernelGGL (deinterleave_kernel, dim3 ((unsigned int)((total + 255) / 256)), dim3 (256), 0, (hipStream_t) stream, dst, pitch, src, frames, C);
+    return hipGetLastError () == hipSuccess ? 0 : -1;
+}
+
+}

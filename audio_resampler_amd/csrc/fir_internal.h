@@ -1,0 +1,9 @@
+// fir_internal.h — what the FIR translation units call in one another (C++ linkage, library-private).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "art_internal.h"
+
+int  artfir_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st);                 // fir_general.hip; -1: span does not fit the LDS
+void artfir_strict (const ArtFirArgs &a, const ArtSegTable &segs, int precise, hipStream_t st);      // fir_general.hip
+bool artfir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref);       // fir_matrix.hip | fir_matrix64.hip
+int  artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, void *stream);    // fir_matrix.hip | fir_matrix64.hip

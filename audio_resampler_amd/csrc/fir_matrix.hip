@@ -1,376 +1,13 @@
-// sinc_fir.hip — gfx950 kernels for the windowed-sinc interpolator.
-//
-// Reference semantics restated (not translated): reference resampler.c:1135-1181 (subsample_*),
-// :1033-1057 (apply_filter*), with positions per reference resampler.c:526/:643/:822 (offset2 = n/ratio).
-//
-// This translation unit is compiled with -ffp-contract=off: the only fused multiply-adds are the
-// explicit ones in the FAST accumulation; position arithmetic and the fp64 lerp round exactly where
-// the reference's C does.
-//
-// Data in HBM (all float32):
-//   bank  (F+1) x T            filter rows, row-major
-//   hist  H x C                frames kept from previous calls, frame-major (H = 1.5 T)
-//   in    n x C  (or planar)   this call's new frames
-//   "linear index" lin addresses the concatenation hist ++ in; ring index + lin_base = lin.
-#include <hip/hip_runtime.h>
-#include <climits>
-#include <cstdint>
-#include <cstdio>
-#include <type_traits>
-#include "art_internal.h"
+// fir_matrix.hip — the matrix-core (MFMA) path of the windowed-sinc interpolator for rational ratios, 4-byte samples (gfx950):
+// mfma_prepare_kernel (per-launch effective rows and canonical slot positions), fir_mfma_stream_kernel (persistent workgroups,
+// regular launches: the headline path), fir_mfma_kernel (one tile per workgroup with per-output position replay: every other
+// launch), their shared K walk, and the host-side rules that pick between them and the general kernel.
+#include "fir_common.hip.h"
+
+#if !ART_WIDE          // the 8-byte sample build has its own matrix-core kernel (fir_matrix64.hip)
 
 namespace {
 
-struct Pos { int ip; int fi; double frac; };
-
-__device__ __forceinline__ art_s load_frame (const ArtFirArgs &a, int lin_floor, int lin, int ch)
-{
-    if (lin < lin_floor || lin < 0 || ch >= a.C) return 0.0f;
-    if (lin < a.H) return a.hist [(size_t) lin * a.C + ch];
-    int f = lin - a.H;
-    if (f >= a.in_frames) return 0.0f;
-    return a.in_pitch ? a.in [(size_t) ch * a.in_pitch + f] : a.in [(size_t) f * a.C + ch];
-}
-
-// last segment whose first output is <= n
-__device__ __forceinline__ int find_segment (const ArtSegTable &segs, unsigned int n)
-{
-    int lo = 0, hi = segs.count - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (segs.first [mid] <= n) lo = mid; else hi = mid - 1;
-    }
-    return lo;
-}
-
-// exact replay of the reference's per-output position arithmetic (fp64, un-fused)
-template <bool INTERP>
-__device__ __forceinline__ Pos locate (const ArtFirArgs &a, const ArtSegTable &segs, unsigned int n)
-{
-    const int e = find_segment (segs, n);
-    const double step = n ? (double) n / a.ratio : 0.0;
-    const double off = segs.base [e] + step;
-    const double whole = floor (off);
-    Pos p;
-
-    double fr = off - whole;
-    fr = fr * (double) a.F;
-
-    if (INTERP) {
-        p.fi = (int) floor (fr);
-        p.frac = fr - (double) p.fi;
-    }
-    else {
-        p.fi = (int) floor (fr + 0.5);
-        p.frac = 0.0;
-    }
-
-    p.ip = (int) whole + segs.lin_base [e];
-    return p;
-}
-
-// One output sample evaluated by ONE lane, fp64 accumulation, the reference's lerp: what the matrix-core kernels do with
-// an output whose exact position is not its slot's canonical one (rare — a phase on a filter boundary that rounds the other
-// way): cheaper than a follow-up launch for a list that is almost always empty.
-template <bool INTERP>
-__device__ __forceinline__ art_s direct_sample (const ArtFirArgs &a, int lin_floor, Pos p, int ch)
-{
-    const int half = a.T / 2, w = p.ip - half + 1;
-    if (!INTERP && !a.lowpass && (p.fi % a.F) == 0) return load_frame (a, lin_floor, w + half - 1 + p.fi / a.F, ch);
-    const art_s *h0 = a.bank + (size_t) p.fi * a.T;
-    double s0 = 0.0, s1 = 0.0;
-    for (int q = 0; q < half; ++q)                            // mirrored pairs from the edges inwards, as everywhere
-        for (int side = 0; side < 2; ++side) {
-            const int k = side ? a.T - 1 - q : q;
-            const double v = (double) load_frame (a, lin_floor, w + k, ch);
-            s0 = s0 + (double) h0 [k] * v;
-            if (INTERP) s1 = s1 + (double) h0 [k + a.T] * v;
-        }
-    if (!INTERP) return (art_s) s0;
-    const double left = s0 * (1.0 - p.frac), right = s1 * p.frac;
-    return (art_s)(left + right);
-}
-
-// Cross-lane reduction of NV per-lane partial sums, carried out in fp64 so that the handful of
-// large-magnitude additions near the root of the tree do not each cost half a float ulp.
-// Halving butterfly: at every level half of the values change hands, so NV values cost
-// NV-1 (+ 6 - log2 NV) shuffle-adds instead of 6*NV.  On return lane L holds the complete sum of
-// value (L >> (6 - log2 NV)) in v[0].
-// (Levels are unrolled at compile time — with a run-time count of live values the register array is indexed
-// dynamically and every exchange turns into a chain of compares and selects over the whole array: 1,400 VALU
-// instructions per output for 16 values instead of ~80.)
-template <int N, int M>                            // N live values, lane mask M
-__device__ __forceinline__ void reduce_level (double *v, int lane)
-{
-    if constexpr (M >= 1) {
-        if constexpr (N > 1) {
-            const bool upper = (lane & M) != 0;
-#pragma unroll
-            for (int j = 0; j < N / 2; ++j) {
-                const double keep = upper ? v [j + N / 2] : v [j];
-                const double send = upper ? v [j] : v [j + N / 2];
-                v [j] = keep + __shfl_xor (send, M);
-            }
-            reduce_level<N / 2, M / 2> (v, lane);
-        }
-        else {
-            v [0] = v [0] + __shfl_xor (v [0], M);
-            reduce_level<1, M / 2> (v, lane);
-        }
-    }
-}
-
-template <int NV>
-__device__ __forceinline__ void wave_reduce (double (&v) [NV], int lane)
-{
-    reduce_level<NV, 32> (v, lane);
-}
-
-__attribute__ ((unused)) __device__ __forceinline__ float fused (float a, float b, float c) { return __builtin_fmaf (a, b, c); }
-__attribute__ ((unused)) __device__ __forceinline__ double fused (double a, double b, double c) { return __builtin_fma (a, b, c); }
-
-constexpr int GEN_THREADS = 256;
-constexpr int GEN_MAX_TILE = 32;
-
-// General kernel: one workgroup per tile of consecutive output frames; the tile's input span is
-// staged once in LDS (coalesced frame-major reads), then each wave evaluates whole output frames:
-// lanes stride the taps, every lane feeds CG channels and both interpolation rows from one LDS read.
-// G: lanes that share one output frame (64 = a whole wave, or 16: four output frames per wave side by side — the cross-lane
-// reduction and the per-output bookkeeping are then paid once per FOUR outputs, which is most of the cost when taps x
-// channels is small).  G depends on the tap count only, never on the tile, so a frame's value does not depend on how a
-// call is cut up.
-template <int CG, bool INTERP, bool PRECISE, int G>
-__device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const ArtSegTable &segs, int tile, unsigned int bx, unsigned int by)
-{
-    constexpr int SUBS = 64 / G;
-    using Acc = typename std::conditional<PRECISE || ART_WIDE, double, float>::type;   // 8-byte samples accumulate in double
-    extern __shared__ __attribute__ ((aligned (16))) art_s xs [];
-    __shared__ int s_ip [GEN_MAX_TILE], s_fi [GEN_MAX_TILE];
-    __shared__ double s_frac [GEN_MAX_TILE];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sub = lane / G, l = lane % G;       // output within the wave, lane within the output's group
-    const int ch0 = by * CG;
-    const int half = a.T / 2;
-    // Blocks [0, workers) evaluate one tile of outputs each; any
-    // further blocks (x only, y == 0) roll the history for the next call (reads hist ++ in, writes the OTHER history
-    // buffer: independent of everything else in flight) — one launch less per call.
-    const unsigned int workers = (a.n_end - a.n_begin + (unsigned int) tile - 1) / (unsigned int) tile;
-    if (bx >= workers) {
-        if (by) return;
-        const int e = (int)(bx - workers) * GEN_THREADS + tid;
-        if (e < a.H * a.C) {
-            const int f = e / a.C, c = e - f * a.C, lin = a.roll_appended + f;
-            art_s v = 0;
-            if (lin < a.H) v = a.hist [(size_t) lin * a.C + c];
-            else if (a.in) { const int gi = lin - a.H; v = a.in_pitch ? a.in [(size_t) c * a.in_pitch + gi] : a.in [(size_t) gi * a.C + c]; }
-            a.roll_dst [e] = v;
-        }
-        return;
-    }
-  {
-    const unsigned int n0 = a.n_begin + bx * (unsigned int) tile;
-    const int cnt = (int) min ((unsigned int) tile, a.n_end - n0);
-
-    __syncthreads ();
-    if (tid < cnt) {
-        Pos p = locate<INTERP> (a, segs, n0 + tid);
-        s_ip [tid] = p.ip; s_fi [tid] = p.fi; s_frac [tid] = p.frac;
-    }
-    __syncthreads ();
-
-    const int lin_lo = s_ip [0] - half + 1;
-    const int span = s_ip [cnt - 1] + half + 1 - lin_lo;
-
-    for (int e = tid; e < span * CG; e += GEN_THREADS) {
-        int f = e / CG, c = e - f * CG;
-        xs [e] = load_frame (a, segs.lin_floor, lin_lo + f, ch0 + c);
-    }
-    __syncthreads ();
-
-    for (int i0 = wave * SUBS; i0 < cnt; i0 += (GEN_THREADS / 64) * SUBS) {
-        const bool live = i0 + sub < cnt;                       // (a dead group recomputes the tile's last frame and drops it)
-        const int i = live ? i0 + sub : cnt - 1;
-        const int ip = s_ip [i], fi = s_fi [i];
-        const art_s *x = xs + (size_t)(ip - half + 1 - lin_lo) * CG;
-        art_s result [CG];
-
-        if (!INTERP && !a.lowpass && (fi % a.F) == 0) {
-            // exact sample hit in nearest-filter mode: the reference copies the sample through
-#pragma unroll
-            for (int c = 0; c < CG; ++c) result [c] = x [(size_t)(half - 1 + fi / a.F) * CG + c];
-        }
-        else {
-            const art_s *h0 = a.bank + (size_t) fi * a.T;
-            const art_s *h1 = h0 + a.T;
-            Acc acc0 [CG], acc1 [CG];
-#pragma unroll
-            for (int c = 0; c < CG; ++c) { acc0 [c] = 0; acc1 [c] = 0; }
-
-            // Taps are visited in mirrored pairs from the window edges towards the centre (as the
-            // reference does): partial sums stay small until the dominant central taps arrive, which
-            // keeps the float accumulation error at or below the reference's.
-            for (int p = l; p < half; p += G) {
-#pragma unroll
-                for (int side = 0; side < 2; ++side) {
-                    const int k = side ? a.T - 1 - p : p;
-                    const art_s c0 = h0 [k];
-                    const art_s c1 = INTERP ? h1 [k] : 0.0f;
-#pragma unroll
-                    for (int c = 0; c < CG; ++c) {
-                        const art_s v = x [(size_t) k * CG + c];
-                        if (PRECISE) {
-                            acc0 [c] = acc0 [c] + (Acc) c0 * (Acc) v;
-                            if (INTERP) acc1 [c] = acc1 [c] + (Acc) c1 * (Acc) v;
-                        }
-                        else {
-                            acc0 [c] = fused ((Acc) c0, (Acc) v, acc0 [c]);
-                            if (INTERP) acc1 [c] = fused ((Acc) c1, (Acc) v, acc1 [c]);
-                        }
-                    }
-                }
-            }
-
-            // interleave rows per channel: value index 2c (+1) = row fi (fi+1) of channel c
-            constexpr int NV = INTERP ? 2 * CG : CG;
-            double part [NV];
-#pragma unroll
-            for (int c = 0; c < CG; ++c) {
-                if (INTERP) { part [2 * c] = (double) acc0 [c]; part [2 * c + 1] = (double) acc1 [c]; }
-                else part [c] = (double) acc0 [c];
-            }
-            reduce_level<NV, G / 2> (part, lane);
-
-            static_assert (NV <= G, "one lane group must hold every value");
-            constexpr int GROUP = G / NV;                        // lanes holding the same reduced value
-            const double mine = part [0];
-            const double frac = s_frac [i];
-            art_s y;
-            if (INTERP) {
-                // the lane group of row fi fetches row fi+1 from the neighbouring group; fp64 lerp, un-fused
-                const double s1 = __shfl_xor (mine, GROUP);
-                const double left = mine * (1.0 - frac);
-                const double right = s1 * frac;
-                y = (art_s)(left + right);
-            }
-            else
-                y = (art_s) mine;
-
-            const int owner = INTERP ? (l / GROUP) >> 1 : l / GROUP;
-            const bool writer = live && (l % GROUP) == 0 && (!INTERP || ((l / GROUP) & 1) == 0);
-            if (writer && ch0 + owner < a.C) {
-                const size_t n = n0 + i;
-                if (a.out_pitch) a.out [(size_t)(ch0 + owner) * a.out_pitch + n] = y;
-                else a.out [n * a.C + ch0 + owner] = y;
-            }
-            continue;
-        }
-
-#pragma unroll
-        for (int c = 0; c < CG; ++c)
-            if (live && l == c && ch0 + c < a.C) {
-                const size_t n = n0 + i;
-                if (a.out_pitch) a.out [(size_t)(ch0 + c) * a.out_pitch + n] = result [c];
-                else a.out [n * a.C + ch0 + c] = result [c];
-            }
-    }
-  }
-}
-
-template <int CG, bool INTERP, bool PRECISE, int G>
-__global__ __launch_bounds__ (GEN_THREADS)
-void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile)
-{
-    fir_general_body<CG, INTERP, PRECISE, G> (a, segs, tile, blockIdx.x, blockIdx.y);
-}
-
-// lanes per output frame: 16 up to 256 taps, 32 above (64 — one frame per wave — is what the kernel started with and still
-// instantiates for experiments).  Measured at 1M-frame blocks: 8 ch x 48 taps 15 -> 35 Gsamples/s, stereo x 156 taps 7.7 ->
-// 13.9 (16 lanes); stereo x 380 taps 6.7 -> 8.2, 8 ch x 988 taps 7.5 -> 8.4 (32 lanes): several frames per wave keep more
-// coefficient loads in flight and share the reduction.  The price is latency on calls too small to fill the chip — a
-// group walks more tap pairs than a wave did: 12 -> 14 us for 1,024 frames at 8 ch x 988 taps — which is why 16 lanes stop
-// at 256 taps (at 380 they gain no more than 32 and cost a 10 ms block 2 us).
-__host__ __device__ constexpr int general_group (int taps) { return taps <= 256 ? 16 : 32; }
-
-// Many independent streams, one launch: blockIdx.z picks a stream's call (its arguments sit in a table in device memory,
-// exactly what the single-stream launch would have passed by value), x / y are that call's own grid.  Same body, same
-// tile geometry => the samples are identical to n separate launches.
-constexpr int BATCH_SEGS = 4;                       // ring-epoch segments a batched call may have (small blocks have 1 or 2)
-struct FirBatchItem {
-    ArtFirArgs a;
-    int seg_count, lin_floor;
-    unsigned int first [BATCH_SEGS]; int lin_base [BATCH_SEGS]; double base [BATCH_SEGS];
-    int tile; unsigned int blocks_x, blocks_y; int pad;
-};
-
-template <int CG, bool INTERP, bool PRECISE, int G>
-__global__ __launch_bounds__ (GEN_THREADS)
-void fir_general_batch_kernel (const FirBatchItem *items)
-{
-    __shared__ ArtSegTable s_tab;                   // the table the body expects, rebuilt from the item's few entries
-    const FirBatchItem &it = items [blockIdx.z];
-    if (blockIdx.x >= it.blocks_x || blockIdx.y >= it.blocks_y) return;
-    if (threadIdx.x < BATCH_SEGS) {
-        s_tab.first [threadIdx.x] = it.first [threadIdx.x]; s_tab.lin_base [threadIdx.x] = it.lin_base [threadIdx.x];
-        s_tab.base [threadIdx.x] = it.base [threadIdx.x];
-    }
-    if (threadIdx.x == 0) { s_tab.count = it.seg_count; s_tab.lin_floor = it.lin_floor; }
-    __syncthreads ();
-    fir_general_body<CG, INTERP, PRECISE, G> (it.a, s_tab, it.tile, blockIdx.x, blockIdx.y);
-}
-
-// Strict kernel: one lane per output sample, taps visited in the reference's source order
-// (pairs from both ends towards the middle, sample-type accumulator; or in order with a double accumulator),
-// no fused operations.  Bit-identical to the reference compiled with -O2 -ffp-contract=off.
-template <bool INTERP>
-__global__ __launch_bounds__ (256)
-void fir_strict_kernel (ArtFirArgs a, ArtSegTable segs, int precise)
-{
-    const size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned int n = a.n_begin + (unsigned int)(idx / a.C);
-    const int ch = (int)(idx % a.C);
-    if (n >= a.n_end) return;
-
-    const Pos p = locate<INTERP> (a, segs, n);
-    const int T = a.T, half = T / 2, w = p.ip - half + 1;
-    art_s y;
-
-    auto dot = [&] (const art_s *h) -> double {
-        if (precise) {
-            double acc = 0.0;
-            for (int k = 0; k < T; ++k) {
-                double prod = (double) h [k] * (double) load_frame (a, segs.lin_floor, w + k, ch);
-                acc = acc + prod;
-            }
-            return acc;
-        }
-        art_s acc = 0.0f;
-        for (int lo = 0, hi = T - 1; lo < hi; ++lo, --hi) {
-            art_s pl = h [lo] * load_frame (a, segs.lin_floor, w + lo, ch);
-            art_s ph = h [hi] * load_frame (a, segs.lin_floor, w + hi, ch);
-            art_s pair = pl + ph;
-            acc = acc + pair;
-        }
-        return (double) acc;
-    };
-
-    if (INTERP) {
-        double s0 = dot (a.bank + (size_t) p.fi * T);
-        double s1 = dot (a.bank + (size_t)(p.fi + 1) * T);
-        double left = s0 * (1.0 - p.frac);
-        double right = s1 * p.frac;
-        y = (art_s)(left + right);
-    }
-    else if (!a.lowpass && (p.fi % a.F) == 0)
-        y = load_frame (a, segs.lin_floor, p.ip + p.fi / a.F, ch);
-    else
-        y = (art_s) dot (a.bank + (size_t) p.fi * T);
-
-    if (a.out_pitch) a.out [(size_t) ch * a.out_pitch + n] = y;
-    else a.out [(size_t) n * a.C + ch] = y;
-}
-
-#if !ART_WIDE          // the matrix-core path is single precision; 8-byte samples use the general kernel
 // ---------------------------------------------------------------------------------------------------
 // MFMA kernel for rational ratios (the headline path: 44.1k -> 48k is 160 outputs per 147 inputs).
 //
@@ -1180,399 +817,8 @@ void fir_mfma_stream_kernel (ArtFirArgs a, MfmaGeom g, int wgs_per_xcd)
         }
     }
 }
-#endif  // !ART_WIDE
-
-#if ART_WIDE
-// ---------------------------------------------------------------------------------------------------
-// fp64 matrix-core kernel for rational ratios (the 8-byte sample build).
-//
-// Same periodic-phase GEMM as the single-precision kernel above (ratio = P/Q: output n + P sits Q input frames after
-// output n at the same filter phase; 32 consecutive slots x 128 columns = periods x channels per workgroup), with
-// two differences that come with the precision target (default mode within 2^-48 of the reference-order result):
-//
-//  * the lerp is NOT folded into one row per slot.  The reference's position arithmetic is quantised to ~1e-7
-//    filter steps after a million frames, so the fractions of one slot differ from period to period by far more
-//    than a double ulp.  The A tile carries both rows of every slot — rows 0-31: h[fi_i], rows 32-63: h[fi_i + 1],
-//    each shifted to the tile's K origin — and the epilogue blends s0, s1 with the output's OWN fraction, taken
-//    from the exact fp64 replay of its position.  An output may use the tile whenever its integer position and
-//    filter index equal the slot's; anything else is evaluated directly in the epilogue (direct_sample).
-//  * accumulation is fp64 throughout (v_mfma_f64_16x16x4_f64), so there is no flush scheme.
-//
-// 4 waves; wave w owns columns [32w, 32w+32) x all rows: 2 column tiles x (4 | 2) row tiles of 16x16.  K is staged
-// through LDS in chunks of 16 ([row][k], pitch 18 doubles: conflict-free ds_read_b128); within a group of 8 k's
-// the four lane groups of a wave take k pairs (0,1),(2,3),(4,5),(6,7) and two MFMAs consume first/second element —
-// a fixed permutation of the summation order.  C/D layout of the f64 form: col = lane & 15, row = (lane >> 4) + 4 reg.
-// ---------------------------------------------------------------------------------------------------
-typedef double f64x4 __attribute__ ((ext_vector_type (4)));
-typedef double f64x2 __attribute__ ((ext_vector_type (2)));
-typedef unsigned int w_u32x4 __attribute__ ((ext_vector_type (4)));
-typedef unsigned int w_u32x2 __attribute__ ((ext_vector_type (2)));
-
-constexpr int MW_THREADS = 256;
-constexpr int MW_KC = 16;                 // k's per staged chunk
-constexpr int MW_LD = MW_KC + 2;          // LDS row pitch in doubles (144 B)
-constexpr int MW_COLS = 128;
-constexpr int MW_ROWS = 32;               // slots per workgroup
-constexpr int MW_MAX_PPW = 64;
-
-constexpr int MW_HEAD_PAD = 64;
-struct WideGeom {
-    int P, Q;
-    int slot_tiles;                       // ceil (P / 32)
-    int nrows;                            // A rows per slot tile: 64 (interpolating) or 32
-    int ktot;                             // K columns, multiple of MW_KC
-    int period_groups, groups_per_xcd;
-    double *rows;                         // [slot_tiles][nrows][ktot]  filter rows shifted to the tile's K origin, zero padded
-    int *canon_ip, *canon_fi;             // [slot_tiles*32]  canonical position of each slot (period 0 of the launch)
-    double *head; int head_frames;        // the call's head as one array (history ++ first input frames, MW_HEAD_PAD zero frames in front)
-};
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t wide_rsrc (const void *base, size_t bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc (const_cast<void *> (base), 0, (int) bytes, 0x00020000);
-}
-__device__ __forceinline__ double u2d (unsigned int lo, unsigned int hi) { return __hiloint2double ((int) hi, (int) lo); }
-
-// grid (slot tile, slot): canonical (ip, fi) of the slot and its one or two filter rows, laid out as the main kernel stages them
-template <bool INTERP>
-__global__ __launch_bounds__ (256)
-void wide_prepare_kernel (ArtFirArgs a, ArtSegTable segs, WideGeom g)
-{
-    const int st = blockIdx.x, row = blockIdx.y, tid = threadIdx.x;
-    const int rows_valid = min (MW_ROWS, g.P - st * MW_ROWS);
-    const Pos p0 = locate<INTERP> (a, segs, a.n_begin + st * MW_ROWS);
-    const Pos p = locate<INTERP> (a, segs, a.n_begin + st * MW_ROWS + min (row, rows_valid - 1));
-    if (tid == 0) {
-        g.canon_ip [st * MW_ROWS + row] = p.ip; g.canon_fi [st * MW_ROWS + row] = p.fi;
-        if (st == 0 && row == 0) a.fix_count [0] = 0;
-    }
-    const double *h0 = a.bank + (size_t) p.fi * a.T;
-    const int shift = p.ip - p0.ip;
-    double *d0 = g.rows + ((size_t) st * g.nrows + row) * g.ktot;
-    double *d1 = d0 + (size_t) MW_ROWS * g.ktot;
-    for (int k = tid; k < g.ktot; k += 256) {
-        const int tap = k - shift;
-        const bool in = tap >= 0 && tap < a.T;
-        d0 [k] = in ? h0 [tap] : 0.0;
-        if (INTERP) d1 [k] = in ? h0 [tap + a.T] : 0.0;
-    }
-    // the call's head, gathered by the whole grid (see mfma_prepare_kernel)
-    const int blocks = gridDim.x * gridDim.y, me = blockIdx.y * gridDim.x + blockIdx.x;
-    const long total = (long) g.head_frames * a.C;
-    for (long e = (long) me * 256 + tid; e < total; e += (long) blocks * 256) {
-        const int f = (int)(e / a.C), c = (int)(e - (long) f * a.C), lin = f - MW_HEAD_PAD;
-        double v = 0.0;
-        if (lin >= 0 && lin < a.H) v = a.hist [(size_t) lin * a.C + c];
-        else if (lin >= a.H && lin - a.H < a.in_frames) v = a.in [(size_t)(lin - a.H) * a.C + c];
-        g.head [e] = v;
-    }
-}
-
-template <bool INTERP, int CG>
-__global__ __launch_bounds__ (MW_THREADS, 2)
-void fir_mfma64_kernel (ArtFirArgs a, ArtSegTable segs, WideGeom g)
-{
-    constexpr int NROWS = INTERP ? 64 : 32, RT = NROWS / 16;           // A rows, row tiles
-    constexpr int PPW = MW_COLS / CG > MW_MAX_PPW ? MW_MAX_PPW : MW_COLS / CG;
-    __shared__ __attribute__ ((aligned (16))) double As [NROWS * MW_LD];
-    __shared__ __attribute__ ((aligned (16))) double Bs [MW_COLS * MW_LD];
-    __shared__ double s_frac [INTERP ? MW_ROWS * PPW : 1];             // the exact fraction of every (slot, period)
-    __shared__ unsigned char s_status [MW_ROWS * PPW];                 // 0 ok, 1 off the pattern (evaluated directly), 2 masked, 3 pass-through
-    __shared__ int s_fi [MW_ROWS], s_ip [MW_ROWS];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // XCD-aware mapping as in the single-precision kernel: XCD x takes a contiguous range of period groups
-    // workgroups past the tile grid roll the history for the next call (see fir_mfma_kernel)
-    const unsigned int tile_blocks = 8u * (unsigned int) g.groups_per_xcd * (unsigned int) g.slot_tiles;
-    if (blockIdx.x >= tile_blocks) {
-        if (a.roll_dst) {
-            const int e = (int)(blockIdx.x - tile_blocks) * MW_THREADS + (int) threadIdx.x;
-            if (e < a.H * a.C) {
-                const int f = e / a.C, c = e - f * a.C, lin = a.roll_appended + f;
-                double v = 0.0;
-                if (lin < a.H) v = a.hist [(size_t) lin * a.C + c];
-                else if (a.in && lin - a.H < a.in_frames) v = a.in [(size_t)(lin - a.H) * a.C + c];
-                a.roll_dst [e] = v;
-            }
-        }
-        return;
-    }
-    const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
-    const int st = within % g.slot_tiles, jg = xcd * g.groups_per_xcd + within / g.slot_tiles;
-    if (jg >= g.period_groups) return;
-    const int half = a.T / 2;
-    const int r0 = st * MW_ROWS;
-    const int rows_valid = min (MW_ROWS, g.P - r0);
-    const unsigned int n_tile = a.n_begin + (unsigned int)(jg * PPW) * g.P + r0;
-    if (n_tile >= a.n_end) return;
-
-    const int j_first = jg * PPW;
-    if (tid < MW_ROWS) { s_ip [tid] = g.canon_ip [st * MW_ROWS + tid] + j_first * g.Q; s_fi [tid] = g.canon_fi [st * MW_ROWS + tid]; }
-    __syncthreads ();
-    const int w0 = s_ip [0] - half + 1;                      // linear index of K column 0 (first period)
-
-    for (int e = tid; e < MW_ROWS * PPW; e += MW_THREADS) {
-        const int i = e & (MW_ROWS - 1), jl = e / MW_ROWS;
-        const unsigned int n = n_tile + (unsigned int) jl * g.P + i;
-        unsigned char status = 2;
-        if (i < rows_valid && n < a.n_end) {
-            const Pos p = locate<INTERP> (a, segs, n);
-            const int dip = p.ip - (s_ip [i] + jl * g.Q), dfi = p.fi - s_fi [i];
-            if (INTERP) { status = (dip == 0 && dfi == 0) ? 0 : 1; s_frac [e] = p.frac; }
-            else {
-                // (ip-1, fi=F) and (ip, fi=0) are the same position: row F is row 0 one tap later (resampler.c:156-168)
-                status = (dip * a.F + dfi == 0) ? 0 : 1;
-                if (status == 0 && !a.lowpass && (p.fi % a.F) == 0) status = 3;
-            }
-            if (status == 1) {
-                atomicAdd (a.fix_count, 1u); atomicAdd (a.fix_count + 1, 1u);       // (diagnostics: resampleHipLastHandedBack)
-            }
-        }
-        s_status [e] = status;
-    }
-
-    // ---- staging plan: raw buffer loads, everything out of range reads as 0.  Fixed per-thread offsets; the chunk moves the
-    // resource bases on the scalar unit — no vector arithmetic per chunk beside the matrix pipe (see fir_mfma_kernel).  A tile
-    // whose window starts inside the history stages from the call's contiguous head (wide_prepare_kernel), all others from `in`.
-    const bool touches_hist = w0 < a.H;
-    const int origin = touches_hist ? -MW_HEAD_PAD : a.H;                      // linear index of the base's first frame
-    constexpr int NA = NROWS / 32;
-    const int a_row = tid >> 3, a_kseg = (tid & 7) * 2;
-    constexpr int VEC = CG >= 2 ? 2 : 1;
-    constexpr int VPF = CG / VEC, VPP = MW_KC * VPF;
-    constexpr int NB = (PPW * VPP) / MW_THREADS;
-    static_assert ((PPW * VPP) % MW_THREADS == 0, "staging plan");
-    static_assert (MW_THREADS % VPP == 0, "per-vector period step must be uniform");
-
-    double ra [NA * 2], rb [NB * VEC];
-    const unsigned int rows_bytes = (unsigned int)((size_t) NROWS * g.ktot * 8);
-    const unsigned int in_bytes = touches_hist ? (unsigned int)((size_t) g.head_frames * CG * 8) : (unsigned int)((size_t) a.in_frames * CG * 8);
-    const char *rows_base = reinterpret_cast<const char *> (g.rows + (size_t) st * NROWS * g.ktot);
-    const char *in_base = touches_hist ? reinterpret_cast<const char *> (g.head) : reinterpret_cast<const char *> (a.in);
-    const int aoff = (a_row * g.ktot + a_kseg) * 8;          // vector u / row tile m differ from the first by a UNIFORM step: scalar too
-    const int boff = (max (w0 + (tid / VPP) * g.Q + (tid % VPP) / VPF - origin, 0) * CG + ((tid % VPP) % VPF) * VEC) * 8;
-    auto lean_fetch = [&] (int chunk) {
-#pragma unroll
-        for (int m = 0; m < NA; ++m) {
-            const unsigned int sa = min ((unsigned int) chunk * (MW_KC * 8u) + (unsigned int)(m * 32 * g.ktot) * 8u, rows_bytes);
-            const w_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128 (wide_rsrc (rows_base + sa, rows_bytes - sa), aoff, 0, 0);
-            ra [m * 2] = u2d (v.x, v.y); ra [m * 2 + 1] = u2d (v.z, v.w);
-        }
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            const unsigned int sb = min ((unsigned int) chunk * (MW_KC * CG * 8u) + (unsigned int)(u * (MW_THREADS / VPP) * g.Q) * (CG * 8u), in_bytes);
-            const __amdgpu_buffer_rsrc_t r_in = wide_rsrc (in_base + sb, in_bytes - sb);
-            if (VEC == 2) {
-                const w_u32x4 x = __builtin_amdgcn_raw_buffer_load_b128 (r_in, boff, 0, 0);
-                rb [u * VEC] = u2d (x.x, x.y); rb [u * VEC + (VEC - 1)] = u2d (x.z, x.w);
-            }
-            else {
-                const w_u32x2 x = __builtin_amdgcn_raw_buffer_load_b64 (r_in, boff, 0, 0);
-                rb [u * VEC] = u2d (x.x, x.y);
-            }
-        }
-    };
-    auto commit = [&] () {
-#pragma unroll
-        for (int m = 0; m < NA; ++m) {
-            f64x2 v; v [0] = ra [m * 2]; v [1] = ra [m * 2 + 1];
-            *reinterpret_cast<f64x2 *> (&As [(m * 32 + a_row) * MW_LD + a_kseg]) = v;
-        }
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            const int vi = tid + u * MW_THREADS;
-            const int jl = vi / VPP, rem = vi % VPP, kk = rem / VPF, cv = rem % VPF;
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) Bs [(jl * CG + cv * VEC + e) * MW_LD + kk] = rb [u * VEC + e];
-        }
-    };
-
-    constexpr int ncols = PPW * CG;
-    if (ncols < MW_COLS)                                     // unused columns stay zero for the whole kernel
-        for (int e = tid; e < (MW_COLS - ncols) * MW_LD; e += MW_THREADS) Bs [ncols * MW_LD + e] = 0.0;
-
-    f64x4 acc [RT][2];
-#pragma unroll
-    for (int m = 0; m < RT; ++m)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) acc [m][c] = f64x4 { 0.0, 0.0, 0.0, 0.0 };
-
-    const int nchunks = g.ktot / MW_KC;
-    const int frag = (lane & 15) * MW_LD + 2 * (lane >> 4);      // this lane's (row | column, k pair) inside a 16-wide tile
-    lean_fetch (0);
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        __syncthreads ();                                    // previous chunk fully consumed (first pass: status table complete)
-        commit ();
-        __syncthreads ();
-        if (chunk + 1 < nchunks) lean_fetch (chunk + 1);     // global loads fly while the matrix cores work
-#pragma unroll
-        for (int grp = 0; grp < MW_KC / 8; ++grp) {
-            f64x2 av [RT], bv [2];
-#pragma unroll
-            for (int m = 0; m < RT; ++m) av [m] = *reinterpret_cast<const f64x2 *> (&As [m * 16 * MW_LD + frag + grp * 8]);
-#pragma unroll
-            for (int c = 0; c < 2; ++c) bv [c] = *reinterpret_cast<const f64x2 *> (&Bs [(wave * 32 + c * 16) * MW_LD + frag + grp * 8]);
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int m = 0; m < RT; ++m)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c)
-                        acc [m][c] = __builtin_amdgcn_mfma_f64_16x16x4f64 (av [m][h], bv [c][h], acc [m][c], 0, 0, 0);
-        }
-    }
-
-    // ---- epilogue.  Row tiles 0,1 hold row fi of slots 0-15 / 16-31, tiles 2,3 row fi+1 of the same slots.
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int col = wave * 32 + c * 16 + (lane & 15);
-        if (col >= ncols) continue;
-        const int jl = col / CG, ch = col - jl * CG;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = t * 16 + (lane >> 4) + 4 * r;
-                const unsigned char status = s_status [jl * MW_ROWS + i];
-                if (status == 0 || status == 3) {
-                    const size_t n = (size_t) n_tile + (size_t) jl * g.P + i;
-                    double y;
-                    if (INTERP) {
-                        const double frac = s_frac [jl * MW_ROWS + i];
-                        const double left = acc [t][c][r] * (1.0 - frac);
-                        const double right = acc [INTERP ? t + 2 : t][c][r] * frac;
-                        y = left + right;
-                    }
-                    else if (status == 3) y = load_frame (a, INT_MIN, s_ip [i] + jl * g.Q + s_fi [i] / a.F, ch);
-                    else y = acc [t][c][r];
-                    a.out [n * CG + ch] = y;
-                }
-                else if (status == 1) {                        // off the canonical pattern: evaluated here at its exact position
-                    const size_t n = (size_t) n_tile + (size_t) jl * g.P + i;
-                    a.out [n * CG + ch] = direct_sample<INTERP> (a, INT_MIN, locate<INTERP> (a, segs, (unsigned int) n), ch);
-                }
-            }
-    }
-}
-#endif  // ART_WIDE
-
-__global__ void roll_history_kernel (art_s *dst, const art_s *hist, const art_s *in, long in_pitch, int appended, int H, int C)
-{
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= H * C) return;
-    const int f = e / C, c = e - f * C, lin = appended + f;
-    art_s v = 0.0f;
-    if (lin < H) v = hist [(size_t) lin * C + c];
-    else if (in) { const int g = lin - H; v = in_pitch ? in [(size_t) c * in_pitch + g] : in [(size_t) g * C + c]; }
-    dst [e] = v;
-}
-
-__global__ void interleave_kernel (art_s *dst, const art_s *src, long pitch, int frames, int C)
-{
-    const size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (size_t) frames * C) return;
-    const size_t f = e / C; const int c = (int)(e - f * C);
-    dst [e] = src [(size_t) c * pitch + f];
-}
-
-__global__ void deinterleave_kernel (art_s *dst, long pitch, const art_s *src, int frames, int C)
-{
-    const size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (size_t) frames * C) return;
-    const size_t f = e / C; const int c = (int)(e - f * C);
-    dst [(size_t) c * pitch + f] = src [e];
-}
-
-// tile size, LDS bytes and grid of one general-kernel launch (shared by the single and the batched launch)
-template <int CG>
-bool general_geometry (const ArtFirArgs &a, int *tile_out, size_t *lds_out, dim3 *grid_out, unsigned int crowd = 1)
-{
-    // tile size: as many consecutive outputs as keep the staged span within the LDS budget
-    const int lds_budget = 64 * 1024;
-    const int max_span = lds_budget / ((int) sizeof (art_s) * CG);
-    int tile = (int) floor ((max_span - a.T - 3) * a.ratio);
-    if (tile > GEN_MAX_TILE) tile = GEN_MAX_TILE;
-    // small calls: prefer many small tiles (each wave walks its tile's outputs serially, so latency ~ tile/4
-    // outputs) over staging efficiency, until there are about four workgroups per CU
-    // (`crowd` = launches of this size sharing the grid — the batched entry point: many streams fill the chip together, so
-    // each keeps larger tiles.  An output's value does not depend on the tile it is computed in.)
-    const unsigned int total_outputs = a.n_end - a.n_begin;
-    while (tile > 4 && (unsigned long long)((total_outputs + tile - 1) / tile) * crowd < 1024u) tile >>= 1;
-    if (tile < 1) tile = 1;
-    long span = a.T + (long) ceil (tile / a.ratio) + 3;
-    size_t lds = (size_t) span * CG * sizeof (art_s);
-    if (lds > 160 * 1024 - 1024) return false;              // absurd ratio/taps combination
-    const unsigned int total = a.n_end - a.n_begin;
-    const unsigned int roll_blocks = a.roll_dst ? (unsigned int)((a.H * a.C + GEN_THREADS - 1) / GEN_THREADS) : 0u;
-    *tile_out = tile; *lds_out = lds;
-    *grid_out = dim3 ((total + tile - 1) / tile + roll_blocks, (a.C + CG - 1) / CG);
-    return true;
-}
-
-template <int CG>
-int launch_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st)
-{
-    int tile; size_t lds; dim3 grid;
-    if (!general_geometry<CG> (a, &tile, &lds, &grid)) return -1;
-    const bool precise = (a.mode & 3) == ART_MODE_PRECISE;
-
-#define GO(I, P) do { const int gg = general_group (a.T); if (gg == 16) GO_ (I, P, 16); else if (gg == 32) GO_ (I, P, 32); else GO_ (I, P, 64); } while (0)
-#define GO_(I, P, GG) do { auto k = fir_general_kernel<CG, I, P, GG>; \
-        if (lds > 48 * 1024) (void) hipFuncSetAttribute ((const void *) k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
-        hipLaunchKernelGGL (k, grid, dim3 (GEN_THREADS), lds, st, a, segs, tile); } while (0)
-    if (a.interpolate) { if (precise) GO (true, true); else GO (true, false); }
-    else               { if (precise) GO (false, true); else GO (false, false); }
-#undef GO
-#undef GO_
-    return 0;
-}
-
-template <int CG>
-int batch_variant (const ArtFirArgs *a, const ArtSegTable *segs, const int *which, int count, bool interp, bool precise, int group,
-                          FirBatchItem *host, FirBatchItem *dev, hipStream_t st)
-{
-    size_t lds_max = 0; unsigned int gx = 0, gy = 0;
-    for (int k = 0; k < count; ++k) {
-        const int i = which [k];
-        int tile; size_t lds; dim3 grid;
-        if (!general_geometry<CG> (a [i], &tile, &lds, &grid, (unsigned int) count)) return -1;
-        if (segs [i].count > BATCH_SEGS) return -1;
-        host [k].a = a [i]; host [k].seg_count = segs [i].count; host [k].lin_floor = segs [i].lin_floor;
-        for (int q = 0; q < BATCH_SEGS; ++q) {
-            const bool used = q < segs [i].count;
-            host [k].first [q] = used ? segs [i].first [q] : 0u; host [k].lin_base [q] = used ? segs [i].lin_base [q] : 0; host [k].base [q] = used ? segs [i].base [q] : 0.0;
-        }
-        host [k].tile = tile; host [k].blocks_x = grid.x; host [k].blocks_y = grid.y; host [k].pad = 0;
-        if (lds > lds_max) lds_max = lds;
-        if (grid.x > gx) gx = grid.x;
-        if (grid.y > gy) gy = grid.y;
-    }
-    if (hipMemcpyAsync (dev, host, sizeof (FirBatchItem) * (size_t) count, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
-#define GOB(I, P) do { if (group == 16) GOB_ (I, P, 16); else if (group == 32) GOB_ (I, P, 32); else GOB_ (I, P, 64); } while (0)
-#define GOB_(I, P, GG) do { auto k = fir_general_batch_kernel<CG, I, P, GG>; \
-        if (lds_max > 48 * 1024) (void) hipFuncSetAttribute ((const void *) k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_max); \
-        hipLaunchKernelGGL (k, dim3 (gx, gy, (unsigned int) count), dim3 (GEN_THREADS), lds_max, st, (const FirBatchItem *) dev); } while (0)
-    if (interp) { if (precise) GOB (true, true); else GOB (true, false); }
-    else        { if (precise) GOB (false, true); else GOB (false, false); }
-#undef GOB
-#undef GOB_
-    return hipGetLastError () == hipSuccess ? 0 : -1;
-}
-
-
 } // namespace
 
-extern "C" {
-
-static int run_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st)
-{
-    if (a.C > 4) return launch_general<8> (a, segs, st);
-    if (a.C > 2) return launch_general<4> (a, segs, st);
-    if (a.C == 2) return launch_general<2> (a, segs, st);
-    return launch_general<1> (a, segs, st);
-}
-
-#if !ART_WIDE
 // May fir_mfma_stream_kernel run this launch (it never replays an output's position)?  Every output n of the launch sits at
 // fl (base_e + fl (n / ratio)) (reference resampler.c:526, :1149); with ratio = fl (P / Q) the lattice the tiles assume is
 // base_e + n Q / P, and the three roundings in between move a position by at most
@@ -1600,14 +846,12 @@ static bool mfma_launch_is_regular (const ArtFirArgs *a, const ArtSegTable *segs
     }
     return true;
 }
-#endif
 
 // does this call take the matrix-core path (arthip_fir), or the general kernel?  One rule, also asked by the batched entry
 // point, which only gathers calls the general kernel would have run anyway.
-static bool takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref)
+bool artfir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref)
 {
     if (a->n_end <= a->n_begin || (a->mode & 3) == ART_MODE_STRICT) return false;
-#if !ART_WIDE
     const unsigned int total = a->n_end - a->n_begin;
     bool enough;
     if (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32) {
@@ -1624,97 +868,13 @@ static bool takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int
     return a->mode == ART_MODE_FAST && a->period_out > 0 && a->fix_list && a->scratch && a->in_pitch == 0 && a->out_pitch == 0 &&
                          segs->lin_floor == INT_MIN && kernel_pref != ART_KERNEL_GENERAL &&
                          (enough || kernel_pref >= ART_KERNEL_MFMA) && total >= (unsigned int) a->period_out;
-
-#else
-    const unsigned int total = a->n_end - a->n_begin;
-    const double k_ns = ((0.2 + 0.05 * a->C) + 0.00021 * a->C * a->T) * (general_group (a->T) == 16 ? 0.55 : a->T <= 512 ? 0.85 : 0.95);
-    const double floor_ns = 15000.0 + 4100.0 * ((a->T + 63) / 32);
-    const bool enough = total * k_ns >= floor_ns - 5000.0;
-    const bool small = (size_t) a->in_frames * a->C * 8 < 0x7fff0000ull && (size_t) a->H * a->C * 8 < 0x7fff0000ull &&
-                       ((uintptr_t) a->in % 16) == 0 && ((uintptr_t) a->hist % 16) == 0;
-    const int cgt = (small && (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32)) ? a->C : 0;
-    return a->mode == ART_MODE_FAST && a->period_out > 0 && a->fix_list && a->scratch && a->in_pitch == 0 && a->out_pitch == 0 &&
-                    segs->lin_floor == INT_MIN && kernel_pref != ART_KERNEL_GENERAL && cgt != 0 &&
-                    (enough || kernel_pref >= ART_KERNEL_MFMA) && total >= (unsigned int) a->period_out;
-#endif
 }
 
-int arthip_fir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref) { return takes_matrix_path (a, segs, kernel_pref) ? 1 : 0; }
-
-// n general-kernel calls of independent streams as ONE launch per kernel variant (column group x interpolation x
-// accumulator type; streams of one service normally share it).  d_table: device scratch of at least
-// n * arthip_fir_batch_item_bytes () bytes.  Returns 0, or -1 (nothing usable was launched for some item).
-size_t arthip_fir_batch_item_bytes (void) { return sizeof (FirBatchItem); }
-int arthip_fir_batch_max_segments (void) { return BATCH_SEGS; }
-
-int arthip_fir_batch (const ArtFirArgs *a, const ArtSegTable *segs, int n, void *d_table, void *stream)
+// Launch the matrix-core path for this call if it applies: returns ART_KERNEL_MFMA (| ART_FIR_ROLLED), -1 on a launch failure,
+// 0 when the call is for the general kernel.
+int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, void *stream)
 {
     hipStream_t st = (hipStream_t) stream;
-    if (n <= 0) return 0;
-    // pinned staging (per calling thread, kept): the table goes to the device without the runtime's bounce through its own
-    // pinned buffers.  Two tables take turns, each guarded by an event recorded after the copies out of it: the call
-    // returns without waiting for the stream, and the host plans the next tick while this one runs.
-    struct Staging { FirBatchItem *host; size_t cap; hipEvent_t ev; bool pending; };
-    static thread_local Staging tl [2] = { { nullptr, 0, nullptr, false }, { nullptr, 0, nullptr, false } };
-    static thread_local int tl_turn = 0;
-    Staging &sg = tl [tl_turn ^= 1];
-    if (sg.pending) { (void) hipEventSynchronize (sg.ev); sg.pending = false; }
-    if (!sg.ev && hipEventCreateWithFlags (&sg.ev, hipEventDisableTiming) != hipSuccess) { sg.ev = nullptr; return -1; }
-    if ((size_t) n > sg.cap) {
-        if (sg.host) (void) hipHostFree (sg.host);
-        sg.cap = (size_t) n + (size_t) n / 2 + 64;
-        if (hipHostMalloc ((void **) &sg.host, sizeof (FirBatchItem) * sg.cap, hipHostMallocDefault) != hipSuccess) { sg.host = nullptr; sg.cap = 0; return -1; }
-    }
-    FirBatchItem *host = sg.host;
-    int *which = (int *) malloc (sizeof (int) * (size_t) n);
-    if (!which) return -1;
-    int rc = 0, done = 0;
-    // group by kernel variant; each group takes its own slice of the table (the copies are asynchronous, the slices must
-    // not be reused inside one call)
-    for (int cgi = 0; cgi < 4 && !rc; ++cgi)
-        for (int v = 0; v < 12 && !rc; ++v) {
-            const bool interp = (v & 1) != 0, precise = (v & 2) != 0;
-            const int group = 16 << (v >> 2);                     // 16, 32, 64 lanes per output frame
-            int count = 0;
-            for (int i = 0; i < n; ++i) {
-                const int cls = a [i].C > 4 ? 3 : a [i].C > 2 ? 2 : a [i].C == 2 ? 1 : 0;
-                if (cls == cgi && (a [i].interpolate != 0) == interp && (((a [i].mode & 3) == ART_MODE_PRECISE) == precise) &&
-                    general_group (a [i].T) == group && a [i].n_end > a [i].n_begin)
-                    which [count++] = i;
-            }
-            if (!count) continue;
-            FirBatchItem *hslice = host + done, *dslice = (FirBatchItem *) d_table + done;
-            switch (cgi) {
-                case 3: rc = batch_variant<8> (a, segs, which, count, interp, precise, group, hslice, dslice, st); break;
-                case 2: rc = batch_variant<4> (a, segs, which, count, interp, precise, group, hslice, dslice, st); break;
-                case 1: rc = batch_variant<2> (a, segs, which, count, interp, precise, group, hslice, dslice, st); break;
-                default: rc = batch_variant<1> (a, segs, which, count, interp, precise, group, hslice, dslice, st); break;
-            }
-            done += count;
-        }
-    // the host table must outlive the asynchronous copies out of it: marked here, waited for before its next turn
-    if (hipEventRecord (sg.ev, st) == hipSuccess) sg.pending = true;
-    else if (hipStreamSynchronize (st) != hipSuccess) rc = -1;
-    free (which);
-    return rc;
-}
-
-int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, void *stream)
-{
-    hipStream_t st = (hipStream_t) stream;
-
-    if (a->n_end <= a->n_begin) return ART_KERNEL_GENERAL;
-
-    if ((a->mode & 3) == ART_MODE_STRICT) {
-        const size_t total = (size_t)(a->n_end - a->n_begin) * a->C;
-        dim3 grid ((unsigned int)((total + 255) / 256));
-        if (a->interpolate) hipLaunchKernelGGL (fir_strict_kernel<true>, grid, dim3 (256), 0, st, *a, *segs, (a->mode & 4) != 0);
-        else hipLaunchKernelGGL (fir_strict_kernel<false>, grid, dim3 (256), 0, st, *a, *segs, (a->mode & 4) != 0);
-        if (a->ev_start) { arthip_event_record (a->ev_start, stream); arthip_event_record (a->ev_stop, stream); }
-        return hipGetLastError () == hipSuccess ? ART_KERNEL_GENERAL : -1;
-    }
-
-#if !ART_WIDE
     // MFMA path: exact rational ratio, default numeric mode, interleaved buffers, no history floor — and enough work
     // to beat the general kernel.  Cost models fitted to MI355X measurements (tools/bench_small_taps.py,
     // profiles/r1_small_calls.txt), n = output frames of the launch:
@@ -1724,7 +884,7 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
     // The MFMA path is taken when the general kernel would take longer than the floor.  For channel counts without a
     // compiled column group the older rule stays: outputs x channels x taps of at least 1.2e8.
     const unsigned int total = a->n_end - a->n_begin;
-    const bool mfma_ok = takes_matrix_path (a, segs, kernel_pref);
+    const bool mfma_ok = artfir_takes_matrix_path (a, segs, kernel_pref);
 
     if (mfma_ok) {
         MfmaGeom g;
@@ -1757,14 +917,14 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
             g.canon_ip = (int *)(g.canon_frac + rows);
             g.canon_fi = g.canon_ip + rows;
             g.tile_w0 = g.canon_fi + rows;
-            if (!base || (size_t)((char *)(g.tile_w0 + 3 * g.slot_tiles) - base) > a->scratch_bytes) goto general_path;
+            if (!base || (size_t)((char *)(g.tile_w0 + 3 * g.slot_tiles) - base) > a->scratch_bytes) return 0;
             g.head = nullptr; g.head_frames = 0;
             if (ws && !wide) {
                 // the call's head as one contiguous array: everything a tile whose window starts inside the history can read
                 // (+ the two chunks the staging runs ahead)
                 const size_t used = (((size_t)((char *)(g.tile_w0 + 3 * g.slot_tiles) - base)) + 255) & ~(size_t) 255;
                 g.head_frames = MF_HEAD_PAD + a->H + (g.ppw - 1) * g.Q + g.ktot + 3 * MF_KC;
-                if (used + (size_t) g.head_frames * a->C * sizeof (float) > a->scratch_bytes) goto general_path;
+                if (used + (size_t) g.head_frames * a->C * sizeof (float) > a->scratch_bytes) return 0;
                 g.head = (float *)(base + used);
             }
         }
@@ -1814,99 +974,7 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
         // two launches per call — prepare, main — where there were three)
         return hipGetLastError () == hipSuccess ? (ART_KERNEL_MFMA | (a->roll_dst ? ART_FIR_ROLLED : 0)) : -1;
     }
-
-#else
-    // fp64 matrix-core path: exact rational ratio, interleaved buffers, the stream's channel count one of the
-    // compiled column groups, no history floor — and enough work: cost models as in the float build, fitted to this
-    // build (tools/bench_small_taps.py --wide): general ~ 5 us + n (0.2 + 0.05 C + 0.00021 C T) ns, fp64 MFMA floor
-    // ~ 15 us + 4.1 us per 32-tap chunk
-    {
-        const unsigned int total = a->n_end - a->n_begin;
-        const bool small = (size_t) a->in_frames * a->C * 8 < 0x7fff0000ull && (size_t) a->H * a->C * 8 < 0x7fff0000ull &&
-                           ((uintptr_t) a->in % 16) == 0 && ((uintptr_t) a->hist % 16) == 0;
-        const int cgt = (small && (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32)) ? a->C : 0;
-        const bool ok = takes_matrix_path (a, segs, kernel_pref);
-        if (ok) {
-            WideGeom g;
-            g.P = a->period_out; g.Q = a->period_in;
-            g.slot_tiles = (g.P + MW_ROWS - 1) / MW_ROWS;
-            g.nrows = a->interpolate ? 64 : 32;
-            const int shift_max = (int)((MW_ROWS - 1.0) * g.Q / g.P) + 2;
-            g.ktot = ((a->T + shift_max + MW_KC - 1) / MW_KC) * MW_KC;
-            const int ppw = MW_COLS / cgt > MW_MAX_PPW ? MW_MAX_PPW : MW_COLS / cgt;
-            const unsigned int periods = (total + g.P - 1) / g.P;
-            g.period_groups = (int)((periods + ppw - 1) / ppw);
-            g.groups_per_xcd = (g.period_groups + 7) / 8;
-            const size_t row_bytes = (size_t) g.slot_tiles * g.nrows * g.ktot * sizeof (double);
-            char *base = (char *) a->scratch;
-            g.rows = (double *) base;
-            g.canon_ip = (int *)(base + ((row_bytes + 15) & ~(size_t) 15));
-            g.canon_fi = g.canon_ip + (size_t) g.slot_tiles * MW_ROWS;
-            const size_t used = (((size_t)((char *)(g.canon_fi + (size_t) g.slot_tiles * MW_ROWS) - base)) + 255) & ~(size_t) 255;
-            g.head_frames = MW_HEAD_PAD + a->H + (ppw - 1) * g.Q + g.ktot + 3 * MW_KC;
-            g.head = (double *)(base + used);
-            if (base && used + (size_t) g.head_frames * a->C * sizeof (double) <= a->scratch_bytes &&
-                (size_t) g.head_frames * a->C * 8 < 0x7fff0000ull && (size_t) g.nrows * g.ktot * 8 < 0x7fff0000ull) {
-                const unsigned int roll_blocks = a->roll_dst ? (unsigned int)((a->H * a->C + MW_THREADS - 1) / MW_THREADS) : 0u;
-                const dim3 grid ((unsigned int)(8 * g.groups_per_xcd * g.slot_tiles) + roll_blocks);
-                if (a->interpolate) hipLaunchKernelGGL (wide_prepare_kernel<true>, dim3 (g.slot_tiles, MW_ROWS), dim3 (256), 0, st, *a, *segs, g);
-                else hipLaunchKernelGGL (wide_prepare_kernel<false>, dim3 (g.slot_tiles, MW_ROWS), dim3 (256), 0, st, *a, *segs, g);
-                if (a->ev_start) arthip_event_record (a->ev_start, stream);
-#define MW_GO(I, CGT) hipLaunchKernelGGL ((fir_mfma64_kernel<I, CGT>), grid, dim3 (MW_THREADS), 0, st, *a, *segs, g)
-                if (a->interpolate) switch (cgt) { case 32: MW_GO (true, 32); break; case 16: MW_GO (true, 16); break; case 8: MW_GO (true, 8); break;
-                                                    case 4: MW_GO (true, 4); break; case 2: MW_GO (true, 2); break; default: MW_GO (true, 1); }
-                else                switch (cgt) { case 32: MW_GO (false, 32); break; case 16: MW_GO (false, 16); break; case 8: MW_GO (false, 8); break;
-                                                    case 4: MW_GO (false, 4); break; case 2: MW_GO (false, 2); break; default: MW_GO (false, 1); }
-#undef MW_GO
-                if (a->ev_stop) arthip_event_record (a->ev_stop, stream);
-                return hipGetLastError () == hipSuccess ? (ART_KERNEL_MFMA | (a->roll_dst ? ART_FIR_ROLLED : 0)) : -1;
-            }
-        }
-    }
-#endif
-
-#if !ART_WIDE
-general_path:
-#endif
-    if (a->ev_start) arthip_event_record (a->ev_start, stream);
-    if (run_general (*a, *segs, st)) {
-        // The tile's input span does not fit the LDS (ratios below ~1/4000 with long filters: thousands of input frames per
-        // output).  The reference accepts any positive ratio, and a caller that loops until its input is consumed must not
-        // see "nothing done": one lane per output sample reading HBM directly (the strict-order kernel: reference source
-        // order, float or double accumulator as the mode asks) — slow, correct, and only ever reached by such ratios.
-        const size_t total = (size_t)(a->n_end - a->n_begin) * a->C;
-        const dim3 grid ((unsigned int)((total + 255) / 256));
-        const int precise = (a->mode & 3) == ART_MODE_PRECISE;
-        if (a->interpolate) hipLaunchKernelGGL (fir_strict_kernel<true>, grid, dim3 (256), 0, st, *a, *segs, precise);
-        else hipLaunchKernelGGL (fir_strict_kernel<false>, grid, dim3 (256), 0, st, *a, *segs, precise);
-        if (a->ev_stop) arthip_event_record (a->ev_stop, stream);
-        return hipGetLastError () == hipSuccess ? ART_KERNEL_GENERAL : -1;        // (no history roll rode along: the host launches it)
-    }
-    if (a->ev_stop) arthip_event_record (a->ev_stop, stream);
-    return hipGetLastError () == hipSuccess ? (ART_KERNEL_GENERAL | (a->roll_dst ? ART_FIR_ROLLED : 0)) : -1;
+    return 0;
 }
 
-int arthip_roll_history (art_s *new_hist, const art_s *hist, const art_s *in, long in_pitch, int appended, int H, int C, void *stream)
-{
-    const int total = H * C;
-    hipLaunchKernelGGL (roll_history_kernel, dim3 ((total + 255) / 256), dim3 (256), 0, (hipStream_t) stream, new_hist, hist, in, in_pitch, appended, H, C);
-    return hipGetLastError () == hipSuccess ? 0 : -1;
-}
-
-int arthip_interleave (art_s *dst, const art_s *src, long pitch, int frames, int C, void *stream)
-{
-    const size_t total = (size_t) frames * C;
-    if (!total) return 0;
-    hipLaunchKernelGGL (interleave_kernel, dim3 ((unsigned int)((total + 255) / 256)), dim3 (256), 0, (hipStream_t) stream, dst, src, pitch, frames, C);
-    return hipGetLastError () == hipSuccess ? 0 : -1;
-}
-
-int arthip_deinterleave (art_s *dst, long pitch, const art_s *src, int frames, int C, void *stream)
-{
-    const size_t total = (size_t) frames * C;
-    if (!total) return 0;
-    hipLaunchKernelGGL (deinterleave_kernel, dim3 ((unsigned int)((total + 255) / 256)), dim3 (256), 0, (hipStream_t) stream, dst, pitch, src, frames, C);
-    return hipGetLastError () == hipSuccess ? 0 : -1;
-}
-
-}
+#endif  // !ART_WIDE
