@@ -131,8 +131,9 @@ int arthip_biquad_order2 (Biquad *d_sections, int C, int S, art_s *d_buf, int fr
 /* bit-exact cascade, parallel over time (speculative chunks + exact verification, pcm_kernels.hip): d_in -> d_out, distinct
  * buffers; L = chunk length, W = warm-up frames per section; d_states: arthip_biquad_spec_scratch () bytes of scratch */
 size_t arthip_biquad_spec_scratch (int C, int S, int frames, int L);
+int arthip_biquad_spec_arm (int *d_first_bad, int C, void *stream);      /* once per scratch: C ints the calls keep at "no mismatch" */
 int arthip_biquad_spec (Biquad *d_sections, int C, int S, const art_s *d_in, int in_stride, art_s *d_out, int out_stride, int frames,
-                        int L, int W, void *d_states, unsigned int *d_repairs, void *stream);
+                        int L, int W, void *d_states, int *d_first_bad, unsigned int *d_repairs, void *stream);
 /* ---- time stretcher (stretch_kernels.hip) ---- */
 typedef struct {
     art_s *ring [2][2];                  /* [stage][ping-pong] input rings, `room` values each */

@@ -90,6 +90,9 @@ static int forget_length (const Biquad *f)
         }
         if (last > worst) worst = last;
     }
+    /* ARTAMD_BIQUAD_WARMUP=n forces the warm-up (tests: a warm-up far too short makes nearly every chunk boundary mismatch,
+     * which exercises the verification and repair path; the results must not change) */
+    { const char *e = getenv ("ARTAMD_BIQUAD_WARMUP"); if (e && *e) return atoi (e); }
     return worst > SPEC_MAX_WARMUP ? 0 : worst + 16;
 }
 
@@ -123,6 +126,7 @@ static struct {
     Biquad *d_state, *h_state;
     void *d_spec; size_t spec_cap;
     unsigned int *d_repairs;
+    int *d_first_bad;
     int device;
 } host_scratch = { .device = -1 };
 
@@ -131,7 +135,7 @@ static int scratch_reserve (size_t samples)
     const int device = arthip_current_device ();
     if (host_scratch.device != device) {                /* first use (or the caller moved to another GPU): start over there */
         arthip_free (host_scratch.d_in); arthip_free (host_scratch.d_out); arthip_free (host_scratch.d_state);
-        arthip_free (host_scratch.d_spec); arthip_free (host_scratch.d_repairs);
+        arthip_free (host_scratch.d_spec); arthip_free (host_scratch.d_repairs); arthip_free (host_scratch.d_first_bad);
         arthip_host_free (host_scratch.h_buf); arthip_host_free (host_scratch.h_state);
         memset (&host_scratch, 0, sizeof (host_scratch));
         host_scratch.device = device;
@@ -141,6 +145,10 @@ static int scratch_reserve (size_t samples)
     if (!host_scratch.d_repairs) {
         if (!(host_scratch.d_repairs = arthip_malloc (sizeof (unsigned int)))) return -1;
         arthip_zero (host_scratch.d_repairs, sizeof (unsigned int), NULL);
+    }
+    if (!host_scratch.d_first_bad) {
+        if (!(host_scratch.d_first_bad = arthip_malloc (sizeof (int)))) return -1;
+        arthip_biquad_spec_arm (host_scratch.d_first_bad, 1, NULL);
     }
     if (samples > host_scratch.cap) {
         arthip_free (host_scratch.d_in); arthip_free (host_scratch.d_out);
@@ -195,7 +203,7 @@ static void biquad_run_host (Biquad *f, art_s *buffer, int n, int stride, int sa
             host_scratch.spec_cap = host_scratch.d_spec ? need + need / 2 : 0;
         }
         rc = host_scratch.d_spec ? arthip_biquad_spec (host_scratch.d_state, 1, 1, host_scratch.d_in, 1, host_scratch.d_out, 1, n, L, W,
-                                                       host_scratch.d_spec, host_scratch.d_repairs, NULL) : -1;
+                                                       host_scratch.d_spec, host_scratch.d_first_bad, host_scratch.d_repairs, NULL) : -1;
         d_result = host_scratch.d_out;
     }
     else if (!sample_form && f->order == 2 && n >= 64)       /* long run of a narrow filter: the pipelined serial kernel, one channel */
@@ -251,6 +259,7 @@ struct artamd_biquad_bank {
     art_s *d_tmp; size_t tmp_cap;        /* the call's input, moved aside (the time-parallel form is not in-place) */
     void *d_spec; size_t spec_cap;
     unsigned int *d_repairs;
+    int *d_first_bad;
     void *stream;
 };
 
@@ -277,8 +286,10 @@ BiquadBank *biquadBankCreate (const Biquad *sections, int numChannels, int numSe
     }
     b->d_sections = arthip_malloc (bytes);
     b->d_repairs = arthip_malloc (sizeof (unsigned int));
-    if (!b->d_sections || !b->d_repairs || arthip_h2d (b->d_sections, sections, bytes, NULL) ||
-        arthip_zero (b->d_repairs, sizeof (unsigned int), NULL) || arthip_sync (NULL)) { biquadBankFree (b); return NULL; }
+    b->d_first_bad = arthip_malloc (sizeof (int) * (size_t) numChannels);
+    if (!b->d_sections || !b->d_repairs || !b->d_first_bad || arthip_h2d (b->d_sections, sections, bytes, NULL) ||
+        arthip_zero (b->d_repairs, sizeof (unsigned int), NULL) || arthip_biquad_spec_arm (b->d_first_bad, numChannels, NULL) ||
+        arthip_sync (NULL)) { biquadBankFree (b); return NULL; }
     return b;
 }
 
@@ -308,7 +319,7 @@ void biquadBankApplyInterleavedDevice (BiquadBank *b, artsample_t *d_buffer, int
         }
         if (b->d_tmp && b->d_spec) {
             arthip_d2d (b->d_tmp, d_buffer, samples * sizeof (art_s), b->stream);
-            if (!arthip_biquad_spec (b->d_sections, b->C, b->S, b->d_tmp, b->C, d_buffer, b->C, numFrames, L, b->warmup, b->d_spec, b->d_repairs, b->stream))
+            if (!arthip_biquad_spec (b->d_sections, b->C, b->S, b->d_tmp, b->C, d_buffer, b->C, numFrames, L, b->warmup, b->d_spec, b->d_first_bad, b->d_repairs, b->stream))
                 return;
         }
         fprintf (stderr, "artamd: time-parallel biquad unavailable (%s): serial kernel\n", arthip_last_error ());
@@ -336,7 +347,7 @@ unsigned int biquadBankRepairs (BiquadBank *b)
 
 void biquadBankFree (BiquadBank *b)
 {
-    if (b) { arthip_sync (b->stream); arthip_free (b->d_sections); arthip_free (b->d_tmp); arthip_free (b->d_spec); arthip_free (b->d_repairs); free (b); }
+    if (b) { arthip_sync (b->stream); arthip_free (b->d_sections); arthip_free (b->d_tmp); arthip_free (b->d_spec); arthip_free (b->d_repairs); arthip_free (b->d_first_bad); free (b); }
 }
 
 /* ------------------------------------------------------------------------------------------

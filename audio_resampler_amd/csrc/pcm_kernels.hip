@@ -9,6 +9,7 @@
 // wave.  Compiled with -ffp-contract=off: every multiply and add rounds separately, as in the
 // reference.
 #include <hip/hip_runtime.h>
+#include <climits>
 #include <cstdlib>
 #include <type_traits>
 #include "art_internal.h"
@@ -159,29 +160,59 @@ __device__ __forceinline__ void put_state (SectionRegs *r, const SpecState *src)
         for (int k = 0; k < 4; ++k) { r [s].x [k] = src [s].x [k]; r [s].y [k] = src [s].y [k]; }
 }
 
-// frames [from, to) of channel c through all S sections (every section live), exact order; writes `out`
-template <int S>
+// frames [from, to) of channel c through sections 0 .. ACTIVE-1, exact order; STORE: the results go to `out`.
+// The recurrence is latency-bound and a lane's loads are independent of it: two batches of U frames are kept in flight
+// (the next batch's loads are issued before the current batch's dependent chain starts).
+template <int S, int ACTIVE, bool STORE>
 __device__ __forceinline__ void spec_run (SectionRegs *r, const art_s *in, int stride, art_s *out, int out_stride, int c, int from, int to)
 {
-    constexpr int U = 8;                                // loads of U frames fly ahead of the dependent chain
-    int n = from;
-    for (; n + U <= to; n += U) {
-        art_s v [U];
+    constexpr int U = 8;
+    auto fetch = [&] (art_s (&v) [U], int n) {
 #pragma unroll
         for (int u = 0; u < U; ++u) v [u] = in [(size_t)(n + u) * stride + c];
+    };
+    auto work = [&] (art_s (&v) [U], int n) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
-            for (int s = 0; s < S; ++s) v [u] = step_buffer_order (r [s], v [u]);
+            for (int s = 0; s < ACTIVE; ++s) v [u] = step_buffer_order (r [s], v [u]);
         }
+        if (STORE) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) out [(size_t)(n + u) * out_stride + c] = v [u];
+            for (int u = 0; u < U; ++u) out [(size_t)(n + u) * out_stride + c] = v [u];
+        }
+    };
+    int n = from;
+    const int batches = (to - from) / U;
+    if (batches > 0) {
+        art_s cur [U], nxt [U];
+        fetch (cur, n);
+        for (int b = 0; b < batches; ++b, n += U) {
+            const bool more = b + 1 < batches;
+            if (more) fetch (nxt, n + U);                  // in flight while this batch's dependent chain runs
+            work (cur, n);
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) cur [u] = nxt [u];
+            }
+        }
     }
     for (; n < to; ++n) {
         art_s v = in [(size_t) n * stride + c];
 #pragma unroll
-        for (int s = 0; s < S; ++s) v = step_buffer_order (r [s], v);
-        out [(size_t) n * out_stride + c] = v;
+        for (int s = 0; s < ACTIVE; ++s) v = step_buffer_order (r [s], v);
+        if (STORE) out [(size_t) n * out_stride + c] = v;
+    }
+}
+
+// the warm-up of a speculative chunk: W frames with section 0 alone, W more with sections 0-1, ... (section s joins (S - s) W
+// frames before the chunk's first frame, fed by sections that have already converged)
+template <int S, int J = 0>
+__device__ __forceinline__ void spec_warm_up (SectionRegs *r, const art_s *in, int stride, int c, int begin, int W)
+{
+    if constexpr (J < S) {
+        spec_run<S, J + 1, false> (r, in, stride, nullptr, 0, c, begin + J * W, begin + (J + 1) * W);
+        spec_warm_up<S, J + 1> (r, in, stride, c, begin, W);
     }
 }
 
@@ -202,72 +233,70 @@ void biquad_spec_kernel (const Biquad *sections, int C, int K, int L, int W, con
 
     const int begin = first - S * W;
     if (begin > 0) {
-        // speculative start: silence behind every section; section s joins (S - s) W frames before the chunk
+        // speculative start: silence behind every section
 #pragma unroll
         for (int s = 0; s < S; ++s)
 #pragma unroll
             for (int q = 0; q < 4; ++q) { r [s].x [q] = 0; r [s].y [q] = 0; }
-        for (int n = begin; n < first; ++n) {
-            art_s v = in [(size_t) n * stride + c];
-#pragma unroll
-            for (int s = 0; s < S; ++s)
-                if (n >= first - (S - s) * W) v = step_buffer_order (r [s], v);
-        }
+        spec_warm_up<S> (r, in, stride, c, begin, W);
     }
-    else if (first > 0) {
-        // close to the start of the call: run from the carried-in state through frames [0, first) — exact, nothing stored
-        for (int n = 0; n < first; ++n) {
-            art_s v = in [(size_t) n * stride + c];
-#pragma unroll
-            for (int s = 0; s < S; ++s) v = step_buffer_order (r [s], v);
-        }
-    }
+    else if (first > 0)
+        // close to the start of the call: from the carried-in state through frames [0, first) — exact, nothing stored
+        spec_run<S, S, false> (r, in, stride, nullptr, 0, c, 0, first);
 
     SpecState st [S];
     get_state<S> (st, r);
 #pragma unroll
     for (int s = 0; s < S; ++s) starts [((size_t) c * K + k) * S + s] = st [s];
 
-    spec_run<S> (r, in, stride, out, out_stride, c, first, last);
+    spec_run<S, S, true> (r, in, stride, out, out_stride, c, first, last);
 
     get_state<S> (st, r);
 #pragma unroll
     for (int s = 0; s < S; ++s) ends [((size_t) c * K + k) * S + s] = st [s];
 }
 
-// One workgroup per channel: every boundary checked in parallel; lane 0 repairs from the first mismatch (rare), then the
-// channel's final state goes back into `sections`.  repairs: running count of chunks recomputed (diagnostics).
+// Every chunk boundary checked, one thread each: flags [c][k] = chunk k did not start from the state chunk k-1 left;
+// first_bad [c] = the first such k of the channel (stays at its armed value, beyond any chunk count, when there is none).
 template <int S>
 __global__ __launch_bounds__ (256)
-void biquad_commit_kernel (Biquad *sections, int C, int K, int L, const art_s *in, int stride, art_s *out, int out_stride, int frames,
-                           const SpecState *starts, SpecState *ends, unsigned char *bad, unsigned int *repairs)
+void biquad_check_kernel (int C, int K, const SpecState *starts, const SpecState *ends, unsigned char *bad, int *first_bad)
 {
-    const int c = blockIdx.x, tid = threadIdx.x;
-    __shared__ int s_first_bad;
-    if (tid == 0) s_first_bad = K;
-    __syncthreads ();
+    const long t = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long) C * K) return;
+    const int c = (int)(t / K), k = (int)(t % K);
+    if (k == 0) return;
+    const bool ok = same_state<S> (starts + ((size_t) c * K + k) * S, ends + ((size_t) c * K + k - 1) * S);
+    bad [(size_t) c * K + k] = ok ? 0 : 1;
+    if (!ok) atomicMin (first_bad + c, k);
+}
+
+// One thread per channel: repairs from the first mismatch (rare: recomputes from the exact state until it rejoins a
+// speculative trajectory — in the worst case everything, serially), then the channel's final state goes back into
+// `sections`.  repairs: running count of chunks recomputed (diagnostics).  first_bad is re-armed for the next call.
+template <int S>
+__global__ __launch_bounds__ (64)
+void biquad_commit_kernel (Biquad *sections, int C, int K, int L, const art_s *in, int stride, art_s *out, int out_stride, int frames,
+                           const SpecState *starts, SpecState *ends, const unsigned char *bad, int *first_bad, unsigned int *repairs)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
     const SpecState *st = starts + (size_t) c * K * S;
     SpecState *en = ends + (size_t) c * K * S;
-    unsigned char *flags = bad + (size_t) c * K;
-    for (int k = 1 + tid; k < K; k += blockDim.x) {
-        const bool ok = same_state<S> (st + (size_t) k * S, en + (size_t)(k - 1) * S);
-        flags [k] = ok ? 0 : 1;
-        if (!ok) atomicMin (&s_first_bad, k);
-    }
-    __syncthreads ();
-    if (tid != 0) return;
+    const unsigned char *flags = bad + (size_t) c * K;
 
     SectionRegs r [S];
 #pragma unroll
     for (int s = 0; s < S; ++s) load_section (r [s], sections [(size_t) c * S + s]);
 
-    int k = s_first_bad;
+    int k = first_bad [c];
+    first_bad [c] = INT_MAX;
     unsigned int redone = 0;
     while (k < K) {
         // chunk k again, from the exact state its predecessor left
         put_state<S> (r, en + (size_t)(k - 1) * S);
         const int first = k * L, last = min (first + L, frames);
-        spec_run<S> (r, in, stride, out, out_stride, c, first, last);
+        spec_run<S, S, true> (r, in, stride, out, out_stride, c, first, last);
         SpecState now [S];
         get_state<S> (now, r);
 #pragma unroll
@@ -407,163 +436,6 @@ void biquad_chain_lds_kernel (Biquad *sections, int C, int S, art_s *buf, int fr
     }
 }
 
-
-// ---- order-2 cascade, hand-scheduled -------------------------------------------------------------
-// Section math (buffer form, reference biquad.c:140-142), un-fused, left to right:
-//     y = ((((x*a0) + (x1*a1)) - (b1*y1)) + (x2*a2)) - (b2*y2)
-// Only b1*y1 and the three adds after it depend on the previous output, so everything else is issued
-// ahead; with two sections the second runs one sample behind the first in the same lane, which gives the
-// scheduler two independent dependency chains to interleave.
-struct Sec2 { art_s a0, a1, a2, b1, b2, x1, x2, y1, y2; };
-
-__device__ __forceinline__ art_s sec2_step (Sec2 &s, art_s x)
-{
-    const art_s p0 = x * s.a0, p1 = s.x1 * s.a1, p3 = s.x2 * s.a2, p4 = s.b2 * s.y2;
-    const art_s u = p0 + p1;
-    const art_s m = s.b1 * s.y1;
-    const art_s t2 = u - m;
-    const art_s t3 = t2 + p3;
-    const art_s y = t3 - p4;
-    s.x2 = s.x1; s.x1 = x; s.y2 = s.y1; s.y1 = y;
-    return y;
-}
-
-__device__ __forceinline__ void sec2_load (Sec2 &s, const Biquad &f)
-{
-    const int i = f.index;
-    s.a0 = f.a [0]; s.a1 = f.a [1]; s.a2 = f.a [2]; s.b1 = f.b [1]; s.b2 = f.b [2];
-    s.x1 = f.x [i & 3]; s.x2 = f.x [(i - 1) & 3]; s.y1 = f.y [i & 3]; s.y2 = f.y [(i - 1) & 3];
-}
-
-// x[] / y[] hold the four most recent values; only two are live in an order-2 section, the other two
-// slots must end up holding what the reference's circular buffer would hold (the 3rd/4th most recent)
-__device__ __forceinline__ void sec2_store (Biquad &f, const Sec2 &s, art_s x3, art_s x4, art_s y3, art_s y4, int steps)
-{
-    const int i = f.index + steps;
-    f.x [i & 3] = s.x1; f.x [(i - 1) & 3] = s.x2; f.x [(i - 2) & 3] = x3; f.x [(i - 3) & 3] = x4;
-    f.y [i & 3] = s.y1; f.y [(i - 1) & 3] = s.y2; f.y [(i - 2) & 3] = y3; f.y [(i - 3) & 3] = y4;
-    f.index = i;
-}
-
-template <int S>                                   // S = 1 or 2 order-2 sections per channel
-__global__ __launch_bounds__ (ST_THREADS)
-void biquad_order2_lds_kernel (Biquad *sections, int C, art_s *buf, int frames)
-{
-    __shared__ __attribute__ ((aligned (16))) art_s tile [ST_CHUNK_FLOATS];
-    const int tid = threadIdx.x;
-    const int c0 = blockIdx.x * 64, Cg = min (64, C - c0);
-    const int chunk_frames = (ST_CHUNK_FLOATS - 64) / Cg;          // last 64 floats: cross-chunk hand-over slot
-
-    Sec2 s1, s2;
-    // the 3rd/4th most recent inputs/outputs of each section (kept only to write the state back faithfully)
-    art_s x3a = 0, x4a = 0, y3a = 0, y4a = 0, x3b = 0, x4b = 0, y3b = 0, y4b = 0;
-    art_s carry = 0.0f;                            // output of section 1 waiting for section 2 (skew of one sample)
-    if (tid < Cg) {
-        const Biquad &f1 = sections [(size_t)(c0 + tid) * S];
-        sec2_load (s1, f1);
-        x3a = f1.x [(f1.index - 2) & 3]; x4a = f1.x [(f1.index - 3) & 3]; y3a = f1.y [(f1.index - 2) & 3]; y4a = f1.y [(f1.index - 3) & 3];
-        if (S == 2) {
-            const Biquad &f2 = sections [(size_t)(c0 + tid) * S + 1];
-            sec2_load (s2, f2);
-            x3b = f2.x [(f2.index - 2) & 3]; x4b = f2.x [(f2.index - 3) & 3]; y3b = f2.y [(f2.index - 2) & 3]; y4b = f2.y [(f2.index - 3) & 3];
-        }
-    }
-
-    bool primed = false;                           // carry holds a valid section-1 output
-    for (int f0 = 0; f0 < frames; f0 += chunk_frames) {
-        const int nf = min (chunk_frames, frames - f0);
-        for (int e = tid; e < nf * Cg; e += ST_THREADS) {
-            const int f = e / Cg, c = e - f * Cg;
-            tile [e] = buf [(size_t)(f0 + f) * C + c0 + c];
-        }
-        __syncthreads ();
-        if (tid < Cg) {
-            // register blocks of 8 samples: the LDS reads of a block are issued together, ahead of the
-            // recurrence, and its writes after it, so LDS latency is off the loop-carried path
-            constexpr int UB = 8;
-            art_s *p = tile + tid;
-            int f = 0;
-
-            // one step of the cascade.  S == 1: returns the finished sample.  S == 2: pushes x into section 1
-            // and returns the finished PREVIOUS sample (section 2 of the value carried from the last step).
-            // `mid_out` receives section 1's output (needed only for the history bookkeeping below).
-            auto advance = [&] (art_s x, art_s &mid_out) -> art_s {
-                const art_s mid = sec2_step (s1, x);
-                mid_out = mid;
-                if (S == 1) return mid;
-                const art_s done = sec2_step (s2, carry);
-                carry = mid;
-                return done;
-            };
-            // The state written back at the end holds the FOUR most recent inputs/outputs of each section while the
-            // recurrence only needs two; the 3rd/4th most recent are refreshed once per register block (or per
-            // sample in the short remainder loops) instead of being shifted along with every sample.
-            auto track1 = [&] (art_s x3, art_s x4, art_s y3, art_s y4) { x3a = x3; x4a = x4; y3a = y3; y4a = y4; };
-            auto track2 = [&] (art_s x3, art_s x4, art_s y3, art_s y4) { x3b = x3; x4b = x4; y3b = y3; y4b = y4; };
-
-            if (S == 2 && !primed) {               // very first sample of the call: section 1 only
-                x4a = x3a; x3a = s1.x2; y4a = y3a; y3a = s1.y2;
-                carry = sec2_step (s1, *p);
-                primed = true; f = 1; p += Cg;
-            }
-            for (; f + UB <= nf; f += UB, p += UB * Cg) {
-                art_s x [UB], y [UB], mid [UB];
-                const art_s carry_in = carry, s2y1 = s2.y1, s2y2 = s2.y2, s2x1 = s2.x1, s2x2 = s2.x2;
-#pragma unroll
-                for (int u = 0; u < UB; ++u) x [u] = p [u * Cg];
-#pragma unroll
-                for (int u = 0; u < UB; ++u) y [u] = advance (x [u], mid [u]);
-                // section 1 consumed x[0..7] and produced mid[0..7]: its 3rd/4th most recent are x[5],x[4] / mid[5],mid[4]
-                track1 (x [UB - 3], x [UB - 4], mid [UB - 3], mid [UB - 4]);
-                if (S == 1) {
-#pragma unroll
-                    for (int u = 0; u < UB; ++u) p [u * Cg] = y [u];
-                }
-                else {
-                    // section 2 consumed carry_in, mid[0..6] and produced y[0..7] (sample f+u-1)
-                    track2 (mid [UB - 4], mid [UB - 5], y [UB - 3], y [UB - 4]);
-                    (void) carry_in; (void) s2y1; (void) s2y2; (void) s2x1; (void) s2x2;
-                    if (f > 0) p [-Cg] = y [0]; else tile [ST_CHUNK_FLOATS - 64 + tid] = y [0];
-#pragma unroll
-                    for (int u = 1; u < UB; ++u) p [(u - 1) * Cg] = y [u];
-                }
-            }
-            for (; f < nf; ++f, p += Cg) {         // remainder, one sample at a time (per-sample bookkeeping)
-                art_s mid;
-                x4a = x3a; x3a = s1.x2; y4a = y3a; y3a = s1.y2;
-                if (S == 2) { x4b = x3b; x3b = s2.x2; y4b = y3b; y3b = s2.y2; }
-                const art_s done = advance (*p, mid);
-                if (S == 1) *p = done;
-                else if (f > 0) p [-Cg] = done;
-                else tile [ST_CHUNK_FLOATS - 64 + tid] = done;
-            }
-        }
-        __syncthreads ();
-        // write back: frames [f0-1 (if any), f0+nf-1) are final; the last frame of the chunk still waits in `carry`
-        if (S == 2) {
-            if (f0 > 0 && tid < Cg) buf [(size_t)(f0 - 1) * C + c0 + tid] = tile [ST_CHUNK_FLOATS - 64 + tid];
-            for (int e = tid; e < (nf - 1) * Cg; e += ST_THREADS) {
-                const int f = e / Cg, c = e - f * Cg;
-                buf [(size_t)(f0 + f) * C + c0 + c] = tile [e];
-            }
-        }
-        else
-            for (int e = tid; e < nf * Cg; e += ST_THREADS) {
-                const int f = e / Cg, c = e - f * Cg;
-                buf [(size_t)(f0 + f) * C + c0 + c] = tile [e];
-            }
-        __syncthreads ();
-    }
-
-    if (tid < Cg) {
-        if (S == 2 && primed) {                    // drain: the last sample through section 2
-            x4b = x3b; x3b = s2.x2; y4b = y3b; y3b = s2.y2;
-            buf [(size_t)(frames - 1) * C + c0 + tid] = sec2_step (s2, carry);
-        }
-        sec2_store (sections [(size_t)(c0 + tid) * S], s1, x3a, x4a, y3a, y4a, frames);
-        if (S == 2) sec2_store (sections [(size_t)(c0 + tid) * S + 1], s2, x3b, x4b, y3b, y4b, frames);
-    }
-}
 
 // ---- order-2 cascade, feed-forward split + section pipeline -----------------------------------------
 // A lone wave issues one instruction every ~4 cycles whatever the number of active lanes, so with 8 channels
@@ -1229,8 +1101,14 @@ size_t arthip_biquad_spec_scratch (int C, int S, int frames, int L)
     return (size_t) C * K * S * sizeof (SpecState) * 2 + (((size_t) C * K + 255) & ~(size_t) 255);
 }
 
+// d_first_bad: C ints of device memory that hold a value beyond any chunk count between calls (armed once, here)
+int arthip_biquad_spec_arm (int *d_first_bad, int C, void *stream)
+{
+    return hipMemsetAsync (d_first_bad, 0x7f, sizeof (int) * (size_t) C, (hipStream_t) stream) == hipSuccess ? 0 : -1;     // 0x7f7f7f7f
+}
+
 int arthip_biquad_spec (Biquad *d_sections, int C, int S, const art_s *d_in, int in_stride, art_s *d_out, int out_stride, int frames,
-                        int L, int W, void *d_states, unsigned int *d_repairs, void *stream)
+                        int L, int W, void *d_states, int *d_first_bad, unsigned int *d_repairs, void *stream)
 {
     if (frames <= 0) return 0;
     if (S < 1 || S > MAX_CHAIN || L < 1) return -1;
@@ -1242,8 +1120,9 @@ int arthip_biquad_spec (Biquad *d_sections, int C, int S, const art_s *d_in, int
     hipStream_t st = (hipStream_t) stream;
 #define SPEC_GO(SS) do { \
         hipLaunchKernelGGL (biquad_spec_kernel<SS>, grid, block, 0, st, (const Biquad *) d_sections, C, K, L, W, d_in, in_stride, d_out, out_stride, frames, starts, ends); \
-        hipLaunchKernelGGL (biquad_commit_kernel<SS>, dim3 (C), block, 0, st, d_sections, C, K, L, d_in, in_stride, d_out, out_stride, frames, \
-                            (const SpecState *) starts, ends, bad, d_repairs); } while (0)
+        hipLaunchKernelGGL (biquad_check_kernel<SS>, grid, block, 0, st, C, K, (const SpecState *) starts, (const SpecState *) ends, bad, d_first_bad); \
+        hipLaunchKernelGGL (biquad_commit_kernel<SS>, dim3 ((C + 63) / 64), dim3 (64), 0, st, d_sections, C, K, L, d_in, in_stride, d_out, out_stride, frames, \
+                            (const SpecState *) starts, ends, (const unsigned char *) bad, d_first_bad, d_repairs); } while (0)
     switch (S) { case 1: SPEC_GO (1); break; case 2: SPEC_GO (2); break; case 3: SPEC_GO (3); break; default: SPEC_GO (4); }
 #undef SPEC_GO
     return hipGetLastError () == hipSuccess ? 0 : -1;
@@ -1252,11 +1131,7 @@ int arthip_biquad_spec (Biquad *d_sections, int C, int S, const art_s *d_in, int
 int arthip_biquad_order2 (Biquad *d_sections, int C, int S, art_s *d_buf, int frames, int stride, void *stream)
 {
     if (frames <= 0) return 0;
-    static const bool legacy_env = getenv ("ARTAMD_BIQUAD_LEGACY") != nullptr;
-    const bool legacy = legacy_env && stride == C;       // ablation: the single-lane-does-everything form
-    if (legacy && S == 1) hipLaunchKernelGGL (biquad_order2_lds_kernel<1>, dim3 ((C + 63) / 64), dim3 (ST_THREADS), 0, (hipStream_t) stream, d_sections, C, d_buf, frames);
-    else if (legacy && S == 2) hipLaunchKernelGGL (biquad_order2_lds_kernel<2>, dim3 ((C + 63) / 64), dim3 (ST_THREADS), 0, (hipStream_t) stream, d_sections, C, d_buf, frames);
-    else if (S == 1 || S == 2) {
+    if (S == 1 || S == 2) {
         const size_t lds = (size_t) 9 * FF_CAP * sizeof (art_s) + 256;           // 108 KiB of the CU's 160 (+ look-ahead slack)
         static bool once = false;
         if (!once) {
@@ -1316,10 +1191,9 @@ int arthip_decimate (const ArtDecArgs *a, const art_s *d_in, int frames, unsigne
                          if (a->dither_on) hipLaunchKernelGGL (kd, grid, block, pipe_lds, st, *a, d_in, frames, d_out, cpw); \
                          else hipLaunchKernelGGL (kn, grid, block, pipe_lds, st, *a, d_in, frames, d_out, cpw); } while (0)
         const size_t pipe_lds = (size_t) 5 * DEC_CHUNK * sizeof (art_s);
-        static const bool unpipelined = getenv ("ARTAMD_DECIMATE_LEGACY") != nullptr;           // ablation
         // with more workgroups than CUs the chip is busy anyway and the smaller LDS footprint of the unpipelined form
         // (more workgroups per CU) wins: 4,096 channels 49 vs 36 Gsamples/s
-        if (order >= 1 && !unpipelined && grid.x <= 256) {
+        if (order >= 1 && grid.x <= 256) {
             switch (order) { case 1: DEC_PIPE (1); break; case 2: DEC_PIPE (2); break; case 3: DEC_PIPE (3); break; default: DEC_PIPE (4); }
             return hipGetLastError () == hipSuccess ? 0 : -1;
         }

@@ -138,3 +138,24 @@ def test_host_api_strided_calls_use_the_parallel_form():
         for s in range(2):
             assert bytes(filt[k][s])[:80] == bytes(ofilt[k][s])[:80]
     print("chunks recomputed (host calls):", L.artamdBiquadRepairs() - before)
+
+
+@pytest.mark.parametrize("warmup", ["2", "20"])
+def test_verification_and_repair_when_the_speculation_fails(monkeypatch, warmup):
+    """ARTAMD_BIQUAD_WARMUP forces a warm-up far too short for the filters: nearly every chunk starts from a state that has not
+    converged, the boundary check catches each one and the chunks are recomputed from the exact state — same bits, many repairs"""
+    monkeypatch.setenv("ARTAMD_BIQUAD_WARMUP", warmup)
+    sets = {1: dict(a0=0.2, a1=0.15, b1=-0.5), 2: dict(a0=0.2, a1=0.15, a2=0.1, b1=-0.5, b2=0.2),
+            3: dict(a0=0.2, a1=0.15, a2=0.1, a3=-0.05, b1=-0.5, b2=0.2, b3=-0.1),
+            4: dict(a0=0.2, a1=0.15, a2=0.1, a3=-0.05, a4=0.02, b1=-0.5, b2=0.2, b3=-0.1, b4=0.03)}
+    frames, ch = 40000, 6
+    total = 0
+    for nsec in (1, 2, 3, 4):
+        x, _ = noise(frames * ch, state=(0x51DE + nsec) | 1)
+        x = x.reshape(frames, ch)
+        designs = [[(A.BiquadCoefficients(**sets[1 + (k + s) % 4]), OCoeffs(**sets[1 + (k + s) % 4]), 0.8) for s in range(nsec)] for k in range(ch)]
+        total += _run_bank(x, designs, [15000, 25000])
+    d = _design("lp", 44100 * 0.45 / 96000)
+    x, _ = noise(200000 * 8)
+    total += _run_bank(x.reshape(200000, 8), [[d, d]] * 8, [200000])
+    assert total > 1000, total
