@@ -31,10 +31,15 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
     const int sub = lane / G, l = lane % G;       // output within the wave, lane within the output's group
     const int ch0 = by * CG;
     const int half = a.T / 2;
-    // Blocks [0, workers) evaluate one tile of outputs each; any
+    // Blocks [0, 8 * per_xcd) evaluate one tile of outputs each, XCD-aware: workgroup b is dispatched to XCD b % 8, consecutive
+    // tiles stage overlapping input spans (a tile's span is T + ~30 frames, its neighbour's starts ~30 frames later), so
+    // XCD x takes the CONTIGUOUS tiles [x * per_xcd, (x + 1) * per_xcd): its L2 then sees one eighth of the call's input
+    // instead of all of it (measured with round-robin tiles: 4.5x the algorithmic bytes from the fabric on the headline shape,
+    // 8.7x on the 65,536-frame stereo ASRC call).  Placement only affects speed.  Any
     // further blocks (x only, y == 0) roll the history for the next call (reads hist ++ in, writes the OTHER history
     // buffer: independent of everything else in flight) — one launch less per call.
-    const unsigned int workers = (a.n_end - a.n_begin + (unsigned int) tile - 1) / (unsigned int) tile;
+    const unsigned int tiles_total = (a.n_end - a.n_begin + (unsigned int) tile - 1) / (unsigned int) tile;
+    const unsigned int per_xcd = (tiles_total + 7u) / 8u, workers = 8u * per_xcd;
     if (bx >= workers) {
         if (by) return;
         const int e = (int)(bx - workers) * GEN_THREADS + tid;
@@ -48,7 +53,9 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
         return;
     }
   {
-    const unsigned int n0 = a.n_begin + bx * (unsigned int) tile;
+    const unsigned int tile_index = (bx & 7u) * per_xcd + (bx >> 3);
+    if (tile_index >= tiles_total) return;
+    const unsigned int n0 = a.n_begin + tile_index * (unsigned int) tile;
     const int cnt = (int) min ((unsigned int) tile, a.n_end - n0);
 
     __syncthreads ();
@@ -291,7 +298,7 @@ bool general_geometry (const ArtFirArgs &a, int *tile_out, size_t *lds_out, dim3
     const unsigned int total = a.n_end - a.n_begin;
     const unsigned int roll_blocks = a.roll_dst ? (unsigned int)((a.H * a.C + GEN_THREADS - 1) / GEN_THREADS) : 0u;
     *tile_out = tile; *lds_out = lds;
-    *grid_out = dim3 ((total + tile - 1) / tile + roll_blocks, (a.C + CG - 1) / CG);
+    *grid_out = dim3 (8u * (((total + tile - 1) / tile + 7u) / 8u) + roll_blocks, (a.C + CG - 1) / CG);      // (tiles rounded up to the 8 XCDs)
     return true;
 }
 
