@@ -356,12 +356,18 @@ void biquadBankFree (BiquadBank *b)
 
 struct artamd_decimator {
     void *stream;
+    /* the state the kernels carry — clip counter, error feedback, dither generators (two copies: the parallel kernel leaves
+     * the advanced state in the other one), noise shapers — lives in ONE device block, so that a host-pointer call brings
+     * it back in the same launch as its output; the pointers below point into it */
+    unsigned char *d_state, *h_state; size_t state_bytes;          /* h_state: page-locked mirror */
     art_s *d_feedback; uint32_t *d_gens, *d_gens_alt; Biquad *d_shapers;
     unsigned long long *d_clipped;
     unsigned long long clipped_seen;
     art_s *d_in; size_t in_cap;
     unsigned char *d_out; size_t out_cap;
+    unsigned char *h_in, *h_out; size_t h_in_cap, h_out_cap;       /* page-locked staging of small host-pointer calls */
 };
+#define DEC_KERNEL_COPY_LIMIT ((size_t) 1 << 20)
 
 /* noise-shaping transfer function N(z) (a0 == 1) -> error-feedback filter H(z), reference decimator.c:389-409 */
 static void shaper_design (Biquad *f, double a1, double a2, double a3, double a4, double b1, double b2, double b3, double b4)
@@ -407,16 +413,30 @@ Decimate *decimateInit (int numChannels, int outputBits, int outputBytes, double
     struct artamd_decimator *hip = calloc (1, sizeof (*hip));
     const int C = numChannels;
 
+    if (!cxt || !hip) { free (cxt); free (hip); return NULL; }
     cxt->hip = hip;
     cxt->numChannels = C; cxt->outputBits = outputBits; cxt->outputBytes = outputBytes;
     cxt->outputGain = outputGain; cxt->flags = flags;
     cxt->feedback = calloc (C, sizeof (art_s));
-    hip->d_feedback = arthip_malloc (sizeof (art_s) * C);
-    hip->d_clipped = arthip_malloc (sizeof (unsigned long long));
-    arthip_zero (hip->d_feedback, sizeof (art_s) * C, NULL);
-    arthip_zero (hip->d_clipped, sizeof (unsigned long long), NULL);
+    {   /* layout of the state block (every part 16-byte aligned) */
+        size_t off = 16;                                                    /* [0] the clip counter */
+        const size_t o_fb = off;     off += (sizeof (art_s) * C + 15) & ~(size_t) 15;
+        const size_t o_g0 = off;     off += (sizeof (uint32_t) * C + 15) & ~(size_t) 15;
+        const size_t o_g1 = off;     off += (sizeof (uint32_t) * C + 15) & ~(size_t) 15;
+        const size_t o_sh = off;     off += (sizeof (Biquad) * C + 15) & ~(size_t) 15;
+        hip->state_bytes = off;
+        hip->d_state = arthip_malloc (off);
+        hip->h_state = arthip_host_alloc (off);
+        if (hip->d_state && hip->h_state) {
+            arthip_zero (hip->d_state, off, NULL);
+            hip->d_clipped = (unsigned long long *) hip->d_state;
+            hip->d_feedback = (art_s *)(hip->d_state + o_fb);
+            if (flags & DITHER_ENABLED) { hip->d_gens = (uint32_t *)(hip->d_state + o_g0); hip->d_gens_alt = (uint32_t *)(hip->d_state + o_g1); }
+            if (flags & SHAPING_ENABLED) hip->d_shapers = (Biquad *)(hip->d_state + o_sh);
+        }
+    }
 
-    if (flags & DITHER_ENABLED) {
+    if ((flags & DITHER_ENABLED) && hip->d_state) {
         /* per-channel seeds: little-endian words cut from the byte stream (state >> 24), three steps per byte */
         uint32_t s = 0x31415926;
         cxt->tpdf_generators = calloc (C, sizeof (uint32_t));
@@ -426,16 +446,13 @@ Decimate *decimateInit (int numChannels, int outputBits, int outputBytes, double
                 s = lcg_step (lcg_step (lcg_step (s)));
             }
         cxt->dither_type = (flags & DITHER_HIGHPASS) ? -1 : (flags & DITHER_LOWPASS) ? 1 : 0;
-        hip->d_gens = arthip_malloc (sizeof (uint32_t) * C);
-        hip->d_gens_alt = arthip_malloc (sizeof (uint32_t) * C);
         arthip_h2d (hip->d_gens, cxt->tpdf_generators, sizeof (uint32_t) * C, NULL);
     }
 
-    if (flags & SHAPING_ENABLED) {
+    if ((flags & SHAPING_ENABLED) && hip->d_state) {
         cxt->noise_shapers = calloc (C, sizeof (Biquad));
         for (int c = 0; c < C; ++c)
             shaper_for (cxt->noise_shapers + c, flags, sampleRate);
-        hip->d_shapers = arthip_malloc (sizeof (Biquad) * C);
         arthip_h2d (hip->d_shapers, cxt->noise_shapers, sizeof (Biquad) * C, NULL);
     }
 
@@ -454,8 +471,8 @@ void decimateFree (Decimate *cxt)
     struct artamd_decimator *hip = cxt->hip;
     if (hip) {
         arthip_sync (hip->stream);
-        arthip_free (hip->d_feedback); arthip_free (hip->d_gens); arthip_free (hip->d_gens_alt); arthip_free (hip->d_shapers);
-        arthip_free (hip->d_clipped); arthip_free (hip->d_in); arthip_free (hip->d_out);
+        arthip_free (hip->d_state); arthip_host_free (hip->h_state);
+        arthip_free (hip->d_in); arthip_free (hip->d_out); arthip_host_free (hip->h_in); arthip_host_free (hip->h_out);
         free (hip);
     }
     free (cxt->feedback); free (cxt->tpdf_generators); free (cxt->noise_shapers);
@@ -505,23 +522,42 @@ long decimateHipClipped (Decimate *cxt)
 static int dec_reserve (Decimate *cxt, size_t in_bytes, size_t out_bytes)
 {
     struct artamd_decimator *hip = cxt->hip;
+    in_bytes += 16; out_bytes += 16;                    /* (copy kernels move whole words) */
     if (in_bytes > hip->in_cap) { arthip_free (hip->d_in); hip->in_cap = in_bytes * 2; if (!(hip->d_in = arthip_malloc (hip->in_cap))) { hip->in_cap = 0; return -1; } }
     if (out_bytes > hip->out_cap) { arthip_free (hip->d_out); hip->out_cap = out_bytes * 2; if (!(hip->d_out = arthip_malloc (hip->out_cap))) { hip->out_cap = 0; return -1; } }
+    if (in_bytes <= DEC_KERNEL_COPY_LIMIT && in_bytes > hip->h_in_cap) {
+        arthip_host_free (hip->h_in); hip->h_in_cap = in_bytes * 2;
+        if (!(hip->h_in = arthip_host_alloc (hip->h_in_cap))) { hip->h_in_cap = 0; return -1; }
+    }
+    if (out_bytes <= DEC_KERNEL_COPY_LIMIT && out_bytes > hip->h_out_cap) {
+        arthip_host_free (hip->h_out); hip->h_out_cap = out_bytes * 2;
+        if (!(hip->h_out = arthip_host_alloc (hip->h_out_cap))) { hip->h_out_cap = 0; return -1; }
+    }
     return 0;
 }
 
-/* after a host-pointer call: return this call's clip count and refresh the host-visible state mirrors */
-static int dec_finish (Decimate *cxt)
+/* after a host-pointer call: bring back the output (out_bytes from d_out; NULL destination: the caller fetched it itself)
+ * together with the state block, return this call's clip count and refresh the host-visible state mirrors */
+static int dec_finish (Decimate *cxt, unsigned char *output, size_t out_bytes)
 {
     struct artamd_decimator *hip = cxt->hip;
     const int C = cxt->numChannels;
-    unsigned long long total = 0;
+    const int staged = output && out_bytes + 16 <= DEC_KERNEL_COPY_LIMIT;
 
-    arthip_d2h (&total, hip->d_clipped, sizeof (total), hip->stream);
-    arthip_d2h (cxt->feedback, hip->d_feedback, sizeof (art_s) * C, hip->stream);
-    if (cxt->tpdf_generators) arthip_d2h (cxt->tpdf_generators, hip->d_gens, sizeof (uint32_t) * C, hip->stream);
-    if (cxt->noise_shapers) arthip_d2h (cxt->noise_shapers, hip->d_shapers, sizeof (Biquad) * C, hip->stream);
-    arthip_sync (hip->stream);
+    if (staged)         /* output and state in ONE launch, no copy-engine command */
+        arthip_copy2_by_kernel (hip->h_out, hip->d_out, (out_bytes + 3) & ~(size_t) 3, hip->h_state, hip->d_state, hip->state_bytes, hip->stream);
+    else {
+        if (output) arthip_d2h (output, hip->d_out, out_bytes, hip->stream);
+        arthip_d2h (hip->h_state, hip->d_state, hip->state_bytes, hip->stream);
+    }
+    if (arthip_sync (hip->stream)) { fprintf (stderr, "artamd: decimator: %s\n", arthip_last_error ()); return 0; }
+    if (staged) memcpy (output, hip->h_out, out_bytes);
+
+    const unsigned char *m = hip->h_state;
+    const unsigned long long total = *(const unsigned long long *) m;
+    memcpy (cxt->feedback, m + ((unsigned char *) hip->d_feedback - hip->d_state), sizeof (art_s) * C);
+    if (cxt->tpdf_generators) memcpy (cxt->tpdf_generators, m + ((unsigned char *) hip->d_gens - hip->d_state), sizeof (uint32_t) * C);
+    if (cxt->noise_shapers) memcpy (cxt->noise_shapers, m + ((unsigned char *) hip->d_shapers - hip->d_state), sizeof (Biquad) * C);
 
     int delta = (int)(total - hip->clipped_seen);
     hip->clipped_seen = total;
@@ -532,18 +568,21 @@ int decimateProcessInterleavedLE (Decimate *cxt, const artsample_t *input, int n
 {
     struct artamd_decimator *hip = cxt->hip;
     if (numInputFrames <= 0) return 0;
-    const size_t samples = (size_t) numInputFrames * cxt->numChannels;
+    const size_t samples = (size_t) numInputFrames * cxt->numChannels, in_bytes = samples * sizeof (art_s);
     ArtDecArgs a;
 
-    if (dec_reserve (cxt, samples * sizeof (art_s), samples * cxt->outputBytes)) {
+    if (dec_reserve (cxt, in_bytes, samples * cxt->outputBytes)) {
         fprintf (stderr, "artamd: decimator device allocation failed: %s\n", arthip_last_error ());
         return 0;
     }
     dec_args (cxt, &a);
-    arthip_h2d (hip->d_in, input, samples * sizeof (art_s), hip->stream);
+    if (in_bytes + 16 <= DEC_KERNEL_COPY_LIMIT) {
+        memcpy (hip->h_in, input, in_bytes);
+        arthip_copy_by_kernel (hip->d_in, hip->h_in, in_bytes, hip->stream);
+    }
+    else arthip_h2d (hip->d_in, input, in_bytes, hip->stream);
     dec_swap_if (cxt, arthip_decimate (&a, hip->d_in, numInputFrames, hip->d_out, hip->stream));
-    arthip_d2h (output, hip->d_out, samples * cxt->outputBytes, hip->stream);
-    return dec_finish (cxt);
+    return dec_finish (cxt, output, samples * cxt->outputBytes);
 }
 
 int decimateProcessLE (Decimate *cxt, const artsample_t *const *input, int numInputFrames, unsigned char *const *output)
@@ -564,7 +603,7 @@ int decimateProcessLE (Decimate *cxt, const artsample_t *const *input, int numIn
     arthip_decimate_planar (&a, hip->d_in, (long) n, numInputFrames, hip->d_out, (long) plane_bytes, hip->stream);
     for (int c = 0; c < C; ++c)
         arthip_d2h (output [c], hip->d_out + plane_bytes * c, plane_bytes, hip->stream);
-    return dec_finish (cxt);
+    return dec_finish (cxt, NULL, 0);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -583,22 +622,50 @@ void floatIntegersLEDevice (const unsigned char *d_input, double inputGain, int 
     arthip_ingest (d_input, ingest_gain (inputGain, inputBits), inputBits, inputBytes, inputStride, d_output, numSamples, stream);
 }
 
+/* host-pointer form: process-wide scratch (device + page-locked), small calls by copy kernels */
+static struct { unsigned char *d_in, *h_in; art_s *d_out, *h_out; size_t in_cap, out_cap; int device; } ingest_scratch = { .device = -1 };
+static pthread_mutex_t ingest_lock = PTHREAD_MUTEX_INITIALIZER;
+
 void floatIntegersLE (unsigned char *input, double inputGain, int inputBits, int inputBytes, int inputStride, artsample_t *output, int numSamples)
 {
     if (numSamples <= 0 || inputBits > 24) return;
-    const size_t in_bytes = (size_t) numSamples * inputStride * inputBytes;
-    unsigned char *d_in = arthip_malloc (in_bytes);
-    art_s *d_out = arthip_malloc (sizeof (art_s) * (size_t) numSamples);
-
-    if (!d_in || !d_out) {
-        fprintf (stderr, "artamd: floatIntegersLE needs a HIP device (no CPU path): %s\n", arthip_last_error ());
-        abort ();
-    }
+    const size_t in_bytes = (size_t) numSamples * inputStride * inputBytes, out_bytes = sizeof (art_s) * (size_t) numSamples;
     /* the last sample's trailing stride bytes may not exist in the caller's buffer */
     const size_t valid = in_bytes - (size_t)(inputStride - 1) * inputBytes;
-    arthip_h2d (d_in, input, valid, NULL);
-    floatIntegersLEDevice (d_in, inputGain, inputBits, inputBytes, inputStride, d_out, numSamples, NULL);
-    arthip_d2h (output, d_out, sizeof (art_s) * (size_t) numSamples, NULL);
-    arthip_sync (NULL);
-    arthip_free (d_in); arthip_free (d_out);
+
+    pthread_mutex_lock (&ingest_lock);
+    const int device = arthip_current_device ();
+    if (ingest_scratch.device != device) {
+        arthip_free (ingest_scratch.d_in); arthip_free (ingest_scratch.d_out); arthip_host_free (ingest_scratch.h_in); arthip_host_free (ingest_scratch.h_out);
+        memset (&ingest_scratch, 0, sizeof (ingest_scratch));
+        ingest_scratch.device = device;
+    }
+    if (in_bytes + 16 > ingest_scratch.in_cap) {
+        arthip_free (ingest_scratch.d_in); arthip_host_free (ingest_scratch.h_in);
+        ingest_scratch.in_cap = (in_bytes + 16) * 2;
+        ingest_scratch.d_in = arthip_malloc (ingest_scratch.in_cap); ingest_scratch.h_in = arthip_host_alloc (ingest_scratch.in_cap);
+    }
+    if (out_bytes + 16 > ingest_scratch.out_cap) {
+        arthip_free (ingest_scratch.d_out); arthip_host_free (ingest_scratch.h_out);
+        ingest_scratch.out_cap = (out_bytes + 16) * 2;
+        ingest_scratch.d_out = arthip_malloc (ingest_scratch.out_cap); ingest_scratch.h_out = arthip_host_alloc (ingest_scratch.out_cap);
+    }
+    if (arthip_device_count () < 1 || !ingest_scratch.d_in || !ingest_scratch.d_out || !ingest_scratch.h_in || !ingest_scratch.h_out) {
+        /* no CPU evaluation path exists: say so and leave the caller's buffer untouched */
+        fprintf (stderr, "artamd: floatIntegersLE needs a HIP device and scratch memory (no CPU path): %s\n", arthip_last_error ());
+        ingest_scratch.in_cap = ingest_scratch.out_cap = 0;
+        pthread_mutex_unlock (&ingest_lock);
+        return;
+    }
+    const int small = in_bytes + out_bytes <= ((size_t) 1 << 20);
+    if (small) {
+        memcpy (ingest_scratch.h_in, input, valid);
+        arthip_copy_by_kernel (ingest_scratch.d_in, ingest_scratch.h_in, (valid + 3) & ~(size_t) 3, NULL);
+    }
+    else arthip_h2d (ingest_scratch.d_in, input, valid, NULL);
+    floatIntegersLEDevice (ingest_scratch.d_in, inputGain, inputBits, inputBytes, inputStride, ingest_scratch.d_out, numSamples, NULL);
+    if (small) arthip_copy_by_kernel (ingest_scratch.h_out, ingest_scratch.d_out, out_bytes, NULL);
+    else arthip_d2h (output, ingest_scratch.d_out, out_bytes, NULL);
+    if (!arthip_sync (NULL) && small) memcpy (output, ingest_scratch.h_out, out_bytes);
+    pthread_mutex_unlock (&ingest_lock);
 }
