@@ -90,6 +90,8 @@ def _write_wav(path, rate, channels, seconds, bits=16):
     ("-2 --tempo=1.25", 44100, 2),           # time stretch only (stretch.h from the library too: art_amd is art.c alone)
     ("-3 -r48000 --pitch=-300", 44100, 1),   # pitch shift: stretch, then resample by the inverse
     ("-2 --tempo=0.3 -o24", 44100, 2),       # below 0.5: the cascaded (dual) stretcher
+    ("-2 --duration=+0.4", 44100, 2),        # a target duration becomes a tempo ratio
+    ("-2 -r22050 -p --tempo=1.25", 44100, 2),    # stretch + downsampling pre-filter (which ART applies to a buffer it then does not use)
 ])
 def test_art_cli_on_hip_library_writes_the_same_file_as_reference_art(tmp_path, opts, rate_in, chans):
     src = str(tmp_path / "in.wav")
@@ -117,6 +119,8 @@ def test_art_cli_on_hip_library_writes_the_same_file_as_reference_art(tmp_path, 
     ("-2 --tempo=1.25", 44100, 2),       # device-resident time stretcher, no resampling
     ("-3 -r48000 --pitch=-300", 44100, 1),
     ("-2 --tempo=0.3 -o24", 44100, 2),   # cascaded stretcher
+    ("-2 --duration=+0.4", 44100, 2), ("-3 -r48000 --duration=1.2", 44100, 1), ("-2 --duration=0:01.0", 44100, 2),
+    ("-2 -r22050 -p --tempo=1.25", 44100, 2),    # ART's pre-filter is a no-op on the output when stretching: reproduced
 ])
 def test_device_resident_art_tool_writes_the_same_file_as_reference_art(tmp_path, opts, rate_in, chans):
     import sys

@@ -12,7 +12,7 @@ position advance and the output-length rule follow ART (art.c:717, 808-830, 849-
 ARTAMD_STRICT=1 the output file is byte-identical to the reference tool's (tests/test_gpu_dropin.py).
 
 usage: art_gpu.py [-1|-2|-3|-4] [-r<Hz>] [-g<dB>] [-l<Hz>] [-f<n>] [-t<n>] [-o<bits>] [-d<0|1|2>] [-n<0..3>]
-                  [-a] [-b] [-h] [-e] [-p] [-x] [-y] [-q] [--tempo=<ratio>] [--pitch=<cents>] in.wav out.wav
+                  [-a] [-b] [-h] [-e] [-p] [-x] [-y] [-q] [--tempo=<ratio>] [--pitch=<cents>] [--duration=<[+|-][[hh:]mm:]ss.ss>] in.wav out.wav
 
 --tempo / --pitch put the time stretcher (stretchProcessDevice, mono or stereo) between ingest and resampler, as ART does
 (art.c:769-797, 1002-1007).
@@ -75,6 +75,31 @@ def wav_header(bits, channels, frames, rate, mask):
         b"data" + struct.pack("<I", data_bytes)
 
 
+def parse_time_spec(text):
+    """--duration=[+|-][[hh:]mm:]ss.ss -> (relative sign or 0, seconds), None when malformed (reference art.c:395-428)"""
+    sign = 0
+    if text[:1] in "+-":
+        sign = 1 if text[0] == "+" else -1
+        text = text[1:]
+    value, colons = 0.0, 0
+    for i, part in enumerate(text.split(":")):
+        if i:
+            colons += 1
+            if colons == 3 or value != math.floor(value):
+                return None
+            value *= 60.0
+        if part == "":
+            continue
+        try:
+            field = float(part)
+        except ValueError:
+            return None
+        if field < 0.0 or (colons and field >= 60.0):
+            return None
+        value += field
+    return sign, value
+
+
 def main(argv):
     import torch
     import audio_resampler_amd as A
@@ -87,12 +112,17 @@ def main(argv):
     bh = hann = allpass = extended = prepost = overwrite = quiet = False
     extrapolate = True
     pitch_ratio = tempo_ratio = 1.0
+    duration = None
     files = []
     for arg in argv:
         if arg.startswith("--"):
             key, _, val = arg[2:].partition("=")
             if key.startswith("pitch"): pitch_ratio = 2.0 ** (float(val) / 1200.0)
             elif key.startswith("tempo"): tempo_ratio = float(val)
+            elif key.startswith("durat"):
+                duration = parse_time_spec(val)
+                if duration is None:
+                    raise SystemExit("invalid --duration parameter!")
             else: raise SystemExit(f"unknown option {arg} !")
         elif arg.startswith("-") and len(arg) > 1:
             o, v = arg[1], arg[2:]
@@ -131,6 +161,16 @@ def main(argv):
     out_bytes = (outbits + 7) // 8
     ratio = rate_out / rate_in
     stream = torch.cuda.current_stream().cuda_stream
+
+    # ---- a target duration, absolute or relative, becomes a tempo ratio (art.c:740-765)
+    if duration is not None:
+        if tempo_ratio != 1.0:
+            raise SystemExit("error: can't specify BOTH a tempo change and a target duration!")
+        source_seconds = frames_in / rate_in
+        target_seconds = source_seconds + duration[0] * duration[1] if duration[0] else duration[1]
+        if target_seconds <= 0.0:
+            raise SystemExit("error: invalid relative duration specified!")
+        tempo_ratio = source_seconds / target_seconds
 
     # ---- time stretcher (art.c:769-797): pitch is a stretch followed by resampling with the inverse ratio
     stretch_ratio, st, stretch_cap = 1.0, None, BLOCK
@@ -204,7 +244,9 @@ def main(argv):
             n = L.stretchProcessDevice(st, d_in.data_ptr(), n, d_st.data_ptr(), stretch_ratio) if n > 0 else \
                 L.stretchFlushDevice(st, d_st.data_ptr())
             src = d_st
-        if n > 0 and pre is not None:
+        # ART filters `inbuffer` here although, when stretching, the resampler reads the stretcher's own buffer (art.c:1009-1016
+        # against :1023): with a stretch the pre-filter has no effect on the output.  Reproduced: the file is the reference's.
+        if n > 0 and pre is not None and not st:
             pre.apply_device(src, n)
         if rs is not None:
             _, made = rs.process_device(src if n > 0 else None, n if n > 0 else -1, d_out, cap, ratio)
