@@ -74,6 +74,7 @@ int   arthip_copy2d (void *dst, size_t dpitch, const void *src, size_t spitch, s
 int   arthip_copy (void *dst, const void *src, size_t bytes, void *stream);                                                /* any direction */
 int   arthip_copy_by_kernel (void *dst, const void *src, size_t bytes, void *stream);   /* page-locked host <-> device, small sizes */
 int   arthip_copy2_by_kernel (void *dst, const void *src, size_t bytes, void *dst2, const void *src2, size_t bytes2, void *stream);
+int   arthip_slice_copy (void *dst, size_t dpitch_words, const void *src, size_t spitch_words, int width_words, size_t rows, void *stream);   /* strided rows of 4-byte words, by a kernel (device / peer memory) */
 void *arthip_host_alloc (size_t bytes);                    /* page-locked host memory */
 void  arthip_host_free (void *p);
 void *arthip_order_event_create (void);                    /* event without timing, for cross-stream ordering */

@@ -59,6 +59,17 @@ int arthip_d2d (void *d, const void *s, size_t n, void *st) { return n ? fail (h
 int arthip_zero (void *d, size_t n, void *st) { return n ? fail (hipMemsetAsync (d, 0, n, (hipStream_t) st), "memset") : 0; }
 int arthip_sync (void *st) { return fail (hipStreamSynchronize ((hipStream_t) st), "sync"); }
 
+// rows of `width` 4-byte words, row starts dpitch / spitch words apart: a channel slice of an interleaved stream, moved by the
+// GPU (the 2-D copy command is an order of magnitude slower on 16-byte rows); either side may live on a peer device
+__global__ void slice_words_kernel (unsigned int *dst, size_t dpitch, const unsigned int *src, size_t spitch, int width, size_t rows)
+{
+    const size_t total = rows * (size_t) width, stride = (size_t) gridDim.x * blockDim.x;
+    for (size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const size_t r = e / width; const int w = (int)(e - r * width);
+        dst [r * dpitch + w] = src [r * spitch + w];
+    }
+}
+
 // dst / src: one of them page-locked host memory (hipHostMalloc: mapped, same address on the device), both 16-byte aligned,
 // bytes a multiple of 4
 int arthip_copy_by_kernel (void *dst, const void *src, size_t bytes, void *st) { return arthip_copy2_by_kernel (dst, src, bytes, nullptr, nullptr, 0, st); }
@@ -75,6 +86,18 @@ int arthip_copy2_by_kernel (void *dst, const void *src, size_t bytes, void *dst2
                         (unsigned int *) dst + quads * 4, (const unsigned int *) src + quads * 4, tail,
                         (unsigned int *) dst2, (const unsigned int *) src2, (int)(bytes2 / 4));
     return fail (hipGetLastError (), "copy kernel");
+}
+
+// width_words 4-byte words per row, pitches in words
+int arthip_slice_copy (void *dst, size_t dpitch_words, const void *src, size_t spitch_words, int width_words, size_t rows, void *st)
+{
+    if (!rows || width_words <= 0) return 0;
+    const size_t total = rows * (size_t) width_words;
+    unsigned int blocks = (unsigned int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL (slice_words_kernel, dim3 (blocks), dim3 (256), 0, (hipStream_t) st, (unsigned int *) dst, dpitch_words,
+                        (const unsigned int *) src, spitch_words, width_words, rows);
+    return fail (hipGetLastError (), "slice kernel");
 }
 
 int arthip_set_device (int device) { return fail (hipSetDevice (device), "hipSetDevice"); }

@@ -1342,11 +1342,11 @@ static ResampleResult sharded_device_call (Resample *cxt, const art_s *d_in, lon
             sp->d_in = grow (sp->d_in, &sp->in_cap, sizeof (art_s) * (size_t) peek.input_used * width);
             sp->d_out = grow (sp->d_out, &sp->out_cap, sizeof (art_s) * (size_t) peek.output_generated * width);
             if ((peek.input_used && !sp->d_in) || (peek.output_generated && !sp->d_out)) { failed = 1; per_shard [k] = res; continue; }
+            const int wpw = (int)(sizeof (art_s) / 4);              /* 4-byte words per sample */
             if (peek.input_used && d_in)
-                arthip_copy2d (sp->d_in, sizeof (art_s) * width, d_in + first, sizeof (art_s) * C, sizeof (art_s) * width, peek.input_used, sp->stream);
+                arthip_slice_copy (sp->d_in, (size_t) width * wpw, d_in + first, (size_t) C * wpw, width * wpw, peek.input_used, sp->stream);
             per_shard [k] = enqueue_call (sh, sp->d_in, 0, nIn, sp->d_out, 0, cap, ratio);
-            arthip_copy2d (d_out + first, sizeof (art_s) * C, sp->d_out, sizeof (art_s) * width, sizeof (art_s) * width,
-                           per_shard [k].output_generated, sp->stream);
+            arthip_slice_copy (d_out + first, (size_t) C * wpw, sp->d_out, (size_t) width * wpw, width * wpw, per_shard [k].output_generated, sp->stream);
         }
         arthip_event_record (hip->ev_shard [k], sp->stream);
     }
@@ -1463,8 +1463,10 @@ static void host_begin (Resample *cxt, const art_s *input, int in_stride, const 
         else if (in_stride == C)
             memcpy (dst, input, sizeof (art_s) * in_samples);
         else
-            for (unsigned int f = 0; f < peek.input_used; ++f)
-                memcpy (dst + (size_t) f * C, input + (size_t) f * in_stride, sizeof (art_s) * C);
+            for (unsigned int f = 0; f < peek.input_used; ++f) {
+                const art_s *row = input + (size_t) f * in_stride;
+                for (int c = 0; c < C; ++c) dst [(size_t) f * C + c] = row [c];
+            }
         TRACE_MARK (1);
         if (sizeof (art_s) * in_samples <= KERNEL_COPY_LIMIT) arthip_copy_by_kernel (hip->d_in, hip->h_in, sizeof (art_s) * in_samples, hip->stream);
         else arthip_h2d (hip->d_in, hip->h_in, sizeof (art_s) * in_samples, hip->stream);
@@ -1484,15 +1486,19 @@ static void host_begin (Resample *cxt, const art_s *input, int in_stride, const 
     TRACE_MARK (2);
     /* small staged calls: the FIR kernels write their output straight into the page-locked buffer (it is mapped into the
      * device's address space; one launch and its dependency gap less than copying it out afterwards) */
-    const int direct_out = staged && sizeof (art_s) * out_samples <= KERNEL_COPY_LIMIT;
-    pend->res = enqueue_call (cxt, hip->d_in, 0, nIn, direct_out ? hip->h_out : hip->d_out, 0, cap, ratio);
+    const int direct_out = staged && sizeof (art_s) * out_samples <= KERNEL_COPY_LIMIT && !hip->nshards;
+    pend->res = hip->nshards ? sharded_device_call (cxt, hip->d_in, 0, nIn, hip->d_out, 0, cap, ratio)
+                             : enqueue_call (cxt, hip->d_in, 0, nIn, direct_out ? hip->h_out : hip->d_out, 0, cap, ratio);
     pend->failed = 0;
     TRACE_MARK (3);
 
     const unsigned int made = pend->res.output_generated;
     if (!made) return;
     if (staged) {
-        if (!direct_out) arthip_d2h (hip->h_out, hip->d_out, sizeof (art_s) * (size_t) made * C, hip->stream);
+        if (!direct_out) {
+            if (sizeof (art_s) * (size_t) made * C <= KERNEL_COPY_LIMIT) arthip_copy_by_kernel (hip->h_out, hip->d_out, sizeof (art_s) * (size_t) made * C, hip->stream);
+            else arthip_d2h (hip->h_out, hip->d_out, sizeof (art_s) * (size_t) made * C, hip->stream);
+        }
         pend->staged_out = 1;
     }
     else if (out_planes) {
@@ -1527,43 +1533,30 @@ static void host_end (Resample *cxt, art_s *output, int out_stride, art_s *const
     else if (out_stride == C)
         memcpy (output, src, sizeof (art_s) * (size_t) made * C);
     else
-        for (unsigned int f = 0; f < made; ++f)
-            memcpy (output + (size_t) f * out_stride, src + (size_t) f * C, sizeof (art_s) * C);
+        for (unsigned int f = 0; f < made; ++f) {
+            art_s *row = output + (size_t) f * out_stride;
+            for (int c = 0; c < C; ++c) row [c] = src [(size_t) f * C + c];
+        }
     TRACE_MARK (6);
 }
 
+/* A sharded context stages the WHOLE interleaved buffer on its own device exactly as an ordinary context does (one dense
+ * transfer each way at full PCIe rate) and hands it to the device-pointer path, whose shards pull and push their channel
+ * slices with slice kernels (peer-to-peer over xGMI when they sit on other GPUs).  (Tried first: every shard packing and
+ * uploading its own slice — the 2-D copy command moves 16-byte rows one by one (32 ch x 262,144 frames: 16 ms against 1.5 ms
+ * for the dense copy), and CPU packing reads the whole interleaved buffer once per shard.) */
 static ResampleResult host_call (Resample *cxt, const art_s *input, const art_s *const *planes, int nIn,
                                  art_s *output, art_s *const *out_planes, int cap, double ratio)
 {
     struct artamd_resampler *hip = cxt->hip;
     const int C = cxt->numChannels;
-    HostPending pend [MAX_DEVICES];
+    HostPending pend;
 
-    if (!hip->nshards) {
-        ENTER_DEVICE (hip);
-        host_begin (cxt, input, C, planes, nIn, output, C, out_planes, cap, ratio, &pend [0]);
-        host_end (cxt, output, C, out_planes, &pend [0]);
-        LEAVE_DEVICE (hip);
-        return pend [0].res;
-    }
-
-    const int prev = arthip_current_device ();
-    ResampleResult per_shard [MAX_DEVICES];
-
-    for (int k = 0; k < hip->nshards; ++k) {
-        const int first = hip->shard_first [k];
-        arthip_set_device (hip->shards [k]->hip->device);
-        host_begin (hip->shards [k], input ? input + first : NULL, C, planes ? planes + first : NULL, nIn,
-                    output ? output + first : NULL, C, out_planes ? out_planes + first : NULL, cap, ratio, &pend [k]);
-    }
-    for (int k = 0; k < hip->nshards; ++k) {
-        const int first = hip->shard_first [k];
-        arthip_set_device (hip->shards [k]->hip->device);
-        host_end (hip->shards [k], output ? output + first : NULL, C, out_planes ? out_planes + first : NULL, &pend [k]);
-        per_shard [k] = pend [k].res;
-    }
-    if (prev >= 0) arthip_set_device (prev);
-    return shards_agree (cxt, per_shard);
+    ENTER_DEVICE (hip);
+    host_begin (cxt, input, C, planes, nIn, output, C, out_planes, cap, ratio, &pend);
+    host_end (cxt, output, C, out_planes, &pend);
+    LEAVE_DEVICE (hip);
+    return pend.res;
 }
 
 ResampleResult resampleProcessInterleaved (Resample *cxt, const artsample_t *input, int numInputFrames, artsample_t *output, int numOutputFrames, double ratio)
