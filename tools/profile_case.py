@@ -1,5 +1,5 @@
 """One named workload, a few dozen launches, for rocprofv3 (kernel stats and --pmc passes): the kernels bench.py does not reach.
-Usage: python tools/profile_case.py CASE [steps]     CASE in: general_E general_P general_A wide biquad biquad_serial decimate strict
+Usage: python tools/profile_case.py CASE [steps]     CASE in: general_E general_P general_A matrix_B matrix_D4 matrix_D32 wide biquad biquad_serial decimate strict
 Prints one JSON line: what ran, samples per launch, algorithmic flop and bytes per sample (tools/roofline_report.py reads it)."""
 import ctypes as C, json, math, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -35,6 +35,15 @@ elif case == "general_P":      # BASELINE configs[0]: mono preset -1 (48 x 48) i
 elif case == "general_A":      # the headline shape on the general kernel
     step, rs = resampler_case(8, 988, 988, BH | IN, 1 << 20, kernel=1)
     info.update(kernel="fir_general_kernel", flop_per_sample=4 * 988 + 3, bytes_per_sample=4 * 44100 / 48000 + 4, peak="fp32")
+elif case == "matrix_B":       # BASELINE configs[1]: stereo preset -3 (380 x 380) interpolating, on the matrix cores (13 chunks: K = 416)
+    step, rs = resampler_case(2, 380, 380, BH | IN, 1 << 20)
+    info.update(kernel="fir_mfma_stream_kernel", flop_per_sample=2 * 416, bytes_per_sample=4 * 44100 / 48000 + 4, peak="fp32")
+elif case == "matrix_D4":      # BASELINE configs[3]: the 4-channel shard one GPU of 8 owns (988 x 988 interpolating)
+    step, rs = resampler_case(4, 988, 988, BH | IN, 1 << 20)
+    info.update(kernel="fir_mfma_stream_kernel", flop_per_sample=2 * 1024, bytes_per_sample=4 * 44100 / 48000 + 4, peak="fp32")
+elif case == "matrix_D32":     # BASELINE configs[3] on ONE GPU: all 32 channels
+    step, rs = resampler_case(32, 988, 988, BH | IN, 1 << 18)
+    info.update(kernel="fir_mfma_stream_kernel", flop_per_sample=2 * 1024, bytes_per_sample=4 * 44100 / 48000 + 4, peak="fp32")
 elif case == "strict":         # RESAMPLE_STRICT_ORDER: the parity instrument
     step, rs = resampler_case(8, 988, 988, BH | IN | A.RESAMPLE_STRICT_ORDER, 1 << 16)
     info.update(kernel="fir_strict_kernel", flop_per_sample=4 * 988 + 3, bytes_per_sample=4 * 44100 / 48000 + 4, peak="fp32")

@@ -77,7 +77,7 @@ pk, (pcalls, pavg, _) = find(st, "mfma_prepare")
 if pk: rows.append(("  (its prepare launch)", pk, pcalls, pavg, "-", "-", "-", None, None))
 
 # ---- the other kernels
-for case in ("general_E", "general_P", "general_A", "strict", "wide", "biquad", "biquad_serial", "decimate"):
+for case in ("matrix_B", "matrix_D4", "matrix_D32", "general_E", "general_P", "general_A", "strict", "wide", "biquad", "biquad_serial", "decimate"):
     p = os.path.join(src, f"case_{case}.json")
     if not os.path.exists(p): continue
     try: info = json.loads(open(p).read().strip().splitlines()[-1])
