@@ -893,10 +893,8 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
         // loads => wave-specialised kernel on 64-slot tiles; otherwise the generic instantiation on 32-slot tiles
         const bool small = (size_t) a->in_frames * a->C * 4 < 0xffff0000ull && ((uintptr_t) a->in % 16) == 0 && ((uintptr_t) a->hist % 16) == 0;
         const int cgt = (small && (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32)) ? a->C : 0;
-        const bool ws = kernel_pref != 3 && cgt != 0;         // kernel_pref 3 = the non-specialised variant (ablation)
-        // 64-slot tiles (two m-tiles per X tile) are correct but currently lose: 156 VGPRs => one workgroup per CU
-        // (measured 29 vs 36 Gsamples/s); kept selectable (kernel_pref 4) for tuning
-        const bool wide = ws && kernel_pref == 4;
+        const bool ws = cgt != 0;                             // (generic channel counts: the non-specialised instantiation on the same tiles)
+        const bool wide = false;                              // (64-slot tiles, two m-tiles per X tile, lost: 156 VGPRs => one workgroup per CU, 29 vs 36 Gsamples/s in round 1; the template keeps the parameter, nothing instantiates it)
         g.tile_rows = wide ? 64 : 32;
         g.slot_tiles = (g.P + g.tile_rows - 1) / g.tile_rows;
         g.cg = a->C < 32 ? a->C : 32;
@@ -961,8 +959,7 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
             if (a->ev_stop) arthip_event_record (a->ev_stop, stream);
             return hipGetLastError () == hipSuccess ? (ART_KERNEL_MFMA | (a->roll_dst ? ART_FIR_ROLLED : 0)) : -1;
         }
-#define MF_GO(I, CGT) do { if (wide && CGT) hipLaunchKernelGGL ((fir_mfma_kernel<I, CGT, (CGT != 0), (CGT != 0 ? 2 : 1)>), grid, dim3 (2 * MF_THREADS), 0, st, *a, *segs, g); \
-                           else if (ws && CGT) hipLaunchKernelGGL ((fir_mfma_kernel<I, CGT, (CGT != 0), 1>), grid, dim3 (2 * MF_THREADS), 0, st, *a, *segs, g); \
+#define MF_GO(I, CGT) do { if (ws && CGT) hipLaunchKernelGGL ((fir_mfma_kernel<I, CGT, (CGT != 0), 1>), grid, dim3 (2 * MF_THREADS), 0, st, *a, *segs, g); \
                            else hipLaunchKernelGGL ((fir_mfma_kernel<I, CGT, false, 1>), grid, dim3 (MF_THREADS), 0, st, *a, *segs, g); } while (0)
         if (a->interpolate) switch (cgt) { case 32: MF_GO (true, 32); break; case 16: MF_GO (true, 16); break; case 8: MF_GO (true, 8); break; case 4: MF_GO (true, 4); break; case 2: MF_GO (true, 2); break;
                                             case 1: MF_GO (true, 1); break; default: MF_GO (true, 0); }

@@ -44,8 +44,9 @@ int resampleHipShardInfo (Resample *cxt, int shard, int *device, int *firstChann
  * scratch buffers are shared between calls); biquadBankSetStream, decimateHipSetStream and stretchHipSetStream do the same. */
 void resampleHipSetStream (Resample *cxt, void *hipStream);
 void resampleHipSynchronize (Resample *cxt);
-/* kernel selection for ablation/tests: 0 = automatic, 1 = general wave-per-output kernel,
- * 2 = MFMA periodic-phase kernel where applicable (falls back to 1 elsewhere) */
+/* kernel selection for tests and comparisons: 0 = automatic, 1 = general kernel, 2 = matrix-core path wherever the ratio is
+ * rational (the persistent streaming kernel for regular launches, the one-tile-per-workgroup kernel otherwise; falls back to
+ * 1 elsewhere), 5 = as 2 but always the one-tile-per-workgroup kernel (same bits as the streaming one) */
 void resampleHipSetKernel (Resample *cxt, int which);
 int  resampleHipLastKernel (Resample *cxt);          /* which kernel produced the bulk of the last call */
 unsigned int resampleHipLastHandedBack (Resample *cxt);   /* outputs the matrix-core kernels evaluated at their own exact position, off their slot's canonical pattern, so far */
