@@ -911,7 +911,11 @@ void decimate_pipe_kernel (ArtDecArgs a, const art_s *in, int frames, unsigned c
     __shared__ uint32_t s_gen [2][64];             // generator state at the start of a chunk, by chunk parity
     const int tid = threadIdx.x, wave = tid >> 6;
     const int c0 = blockIdx.x * cpw, Cg = min (cpw, a.C - c0);
-    const int chunk_frames = (DEC_CHUNK / Cg) & ~1;                       // even: chunk boundaries keep generator parity
+    // LDS tiles are CHANNEL-major, [channel][frame] with a pitch of chunk_frames + 4 (the serial lane then moves four frames per
+    // ds_read_b128 / ds_write_b128 instead of one per instruction — a lone wave's budget is instructions; the +4 keeps the
+    // channels' rows on different banks)
+    const int chunk_frames = ((DEC_CHUNK / Cg) - 4) & ~3;                 // multiple of 4 (vector alignment; even: chunk boundaries keep generator parity)
+    const int pitch = chunk_frames + 4;
     const int nchunks = (frames + chunk_frames - 1) / chunk_frames;
 
     art_s fb = 0.0f; SectionRegs sh; unsigned long long clips = 0;
@@ -937,7 +941,7 @@ void decimate_pipe_kernel (ArtDecArgs a, const art_s *in, int frames, unsigned c
                 art_s *tile = tiles + (k % 3) * DEC_CHUNK, *dth = dths + (k & 1) * DEC_CHUNK;
                 for (int e = ht; e < nf * Cg; e += HELPERS) {
                     const int f = e / Cg, c = e - f * Cg;
-                    tile [e] = in [(size_t)(f0 + f) * a.C + c0 + c] * scale;     // (the serial wave's first operation, done here: same product)
+                    tile [c * pitch + f] = in [(size_t)(f0 + f) * a.C + c0 + c] * scale;     // (the serial wave's first operation, done here: same product)
                 }
                 if (DITHER) {
                     const int segs_per_ch = (nf + DEC_SEG - 1) / DEC_SEG;
@@ -952,7 +956,7 @@ void decimate_pipe_kernel (ArtDecArgs a, const art_s *in, int frames, unsigned c
                             r = lcg (lcg (lcg (r)));
                             g = r;
                             const uint32_t u = (first >> 1) + (r >> 1);
-                            dth [(n0 + i) * Cg + c] = (art_s)(int)(u ^ 0x80000000u) * (art_s) 4.656612873077392578125e-10;
+                            dth [c * pitch + n0 + i] = (art_s)(int)(u ^ 0x80000000u) * (art_s) 4.656612873077392578125e-10;
                         }
                         if (n0 + cnt == nf) s_gen [(k & 1) ^ 1][c] = g;      // start state of chunk k+1
                     }
@@ -963,7 +967,7 @@ void decimate_pipe_kernel (ArtDecArgs a, const art_s *in, int frames, unsigned c
                 const art_s *tile = tiles + (k % 3) * DEC_CHUNK;
                 for (int e = ht; e < nf * Cg; e += HELPERS) {
                     const int f = e / Cg, c = e - f * Cg;
-                    int q = (int) tile [e];
+                    int q = (int) tile [c * pitch + f];
                     if (q > hi) { q = hi; clips++; }
                     else if (q < lo) { q = lo; clips++; }
                     const uint32_t v = ((uint32_t) q << shift) + bias;
@@ -987,18 +991,21 @@ void decimate_pipe_kernel (ArtDecArgs a, const art_s *in, int frames, unsigned c
                 fb = shaper_step<ORDER> (sh, err);
                 return qf;
             };
-            constexpr int UB = 8;
+            typedef art_s vec4 __attribute__ ((ext_vector_type (4)));
+            art_s *mine = tile + tid * pitch;
+            const art_s *my_dither = dth + tid * pitch;
             int f = 0;
-            for (; f + UB <= nf; f += UB) {
-                art_s x [UB], d [UB];
+            for (; f + 8 <= nf; f += 8) {
+                vec4 xa = *reinterpret_cast<const vec4 *> (mine + f), xb = *reinterpret_cast<const vec4 *> (mine + f + 4), da, db;
+                if (DITHER) { da = *reinterpret_cast<const vec4 *> (my_dither + f); db = *reinterpret_cast<const vec4 *> (my_dither + f + 4); }
+                else { da = (art_s) 0; db = (art_s) 0; }
 #pragma unroll
-                for (int u = 0; u < UB; ++u) { x [u] = tile [(f + u) * Cg + tid]; d [u] = DITHER ? dth [(f + u) * Cg + tid] : (art_s) 0; }
+                for (int u = 0; u < 4; ++u) xa [u] = one (xa [u], da [u]);
 #pragma unroll
-                for (int u = 0; u < UB; ++u) x [u] = one (x [u], d [u]);
-#pragma unroll
-                for (int u = 0; u < UB; ++u) tile [(f + u) * Cg + tid] = x [u];
+                for (int u = 0; u < 4; ++u) xb [u] = one (xb [u], db [u]);
+                *reinterpret_cast<vec4 *> (mine + f) = xa; *reinterpret_cast<vec4 *> (mine + f + 4) = xb;
             }
-            for (; f < nf; ++f) tile [f * Cg + tid] = one (tile [f * Cg + tid], DITHER ? dth [f * Cg + tid] : (art_s) 0);
+            for (; f < nf; ++f) mine [f] = one (mine [f], DITHER ? my_dither [f] : (art_s) 0);
         }
         // LDS-only barrier: the helpers' stores (and loads already consumed) stay in flight; nobody reads global memory
         // that this launch writes
