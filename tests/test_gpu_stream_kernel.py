@@ -81,3 +81,38 @@ def test_streaming_kernel_long_call_with_many_ring_epochs_matches_oracle():
     uo, go, yo = o.process(x[:400000], int(400000 * ratio) + 4000, ratio, threads=2)
     ok, worst, rms = tolerance_ok(outs[0][:go], yo)
     assert ok and rms < 2.0e-8, (worst, rms)
+
+
+def test_irregular_launches_take_the_replaying_kernel_and_match_the_oracle():
+    """launches the host-side regularity test rejects: (a) nearest-filter phases exactly on a half step (160/147 with 80 filters:
+    every other slot sits at x.5 filter steps, where the reference's own fp64 noise decides the rounding per output) and (b) a
+    call long enough for the position arithmetic's rounding to exceed the tolerance (4.7M frames x 988 filters).  Both must run
+    on the one-tile-per-workgroup kernel with its exact per-output replay — (a) against the oracle, every output's filter
+    choice included; (b) against the general kernel (both within the bar of the truth)."""
+    ratio = 48000 / 44100
+    ch, T, F, frames = 2, 380, 80, 150000
+    x, _ = noise(frames * ch, state=0xBADC0FFEE | 1)
+    x = x.reshape(frames, ch)
+    r = HipResampler(ch, T, F, 0.0, BH, kernel=2)
+    o = OracleResampler(ch, T, F, 0.0, BH | PRECISE)
+    for b in (r, o):
+        b.advance(T / 2)
+    cap = int(frames * ratio) + 4000
+    u, g, y = r.process(x, cap, ratio)
+    uo, go, yo = o.process(x, cap, ratio, threads=2)
+    assert (u, g) == (uo, go) and r.last_kernel() == 2
+    ok, worst, rms = tolerance_ok(y, yo)
+    assert ok, (worst, rms)
+
+    ch, T, frames = 1, 988, 4700000
+    x, _ = noise(frames * ch)
+    x = x.reshape(frames, ch)
+    outs = []
+    for kernel in (2, 1):
+        r = HipResampler(ch, T, T, 0.0, BH | INTERP, kernel=kernel)
+        r.advance(T / 2)
+        u, g, y = r.process(x, int(frames * ratio) + 4000, ratio)
+        assert u == frames and r.last_kernel() == kernel
+        outs.append(y)
+    d = np.abs(outs[0].astype(np.float64) - outs[1].astype(np.float64))
+    assert np.all(d <= 2.0 * 2.0 ** -23 * np.maximum(1.0, np.abs(outs[1]))), d.max()
