@@ -742,7 +742,7 @@ void resampleHipSetStream (Resample *cxt, void *stream)
     struct artamd_resampler *hip = cxt->hip;
     if (hip->stream == stream) return;
     ENTER_DEVICE (hip);
-    if (!hip->nshards) arthip_sync (hip->stream);
+    arthip_sync (hip->stream);          /* (a sharded context's own stream carries its staging copies and the shards' completion events) */
     if (hip->own_stream) { arthip_stream_destroy (hip->stream); hip->own_stream = 0; }
     hip->stream = stream;
     LEAVE_DEVICE (hip);
