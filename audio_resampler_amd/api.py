@@ -114,6 +114,7 @@ def _bind(width):
         "resampleHipSetKernel": (None, [RP, C.c_int]),
         "resampleHipLastKernel": (C.c_int, [RP]),
         "resampleHipLastHandedBack": (C.c_uint, [RP]),
+        "resampleHipLastFixedPoint": (C.c_int, [RP, C.POINTER(C.c_double)]),
         "resampleHipSetTiming": (None, [RP, C.c_int]),
         "resampleHipReadTiming": (C.c_double, [RP, C.POINTER(C.c_int)]),
         "resampleProcessInterleavedDevice": (ResampleResult, [RP, ptr, C.c_int, ptr, C.c_int, C.c_double]),
@@ -249,6 +250,13 @@ def _bind(width):
 
         def synchronize(self):
             self.L.resampleHipSynchronize(self.p)
+
+        def fixed_point(self):
+            """(state, pairs): state 0 = the last call's FIR was not the fixed-point matrix kernel, 1 = it was, 2 = it stood down
+            for the f32 kernel; pairs = digit-pair products per 32-tap chunk (9..13)"""
+            pairs = C.c_double(0.0)
+            state = self.L.resampleHipLastFixedPoint(self.p, C.byref(pairs))
+            return state, pairs.value
 
         def handed_back(self):
             return self.L.resampleHipLastHandedBack(self.p)

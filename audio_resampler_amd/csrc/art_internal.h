@@ -60,6 +60,11 @@ typedef struct {
     unsigned int fix_cap;
     /* device scratch for the MFMA path: per-launch effective rows + canonical slot positions */
     void *scratch; size_t scratch_bytes;
+    /* device memory for the fixed-point matrix kernel's digit planes of one launch (arthip_fir_planes_bytes; NULL: f32 kernels) */
+    void *planes; size_t planes_bytes;
+    /* host, optional, 3 ints filled when the fixed-point kernel is enqueued: the launch's flag value (the first word of
+     * `planes` equals it afterwards iff the kernel stood down), mask words behind the flag (at planes + 256), chunks per tile */
+    int *fixed_out;
     /* optional HIP events recorded immediately before/after the dominant kernel's launch (host side only) */
     void *ev_start, *ev_stop;
 } ArtFirArgs;
@@ -97,6 +102,8 @@ float arthip_event_elapsed_ms (void *start, void *stop);   /* synchronises on `s
 /* ---- sinc_fir.hip ---- */
 /* returns the kernel actually used (ART_KERNEL_*), <0 on launch failure */
 int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, void *stream);
+/* bytes a->planes must hold for the fixed-point matrix kernel to run a call of this shape (C, T, H, in_frames, period; 0: never) */
+size_t arthip_fir_planes_bytes (const ArtFirArgs *a);
 /* n independent general-kernel calls (default / precise mode) in one launch per kernel variant; d_table = device scratch of
  * n * arthip_fir_batch_item_bytes () bytes (reused call after call: stream order protects it); asynchronous like arthip_fir */
 size_t arthip_fir_batch_item_bytes (void);

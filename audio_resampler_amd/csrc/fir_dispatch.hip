@@ -5,6 +5,8 @@ extern "C" {
 
 int arthip_fir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref) { return artfir_takes_matrix_path (a, segs, kernel_pref) ? 1 : 0; }
 
+size_t arthip_fir_planes_bytes (const ArtFirArgs *a) { return artfir_planes_bytes (a); }
+
 int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, void *stream)
 {
     hipStream_t st = (hipStream_t) stream;

@@ -2,7 +2,7 @@
 // mfma_prepare_kernel (per-launch effective rows and canonical slot positions), fir_mfma_stream_kernel (persistent workgroups,
 // regular launches: the headline path), fir_mfma_kernel (one tile per workgroup with per-output position replay: every other
 // launch), their shared K walk, and the host-side rules that pick between them and the general kernel.
-#include "fir_common.hip.h"
+#include "fir_matrix_common.hip.h"
 
 #if !ART_WIDE          // the 8-byte sample build has its own matrix-core kernel (fir_matrix64.hip)
 
@@ -41,63 +41,6 @@ namespace {
 // the tile's row is used.  Anything else (ratio drift, ring-epoch seams) is evaluated in the epilogue by the lane that
 // owns the output, at its exact position (direct_sample) and counted (fix_count: diagnostics).
 // ---------------------------------------------------------------------------------------------------
-
-typedef float f32x16 __attribute__ ((ext_vector_type (16)));
-typedef float f32x4 __attribute__ ((ext_vector_type (4)));
-
-constexpr int MF_THREADS = 256;
-constexpr int MF_KC = 32;                 // k's per staged chunk
-constexpr int MF_LD = MF_KC + 4;          // LDS row pitch in floats (144 B: 16-B aligned, conflict-free b128)
-constexpr int MF_COLS = 128;              // columns per workgroup
-constexpr int MF_MAX_PPW = 64;            // periods per workgroup (C = 2)
-// A slot's phase may differ from its canonical value by this many filter steps and still use the tile's
-// effective row: adjacent rows differ by < 3e-3 per tap, so the row changes by < 6e-9 relative (a tenth of
-// half a float ulp).  The reference's own position arithmetic is quantised to ~1e-7 steps after 1M frames.
-constexpr double MF_PHASE_TOL = 2e-6;
-constexpr int MF_HEAD_PAD = 64;
-
-struct MfmaGeom {
-    int P, Q;                             // outputs / inputs per period
-    int tile_rows;                        // slots per workgroup tile: 32, or 64 (two MFMA m-tiles sharing one X tile)
-    int slot_tiles;                       // ceil (P / tile_rows)
-    int ppw;                              // periods per workgroup
-    int cg;                               // channels per column group
-    int ktot;                             // K columns, multiple of MF_KC
-    int period_groups;
-    int groups_per_xcd;                   // ceil (period_groups / 8)
-    int band_lo, band_hi;
-    // per-launch tables in device scratch (written by mfma_prepare_kernel)
-    float *eff;                           // [slot_tiles*tile_rows][ktot]  blended rows, shifted to the tile's K origin, zero padded
-    int *canon_ip, *canon_fi;             // [slot_tiles*tile_rows]        canonical position of each slot (period 0 of the launch)
-    double *canon_frac;                 // K columns [band_lo, band_hi) hold every row's central taps
-    // the head of the call as ONE contiguous array (history ++ first input frames, MF_HEAD_PAD zero frames in front): tiles that
-    // reach into the history stage from it exactly as all others stage from `in` (written by mfma_prepare_kernel)
-    float *head; int head_frames;
-    // per slot tile, 3 ints: [0] linear index of K column 0 in period 0 of the launch; [1] the tile's pass-through row (nearest-
-    // filter mode without a low-pass: the one slot per period whose position falls exactly on an input sample), -1 if none;
-    // [2] that sample's linear index in period 0 (streaming kernel)
-    int *tile_w0;
-};
-
-typedef unsigned int u32x4 __attribute__ ((ext_vector_type (4)));
-typedef unsigned int u32x2 __attribute__ ((ext_vector_type (2)));
-
-// raw buffer descriptor: the hardware range check returns 0 for any access past `bytes`, which is
-// exactly the zero padding the tile needs (beyond the valid input, before/after a filter row)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc (const void *base, unsigned int bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc (const_cast<void *> (base), 0, (int) bytes, 0x00020000);
-}
-
-template <int VEC> struct VecLoad;
-template <> struct VecLoad<1> { static __device__ __forceinline__ void load (float *dst, __amdgpu_buffer_rsrc_t r, unsigned int off) {
-    dst [0] = __uint_as_float (__builtin_amdgcn_raw_buffer_load_b32 (r, (int) off, 0, 0)); } };
-template <> struct VecLoad<2> { static __device__ __forceinline__ void load (float *dst, __amdgpu_buffer_rsrc_t r, unsigned int off) {
-    u32x2 v = __builtin_amdgcn_raw_buffer_load_b64 (r, (int) off, 0, 0);
-    dst [0] = __uint_as_float (v.x); dst [1] = __uint_as_float (v.y); } };
-template <> struct VecLoad<4> { static __device__ __forceinline__ void load (float *dst, __amdgpu_buffer_rsrc_t r, unsigned int off) {
-    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128 (r, (int) off, 0, 0);
-    dst [0] = __uint_as_float (v.x); dst [1] = __uint_as_float (v.y); dst [2] = __uint_as_float (v.z); dst [3] = __uint_as_float (v.w); } };
 
 // Grid (slot tile, row): canonical (ip, fi, frac) of the slot from the first period of the launch, and its
 // effective row g_i[k - shift_i] (lerp folded in, fp64, one rounding) laid out exactly as the main kernel
@@ -649,7 +592,7 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
 // instantiation: the extra loads of that epilogue cost the common ones a spilled register otherwise).
 template <bool INTERP, int CG, bool PASS>
 __global__ __launch_bounds__ (2 * MF_THREADS) __attribute__ ((amdgpu_waves_per_eu (6)))
-void fir_mfma_stream_kernel (ArtFirArgs a, MfmaGeom g, int wgs_per_xcd)
+void fir_mfma_stream_kernel (ArtFirArgs a, MfmaGeom g, int wgs_per_xcd, const int *gate, int gate_value)
 {
     constexpr int THREADS = 2 * MF_THREADS;
     constexpr int PPW = MF_COLS / CG > MF_MAX_PPW ? MF_MAX_PPW : MF_COLS / CG;
@@ -675,6 +618,9 @@ void fir_mfma_stream_kernel (ArtFirArgs a, MfmaGeom g, int wgs_per_xcd)
         }
         return;
     }
+
+    // enqueued behind the fixed-point kernel (fir_matrix_i8.hip): this launch only has work if that one stood down (uniform)
+    if (gate && *gate != gate_value) return;
 
     const int xcd = blockIdx.x & 7, rank = blockIdx.x >> 3;
     const int tiles_per_xcd = g.groups_per_xcd * g.slot_tiles;
@@ -870,6 +816,43 @@ bool artfir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int
                          (enough || kernel_pref >= ART_KERNEL_MFMA) && total >= (unsigned int) a->period_out;
 }
 
+// Tile geometry of a launch (everything but the tables in device scratch); returns the compile-time channel count of the
+// wave-specialised kernels, 0 for the generic instantiation.
+static int matrix_geometry (const ArtFirArgs *a, MfmaGeom &g)
+{
+    const unsigned int total = a->n_end - a->n_begin;
+    g.P = a->period_out; g.Q = a->period_in;
+    // compile-time channel count where the whole stream is one column group and the buffers allow vector loads
+    const bool small = (size_t) a->in_frames * a->C * 4 < 0xffff0000ull && ((uintptr_t) a->in % 16) == 0 && ((uintptr_t) a->hist % 16) == 0;
+    const int cgt = (small && (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32)) ? a->C : 0;
+    g.tile_rows = 32;
+    g.slot_tiles = (g.P + g.tile_rows - 1) / g.tile_rows;
+    g.cg = a->C < 32 ? a->C : 32;
+    g.ppw = MF_COLS / g.cg;
+    if (g.ppw > MF_MAX_PPW) g.ppw = MF_MAX_PPW;
+    // (+ 3: the fixed-point kernel starts a tile's K columns on a 4-frame block, up to 3 frames early)
+    const int shift_max = (int)((g.tile_rows - 1.0) * g.Q / g.P) + 2;
+    g.ktot = ((a->T + shift_max + 3 + MF_KC - 1) / MF_KC) * MF_KC;
+    g.band_lo = a->T / 2 - 1 - 6;                       // central taps of the first row ...
+    g.band_hi = a->T / 2 + shift_max + 6;               // ... to those of the last
+    const unsigned int periods = (total + g.P - 1) / g.P;
+    g.period_groups = (int)((periods + g.ppw - 1) / g.ppw);
+    g.groups_per_xcd = (g.period_groups + 7) / 8;
+    g.eff = nullptr; g.canon_ip = g.canon_fi = nullptr; g.canon_frac = nullptr; g.head = nullptr; g.head_frames = 0; g.tile_w0 = nullptr;
+    return cgt;
+}
+
+// bytes of digit planes the fixed-point kernel wants for a call of this shape (the host sizes a->planes with it before the launch)
+size_t artfir_planes_bytes (const ArtFirArgs *a)
+{
+    if (!a->period_out || a->mode != ART_MODE_FAST) return 0;
+    static const bool off = [] { const char *e = getenv ("ARTAMD_NO_FIXED"); return e && *e && *e != '0'; } ();
+    if (off) return 0;
+    MfmaGeom g;
+    const int cgt = matrix_geometry (a, g);
+    return cgt ? artfir_i8_bytes (a, g, cgt) : 0;
+}
+
 // Launch the matrix-core path for this call if it applies: returns ART_KERNEL_MFMA (| ART_FIR_ROLLED), -1 on a launch failure,
 // 0 when the call is for the general kernel.
 int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, void *stream)
@@ -883,30 +866,13 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
     //                                             also those at the history seam, stages through the same loop (was 14 + 1.4)
     // The MFMA path is taken when the general kernel would take longer than the floor.  For channel counts without a
     // compiled column group the older rule stays: outputs x channels x taps of at least 1.2e8.
-    const unsigned int total = a->n_end - a->n_begin;
     const bool mfma_ok = artfir_takes_matrix_path (a, segs, kernel_pref);
 
     if (mfma_ok) {
         MfmaGeom g;
-        g.P = a->period_out; g.Q = a->period_in;
-        // compile-time channel count where the whole stream is one column group and the buffers allow vector
-        // loads => wave-specialised kernel on 64-slot tiles; otherwise the generic instantiation on 32-slot tiles
-        const bool small = (size_t) a->in_frames * a->C * 4 < 0xffff0000ull && ((uintptr_t) a->in % 16) == 0 && ((uintptr_t) a->hist % 16) == 0;
-        const int cgt = (small && (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32)) ? a->C : 0;
+        const int cgt = matrix_geometry (a, g);
         const bool ws = cgt != 0;                             // (generic channel counts: the non-specialised instantiation on the same tiles)
         const bool wide = false;                              // (64-slot tiles, two m-tiles per X tile, lost: 156 VGPRs => one workgroup per CU, 29 vs 36 Gsamples/s in round 1; the template keeps the parameter, nothing instantiates it)
-        g.tile_rows = wide ? 64 : 32;
-        g.slot_tiles = (g.P + g.tile_rows - 1) / g.tile_rows;
-        g.cg = a->C < 32 ? a->C : 32;
-        g.ppw = MF_COLS / g.cg;
-        if (g.ppw > MF_MAX_PPW) g.ppw = MF_MAX_PPW;
-        const int shift_max = (int)((g.tile_rows - 1.0) * g.Q / g.P) + 2;
-        g.ktot = ((a->T + shift_max + MF_KC - 1) / MF_KC) * MF_KC;
-        g.band_lo = a->T / 2 - 1 - 6;                       // central taps of the first row ...
-        g.band_hi = a->T / 2 + shift_max + 6;               // ... to those of the last
-        const unsigned int periods = (total + g.P - 1) / g.P;
-        g.period_groups = (int)((periods + g.ppw - 1) / g.ppw);
-        g.groups_per_xcd = (g.period_groups + 7) / 8;
         {   // carve the per-launch tables out of the scratch buffer
             const size_t rows = (size_t) g.slot_tiles * g.tile_rows, eff_bytes = rows * g.ktot * sizeof (float);
             char *base = (char *) a->scratch;
@@ -930,14 +896,22 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
         const unsigned int roll_blocks = a->roll_dst ? (unsigned int)((a->H * a->C + wg_threads - 1) / wg_threads) : 0u;
         dim3 grid ((unsigned int)(8 * g.groups_per_xcd * g.slot_tiles) + roll_blocks, (unsigned int)((a->C + g.cg - 1) / g.cg));
 
-        if (a->interpolate) hipLaunchKernelGGL (mfma_prepare_kernel<true>, dim3 (g.slot_tiles, g.tile_rows), dim3 (256), 0, st, *a, *segs, g);
+        const bool regular = ws && !wide && kernel_pref != 5 && (size_t) a->n_end * a->C * 4 < 0xffff0000ull && mfma_launch_is_regular (a, segs);
+        // Fixed point on the integer matrix cores (fir_matrix_i8.hip) where the launch has its digit planes; the f32 kernels
+        // then follow as a gated stand-by (they return at once unless the staging pass met a sample the digits cannot
+        // hold) without the history roll, which the fixed-point launch has taken.  kernel_pref 6 pins the f32 kernel.
+        const int *gate = nullptr; int gate_value = 0;
+        const bool fixed = regular && kernel_pref != 6 && artfir_i8_launch (a, segs, g, cgt, roll_blocks, &gate, &gate_value, st);
+        // (the fixed-point path's staging pass has written this kernel's tables as well)
+        if (fixed) ;
+        else if (a->interpolate) hipLaunchKernelGGL (mfma_prepare_kernel<true>, dim3 (g.slot_tiles, g.tile_rows), dim3 (256), 0, st, *a, *segs, g);
         else hipLaunchKernelGGL (mfma_prepare_kernel<false>, dim3 (g.slot_tiles, g.tile_rows), dim3 (256), 0, st, *a, *segs, g);
-        if (a->ev_start) arthip_event_record (a->ev_start, stream);
+        if (a->ev_start && !fixed) arthip_event_record (a->ev_start, stream);
 
         // Regular launches (all but very long calls and nearest-filter phases on a half step) stream their tiles through
         // persistent workgroups: three per CU, each with an equal share of its XCD's tile list.  kernel_pref 5 pins the
         // one-tile-per-workgroup kernel (identical results; comparisons, tests).
-        if (ws && !wide && kernel_pref != 5 && (size_t) a->n_end * a->C * 4 < 0xffff0000ull && mfma_launch_is_regular (a, segs)) {
+        if (regular) {
             const int tiles_per_xcd = g.groups_per_xcd * g.slot_tiles;
             const int resident = 96;                                        // 32 CUs per XCD x 3 workgroups (80 VGPRs, 46 KB of LDS)
             // a static share per workgroup costs up to one tile time at the end: worth it from three rounds on, or when the
@@ -945,10 +919,14 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
             // workgroup 0.095 ms, two 0.110; 8 channels = 280 tiles, three per workgroup 0.167, one 0.171)
             int rounds = (tiles_per_xcd + resident - 1) / resident;
             if (rounds == 2 && tiles_per_xcd < 170) rounds = 1;
+            if (fixed && rounds < (tiles_per_xcd + 31) / 32) rounds = (tiles_per_xcd + 31) / 32;       // (stand-by: a small grid, quick to dismiss)
             { static const int k_env = [] { const char *e = getenv ("ARTAMD_TILES_PER_WG"); return e && *e ? atoi (e) : 0; } (); if (k_env > 0) rounds = k_env; }
             const int wgs_per_xcd = (tiles_per_xcd + rounds - 1) / rounds;
-            const dim3 sgrid ((unsigned int)(8 * wgs_per_xcd) + roll_blocks);
-#define MS_GO_(I, CGT, PS) hipLaunchKernelGGL ((fir_mfma_stream_kernel<I, CGT, PS>), sgrid, dim3 (2 * MF_THREADS), 0, st, *a, g, wgs_per_xcd)
+            ArtFirArgs behind = *a;
+            unsigned int behind_roll = roll_blocks;
+            if (fixed) { behind.roll_dst = nullptr; behind.ev_start = behind.ev_stop = nullptr; behind_roll = 0; }
+            const dim3 sgrid ((unsigned int)(8 * wgs_per_xcd) + behind_roll);
+#define MS_GO_(I, CGT, PS) hipLaunchKernelGGL ((fir_mfma_stream_kernel<I, CGT, PS>), sgrid, dim3 (2 * MF_THREADS), 0, st, behind, g, wgs_per_xcd, gate, gate_value)
 #define MS_GO(I, CGT) do { if (!I && !a->lowpass) MS_GO_ (false, CGT, true); else MS_GO_ (I, CGT, false); } while (0)
             if (a->interpolate) switch (cgt) { case 32: MS_GO (true, 32); break; case 16: MS_GO (true, 16); break; case 8: MS_GO (true, 8); break;
                                                 case 4: MS_GO (true, 4); break; case 2: MS_GO (true, 2); break; default: MS_GO (true, 1); }
@@ -956,7 +934,7 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
                                                 case 4: MS_GO (false, 4); break; case 2: MS_GO (false, 2); break; default: MS_GO (false, 1); }
 #undef MS_GO
 #undef MS_GO_
-            if (a->ev_stop) arthip_event_record (a->ev_stop, stream);
+            if (behind.ev_stop) arthip_event_record (behind.ev_stop, stream);
             return hipGetLastError () == hipSuccess ? (ART_KERNEL_MFMA | (a->roll_dst ? ART_FIR_ROLLED : 0)) : -1;
         }
 #define MF_GO(I, CGT) do { if (ws && CGT) hipLaunchKernelGGL ((fir_mfma_kernel<I, CGT, (CGT != 0), 1>), grid, dim3 (2 * MF_THREADS), 0, st, *a, *segs, g); \

@@ -1,0 +1,73 @@
+#pragma once
+// fir_matrix_common.hip.h — what the 4-byte-sample matrix-core translation units share (fir_matrix.hip: f32 MFMA kernels and the
+// launch rules; fir_matrix_i8.hip: the fixed-point kernel): tile geometry of one launch, raw buffer resources, vector loads.
+#include "fir_common.hip.h"
+
+struct MfmaGeom {
+    int P, Q;                             // outputs / inputs per period
+    int tile_rows;                        // slots per workgroup tile: 32, or 64 (two MFMA m-tiles sharing one X tile)
+    int slot_tiles;                       // ceil (P / tile_rows)
+    int ppw;                              // periods per workgroup
+    int cg;                               // channels per column group
+    int ktot;                             // K columns, multiple of MF_KC
+    int period_groups;
+    int groups_per_xcd;                   // ceil (period_groups / 8)
+    int band_lo, band_hi;
+    // per-launch tables in device scratch (written by mfma_prepare_kernel)
+    float *eff;                           // [slot_tiles*tile_rows][ktot]  blended rows, shifted to the tile's K origin, zero padded
+    int *canon_ip, *canon_fi;             // [slot_tiles*tile_rows]        canonical position of each slot (period 0 of the launch)
+    double *canon_frac;                 // K columns [band_lo, band_hi) hold every row's central taps
+    // the head of the call as ONE contiguous array (history ++ first input frames, MF_HEAD_PAD zero frames in front): tiles that
+    // reach into the history stage from it exactly as all others stage from `in` (written by mfma_prepare_kernel)
+    float *head; int head_frames;
+    // per slot tile, 3 ints: [0] linear index of K column 0 in period 0 of the launch; [1] the tile's pass-through row (nearest-
+    // filter mode without a low-pass: the one slot per period whose position falls exactly on an input sample), -1 if none;
+    // [2] that sample's linear index in period 0 (streaming kernel)
+    int *tile_w0;
+};
+
+// fir_matrix_i8.hip: the fixed-point kernel of regular launches
+size_t artfir_i8_bytes (const ArtFirArgs *a, const MfmaGeom &g, int cgt);         // device bytes of a launch's digit planes (0: not for it)
+// stage + main kernel of one launch; *gate / *gate_value: the f32 streaming kernel enqueued behind runs iff *gate == gate_value
+int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGeom &g, int cgt, unsigned int roll_blocks,
+                      const int **gate, int *gate_value, hipStream_t st);
+
+namespace {
+
+typedef float f32x16 __attribute__ ((ext_vector_type (16)));
+typedef float f32x4 __attribute__ ((ext_vector_type (4)));
+
+constexpr int MF_THREADS = 256;
+constexpr int MF_KC = 32;                 // k's per staged chunk
+constexpr int MF_LD = MF_KC + 4;          // LDS row pitch in floats (144 B: 16-B aligned, conflict-free b128)
+constexpr int MF_COLS = 128;              // columns per workgroup
+constexpr int MF_MAX_PPW = 64;            // periods per workgroup (C = 2)
+// A slot's phase may differ from its canonical value by this many filter steps and still use the tile's
+// effective row: adjacent rows differ by < 3e-3 per tap, so the row changes by < 6e-9 relative (a tenth of
+// half a float ulp).  The reference's own position arithmetic is quantised to ~1e-7 steps after 1M frames.
+constexpr double MF_PHASE_TOL = 2e-6;
+constexpr int MF_HEAD_PAD = 64;
+
+
+typedef unsigned int u32x4 __attribute__ ((ext_vector_type (4)));
+typedef unsigned int u32x2 __attribute__ ((ext_vector_type (2)));
+
+// raw buffer descriptor: the hardware range check returns 0 for any access past `bytes`, which is
+// exactly the zero padding the tile needs (beyond the valid input, before/after a filter row)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc (const void *base, unsigned int bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc (const_cast<void *> (base), 0, (int) bytes, 0x00020000);
+}
+
+template <int VEC> struct VecLoad;
+template <> struct VecLoad<1> { static __device__ __forceinline__ void load (float *dst, __amdgpu_buffer_rsrc_t r, unsigned int off) {
+    dst [0] = __uint_as_float (__builtin_amdgcn_raw_buffer_load_b32 (r, (int) off, 0, 0)); } };
+template <> struct VecLoad<2> { static __device__ __forceinline__ void load (float *dst, __amdgpu_buffer_rsrc_t r, unsigned int off) {
+    u32x2 v = __builtin_amdgcn_raw_buffer_load_b64 (r, (int) off, 0, 0);
+    dst [0] = __uint_as_float (v.x); dst [1] = __uint_as_float (v.y); } };
+template <> struct VecLoad<4> { static __device__ __forceinline__ void load (float *dst, __amdgpu_buffer_rsrc_t r, unsigned int off) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128 (r, (int) off, 0, 0);
+    dst [0] = __uint_as_float (v.x); dst [1] = __uint_as_float (v.y); dst [2] = __uint_as_float (v.z); dst [3] = __uint_as_float (v.w); } };
+
+
+} // namespace

@@ -63,6 +63,8 @@ struct artamd_resampler {
     int timing; void **ev; int ev_count, ev_cap;
     art_s *d_patch; size_t patch_cap;        /* end-point extrapolation: samples computed on the host */
     void *d_scratch; size_t scratch_cap;     /* MFMA path: effective rows + canonical positions of one launch */
+    void *d_planes; size_t planes_cap;       /* fixed-point matrix kernel: digit planes of one launch (flag word first) */
+    int last_fixed [3];                      /* its last launch of the last call: flag value (0: none), mask words, chunks per tile */
     unsigned int *d_fix; size_t fix_cap;    /* [0] per-launch, [1] running count of outputs the matrix kernels evaluated off-pattern */
     void *d_batch; size_t batch_cap;         /* argument table of the batched calls led by this context */
     unsigned long batch_stamp;               /* last batched call this context took part in (duplicate check) */
@@ -625,7 +627,7 @@ void resampleFree (Resample *cxt)
         arthip_event_destroy (hip->ev_parent);
         free (hip->shards); free (hip->shard_first); free (hip->ev_shard);
         bank_release (hip->bank); arthip_free (hip->d_hist [0]); arthip_free (hip->d_hist [1]);
-        arthip_free (hip->d_in); arthip_free (hip->d_out); arthip_free (hip->d_tmp); arthip_free (hip->d_fix); arthip_free (hip->d_scratch); arthip_free (hip->d_patch); arthip_free (hip->d_batch);
+        arthip_free (hip->d_in); arthip_free (hip->d_out); arthip_free (hip->d_tmp); arthip_free (hip->d_fix); arthip_free (hip->d_scratch); arthip_free (hip->d_planes); arthip_free (hip->d_patch); arthip_free (hip->d_batch);
         arthip_host_free (hip->h_in); arthip_host_free (hip->h_out);
         for (int i = 0; i < hip->ev_cap; ++i) arthip_event_destroy (hip->ev [i]);
         if (hip->own_stream) arthip_stream_destroy (hip->stream);
@@ -821,6 +823,35 @@ static void *timing_event (struct artamd_resampler *hip)
         hip->ev_cap = cap;
     }
     return hip->ev [hip->ev_count++];
+}
+
+/* Did the last call's FIR run on the fixed-point matrix kernel?  0: no; 1: yes; 2: it was enqueued and stood down (a sample
+ * outside (-1.98, 1.98) or not finite: the f32 kernel behind it produced the call).  *pairsPerChunk (optional): digit-pair
+ * products issued per 32-tap chunk and 32 x 32 outputs, averaged over the tile families (9 .. 13).  Synchronises. */
+int resampleHipLastFixedPoint (Resample *cxt, double *pairsPerChunk)
+{
+    struct artamd_resampler *hip = cxt->hip->nshards ? cxt->hip->shards [0]->hip : cxt->hip;
+    if (pairsPerChunk) *pairsPerChunk = 0.0;
+    if (!hip->last_fixed [0] || !hip->d_planes) return 0;
+    ENTER_DEVICE (hip);
+    int flag = 0;
+    const int words = hip->last_fixed [1], chunks = hip->last_fixed [2];
+    unsigned long long *masks = malloc (sizeof (unsigned long long) * (size_t)(words > 0 ? words : 1));
+    arthip_d2h (&flag, hip->d_planes, sizeof (flag), hip->stream);
+    if (masks && words > 0) arthip_d2h (masks, (char *) hip->d_planes + 256, sizeof (unsigned long long) * (size_t) words, hip->stream);
+    arthip_sync (hip->stream);
+    if (pairsPerChunk && masks && words > 0 && chunks > 0) {
+        double full = 0.0;
+        for (int v = 0; v < words; v += 32) {                 /* a tile family's mask = OR over its 32 rows */
+            unsigned long long m = 0;
+            for (int r = 0; r < 32; ++r) m |= masks [v + r];
+            for (; m; m &= m - 1) full += 1.0;
+        }
+        *pairsPerChunk = 9.0 + 4.0 * full / ((double)(words / 32) * chunks);
+    }
+    free (masks);
+    LEAVE_DEVICE (hip);
+    return flag == hip->last_fixed [0] ? 2 : 1;
 }
 
 int  resampleHipLastKernel (Resample *cxt) { return cxt->hip->nshards ? cxt->hip->shards [0]->hip->last_kernel : cxt->hip->last_kernel; }
@@ -1098,6 +1129,7 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
          * actually big enough for it (asked with stand-ins first — a service with thousands of small-block contexts never
          * pays for them) */
         int matrix_sized = 0;
+        hip->last_fixed [0] = 0;
         if (a.period_out && a.mode == ART_MODE_FAST && hip->kernel_pref != ART_KERNEL_GENERAL && !is_flush) {
             ArtSegTable probe;
             probe.count = 1; probe.lin_floor = lin_floor;
@@ -1116,6 +1148,14 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
             if (hip->d_fix) { a.fix_count = hip->d_fix; a.fix_list = hip->d_fix + 2; a.fix_cap = 0; }
             if (!hip->d_scratch) hip->d_scratch = grow (hip->d_scratch, &hip->scratch_cap, (size_t) 8 << 20);
             a.scratch = hip->d_scratch; a.scratch_bytes = hip->d_scratch ? hip->scratch_cap : 0;
+            /* digit planes for the fixed-point kernel (about the size of the call's input; without them the f32 kernels run) */
+            const size_t want = hip->kernel_pref == 5 || hip->kernel_pref == 6 ? 0 : arthip_fir_planes_bytes (&a);
+            if (want > hip->planes_cap) {
+                hip->d_planes = grow (hip->d_planes, &hip->planes_cap, want);
+                if (hip->d_planes) arthip_zero (hip->d_planes, 256, hip->stream);
+            }
+            a.planes = want ? hip->d_planes : NULL; a.planes_bytes = hip->d_planes ? hip->planes_cap : 0;
+            a.fixed_out = hip->last_fixed;
         }
 
         for (int s0 = 0; s0 < nseg; s0 += ART_MAX_SEGS) {

@@ -36,6 +36,7 @@ TAPS = FILTERS = 988                      # preset -4 (reference art.c:163-166 /
 SRC, DST = 44100, 48000
 FLOP_PER_SAMPLE = 4 * TAPS + 3            # two T-tap dot products + lerp           
 BYTES_PER_SAMPLE = 4.0 * SRC / DST + 4.0  # float32 in (1/R frames per out frame) + float32 out
+PEAK_I8_TOPS = 5033.0                     # MI355X dense int8 MFMA peak: twice the 2.5 PF bf16 rate, = the ~5 PF dense fp8 figure (MI355X_MICROARCH.md)
 PEAK_FP32_TFLOPS = 157.3                  # MI355X f32 FMA / f32-MFMA dense peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 
@@ -191,6 +192,7 @@ def main():
             torch.cuda.synchronize()
     dt, out_frames, kernel_ms, launches = timed_region()
     kernel_used = rs.last_kernel()
+    fixed_state, fixed_pairs = rs.fixed_point()           # 1: the matrix path ran in fixed point on the integer matrix cores
 
     dev = "cuda" if backend == "nccl" else "cpu"
     agg = agree_and_aggregate(dist, dev, dt, out_frames, Cn, kernel_ms, launches)
@@ -207,10 +209,14 @@ def main():
         per_launch_samples = out_frames * Cn / max(launches, 1)
         avg_ms = kernel_ms / max(launches, 1)
         kpad = ((TAPS + 31 + 31) // 32) * 32
-        executed_per_sample = 2 * kpad if kernel_used == 2 else FLOP_PER_SAMPLE
+        fixed = kernel_used == 2 and fixed_state == 1
+        # fixed-point kernel: every (sample, K column) costs one integer multiply-add per digit pair issued (13, or 9 where the
+        # rows' most significant digit plane is all zero: resampleHipLastFixedPoint reports the average)
+        executed_per_sample = (2 * kpad * fixed_pairs if fixed else 2 * kpad) if kernel_used == 2 else FLOP_PER_SAMPLE
+        peak = PEAK_I8_TOPS if fixed else PEAK_FP32_TFLOPS
         rate = per_launch_samples / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
         tflops_exec = rate * executed_per_sample / 1e12
-        tflops_useful = rate * (2 * TAPS if kernel_used == 2 else FLOP_PER_SAMPLE) / 1e12
+        tflops_useful = rate * ((2 * TAPS * fixed_pairs if fixed else 2 * TAPS) if kernel_used == 2 else FLOP_PER_SAMPLE) / 1e12
         tflops_ref_form = rate * FLOP_PER_SAMPLE / 1e12
         gbs = rate * BYTES_PER_SAMPLE / 1e9
         # HBM traffic of the dominant kernel is a PMC measurement (tools/pmc.sh: separate rocprofv3 --pmc passes, FETCH_SIZE
@@ -221,7 +227,7 @@ def main():
             try:
                 tr = json.load(open(os.path.join(ROOT, "profiles", name)))
                 w = tr["workload"]
-                if kernel_used == 2 and (w["block_frames"], w["channels"], w["taps"]) == (block, Cn, TAPS) and launches == args.steps:
+                if kernel_used == 2 and bool(tr.get("fixed_point", False)) == fixed and (w["block_frames"], w["channels"], w["taps"]) == (block, Cn, TAPS) and launches == args.steps:
                     traffic = tr["traffic_bytes_per_launch"]
                 break
             except Exception:
@@ -237,24 +243,33 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "preroll_ms": args.preroll_ms,
             "value_cold": round(agg_cold["samples_total"] / agg_cold["seconds_max"] / 1e6, 2),
             "value_cold_note": "the same W warmup + K timed steps run first, from cold clocks, before the untimed pre-roll",
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "i8 x 4 digits (32-bit fixed point of the f32 samples and the fp64-blended filter rows, exact i32 accumulation, one float rounding per output)" if fixed else "f32",
+            "data": "synthetic",
             "config": {"workload": f"{mode}; ranks take contiguous channel slices of ONE {total_ch}-channel stream; 44100->48000 Hz, "
                                    f"preset -4 = 988 filters x 988 taps Blackman-Harris interpolating (artest -4 -c8), float32 interleaved, "
                                    f"{block} input frames per call, device-resident in/out, resampleProcessInterleavedDevice",
                        "stream_channels": total_ch, "channels_per_gpu": Cn, "block_frames": block, "taps": TAPS, "filters": FILTERS,
-                       "fir_kernel": {1: "general", 2: "mfma"}.get(kernel_used, str(kernel_used)),
+                       "fir_kernel": "mfma-i8 (fixed point)" if fixed else {1: "general", 2: "mfma"}.get(kernel_used, str(kernel_used)),
                        "parallelism": f"channel-shard x{world}, no data-path collective",
-                       "accuracy": "default mode: |y - fp64-accumulate| <= 2^-23 max(1,|y|) (2 ulp on < 0.1 % of samples when |y| > 1, as the "
-                                   "reference's own float build); RESAMPLE_STRICT_ORDER is bit-exact"},
-            "roofline": {"bound": "mfma", "achieved": round(tflops_exec, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(tflops_exec / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
+                       "accuracy": ("default mode, fixed-point matrix kernel: |y - fp64-accumulate| <= half a float ulp + 2^-29; "
+                                    "RESAMPLE_STRICT_ORDER is bit-exact") if fixed else
+                                   ("default mode: |y - fp64-accumulate| <= 2^-23 max(1,|y|) (2 ulp on < 0.1 % of samples when |y| > 1, as the "
+                                    "reference's own float build); RESAMPLE_STRICT_ORDER is bit-exact")},
+            "roofline": {"bound": "mfma", "achieved": round(tflops_exec, 3), "peak": peak, "unit": "TFLOP/s",
+                         "unit_note": "integer multiply-adds of v_mfma_i32_32x32x32_i8, 2 ops each (TOP/s), against the dense int8 MFMA peak" if fixed else "f32 MFMA",
+                         "frac": round(tflops_exec / peak, 4), "traffic": traffic,
                          "traffic_unit": "bytes/launch (HBM, PMC)", "algorithmic_bytes_per_launch": int(per_launch_samples * BYTES_PER_SAMPLE),
-                         "kernel": "fir", "avg_kernel_ms": round(avg_ms, 4), "launches": launches,
-                         "flop_per_sample_executed": executed_per_sample, "bytes_per_sample": round(BYTES_PER_SAMPLE, 3),
-                         "useful_frac": round(tflops_useful / PEAK_FP32_TFLOPS, 4),
+                         "kernel": "fir_i8_stream_kernel" if fixed else "fir", "avg_kernel_ms": round(avg_ms, 4), "launches": launches,
+                         "flop_per_sample_executed": round(executed_per_sample, 1), "bytes_per_sample": round(BYTES_PER_SAMPLE, 3),
+                         "digit_pairs_per_chunk": round(fixed_pairs, 3) if fixed else None,
+                         "f32_mfma_equivalent_frac": round(rate * 2 * kpad / 1e12 / PEAK_FP32_TFLOPS, 4) if kernel_used == 2 else None,
+                         "useful_frac": round(tflops_useful / peak, 4),
                          "algorithmic_vs_reference_formulation": round(tflops_ref_form / PEAK_FP32_TFLOPS, 4),
-                         "note": "achieved/frac = flop the kernel EXECUTES on the matrix cores (2 x Kpad per sample, lerp folded into one "
-                                 "row per phase) over the f32-MFMA peak; useful_frac counts only the 2 x T non-padding columns; "
+                         "note": "achieved/frac = operations the kernel EXECUTES on the matrix cores (2 x Kpad per sample, lerp folded into one "
+                                 "row per phase; x digit pairs issued for the fixed-point kernel) over that instruction's dense peak; "
+                                 "f32_mfma_equivalent_frac prices the same samples/s as the f32 kernel's 2 x Kpad flop over the f32-MFMA peak "
+                                 "(the figure of earlier rounds; not a roofline fraction for the integer kernel); "
+                                 "useful_frac counts only the 2 x T non-padding columns; "
                                  "algorithmic_vs_reference_formulation prices the same samples/s at the reference's 4T+3 flop per "
                                  "sample (SURVEY 8d) and is not a roofline fraction",
                          "hbm_algorithmic_GBps": round(gbs, 2), "hbm_frac": round(gbs / PEAK_HBM_GBS, 5)},

@@ -46,9 +46,15 @@ void resampleHipSetStream (Resample *cxt, void *hipStream);
 void resampleHipSynchronize (Resample *cxt);
 /* kernel selection for tests and comparisons: 0 = automatic, 1 = general kernel, 2 = matrix-core path wherever the ratio is
  * rational (the persistent streaming kernel for regular launches, the one-tile-per-workgroup kernel otherwise; falls back to
- * 1 elsewhere), 5 = as 2 but always the one-tile-per-workgroup kernel (same bits as the streaming one) */
+ * 1 elsewhere), 5 = as 2 but always the one-tile-per-workgroup f32 kernel, 6 = as 2 but never the fixed-point kernel: the f32
+ * streaming kernel for regular launches (5 and 6 give the same bits; the fixed-point kernel rounds once per output and
+ * differs from them in the last place) */
 void resampleHipSetKernel (Resample *cxt, int which);
 int  resampleHipLastKernel (Resample *cxt);          /* which kernel produced the bulk of the last call */
+/* the matrix-core path's fixed-point kernel (regular launches, 4-byte samples): 0 = the last call did not use it, 1 = it ran,
+ * 2 = it was enqueued and stood down for the f32 kernel behind it (a sample outside (-1.98, 1.98) or not finite).
+ * *pairsPerChunk (may be NULL): digit-pair products issued per 32-tap chunk, 9 .. 13.  Synchronises. */
+int  resampleHipLastFixedPoint (Resample *cxt, double *pairsPerChunk);
 unsigned int resampleHipLastHandedBack (Resample *cxt);   /* outputs the matrix-core kernels evaluated at their own exact position, off their slot's canonical pattern, so far */
 /* HIP-event timing of the dominant FIR kernel only (events recorded on the context's stream immediately
  * before and after that kernel's launch; the fix-up and history kernels are outside the bracket).  Enable, run calls, then read: returns accumulated kernel milliseconds and the launch count

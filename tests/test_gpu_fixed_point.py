@@ -1,0 +1,144 @@
+"""GPU (-m gpu): the fixed-point form of the matrix-core path (fir_matrix_i8.hip: samples and effective rows as four signed
+8-bit digits, exact integer accumulation on v_mfma_i32_32x32x32_i8, one float rounding per output) — the default kernel of
+regular launches.  Its only errors are the 2^-31 quantisation of the effective rows (about 3e-9 rms at +-0.5 noise, whatever the
+output's size) and ONE float rounding, so against the double-accumulate oracle's float it must sit within one float spacing
++ 2^-25 everywhere and at about half the f32 kernels' rms error or less (they carry ~T roundings and only promise the parity
+bar); samples the digits cannot hold (beyond +-1.98,
+infinities, NaNs — in the call's input or in the history) must hand the launch to the f32 streaming kernel, bit for bit."""
+import numpy as np
+import pytest
+
+import audio_resampler_amd as A
+from _hip import HipResampler, tolerance_ok
+from _oracle import OracleResampler, noise, BH, INTERP, LOWPASS, PRECISE
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # (channels, taps, filters, src, dst, fixed-ratio form, flags, blocks)
+    (8, 988, 988, 44100, 48000, False, BH | INTERP, (70000, 50000, 131072)),          # headline shape
+    (4, 988, 988, 44100, 48000, False, BH | INTERP, (90000, 90000)),
+    (2, 380, 380, 44100, 48000, False, BH | INTERP, (200000, 100001)),                # 13 chunks per tile (odd)
+    (1, 380, 380, 44100, 48000, False, BH | INTERP, (300000,)),                       # mono: half the columns idle
+    (16, 156, 156, 44100, 48000, False, BH | INTERP, (60000, 60000)),
+    (32, 988, 988, 44100, 48000, False, BH | INTERP, (30000, 30000)),
+    (2, 380, 380, 44100, 48000, True, BH | INTERP | LOWPASS, (150000, 150000)),       # ART form: nearest filter, SNAP, low-pass
+    (8, 988, 988, 96000, 44100, True, BH | INTERP | LOWPASS, (140000, 140000)),       # downsampling: P = 147, Q = 320 (period stride 1)
+    (2, 380, 320, 44100, 48000, False, BH, (120000, 120000)),                         # nearest filter, pass-through samples
+    (2, 64, 160, 48000, 44100, False, BH, (250000,)),                                 # P = 147, Q = 160, 3 chunks
+    (2, 380, 380, 48000, 40000, False, BH | INTERP, (200000,)),                       # P = 5, Q = 6: period stride 2, 5 live rows per tile
+    (8, 988, 988, 44100, 48000, False, BH | INTERP, (2000, 3000, 500, 9000)),         # small calls
+]
+IDS = [f"c{c[0]}_t{c[1]}_f{c[2]}_{c[3]}to{c[4]}{'_fixed' if c[5] else ''}_{len(c[7])}calls" for c in CASES]
+
+
+def _make(case, kernel, oracle=False):
+    ch, T, F, src, dst, fixed, flags, blocks = case
+    if oracle:
+        r = OracleResampler(ch, T, F, flags=flags | PRECISE, fixed=(float(src), float(dst), 0)) if fixed else OracleResampler(ch, T, F, 0.0, flags | PRECISE)
+    else:
+        r = HipResampler(ch, T, F, flags=flags, fixed=(float(src), float(dst), 0), kernel=kernel) if fixed else HipResampler(ch, T, F, 0.0, flags, kernel=kernel)
+    r.advance(T / 2)
+    return r
+
+
+def _spacing(t64):
+    """float32 spacing of the binade each value lies in"""
+    return 2.0 ** (np.floor(np.log2(np.maximum(np.abs(t64), 2.0 ** -126))) - 23)
+
+
+def _play(r, x, blocks, ratio, fixed, want_state=None):
+    outs, pos = [], 0
+    for n in blocks:
+        u, g, y = r.process(x[pos:pos + n], int(n * ratio) + 4000, 0.0 if fixed else ratio)
+        assert u == n
+        if want_state is not None:
+            assert r.last_kernel() == 2 and r.fixed_point() [0] == want_state, (r.last_kernel(), r.fixed_point())
+        outs.append(np.array(y).copy())
+        pos += n
+    outs.append(np.array(r.process(None, 8000, ratio, flush=True) [2]).copy())
+    return outs
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_fixed_point_kernel_is_correctly_rounded_against_the_double_accumulate_oracle(case):
+    ch, T, F, src, dst, fixed, flags, blocks = case
+    ratio, total = dst / src, sum(blocks)
+    x, _ = noise(total * ch, state=0xFACADE5EED | 1)
+    x = x.reshape(total, ch)
+    # (calls of a few hundred frames go to the general kernel: only the results are checked there)
+    y = np.concatenate(_play(_make(case, 2), x, blocks, ratio, fixed, want_state=1 if min(blocks) >= 20000 else None))
+    t = np.concatenate(_play(_make(case, 0, oracle=True), x, blocks, ratio, fixed))
+    assert y.shape == t.shape
+    y64, t64 = y.astype(np.float64), t.astype(np.float64)
+    # both round a value known to a few 1e-9 (rows on a 2^-30 grid: 2.7e-10 rms per tap x sqrt (T) x the signal's rms): the same
+    # float, its neighbour across a rounding boundary, or — for small results — anything within that absolute error
+    err = np.abs(y64 - t64)
+    assert np.all(err <= _spacing(t64) + 2.0 ** -25), float((err - _spacing(t64)).max())
+    assert tolerance_ok(y, t) [0]
+    # about half the f32 kernels' rms error, or less
+    yf = np.concatenate(_play(_make(case, 6), x, blocks, ratio, fixed))
+    assert np.sqrt(np.mean((y64 - t64) ** 2)) <= 0.6 * np.sqrt(np.mean((yf.astype(np.float64) - t64) ** 2))
+
+
+@pytest.mark.parametrize("amplitude", [1.9, 1e-3, 1e-6], ids=["1.9", "1e-3", "1e-6"])
+def test_fixed_point_kernel_over_the_amplitude_range(amplitude):
+    """near the top of the representable range (the rows' quantisation error grows with the signal: 2^-24 allowed), and quiet
+    signals (samples below 2^-7 are themselves rounded to the 2^-30 grid: absolute error of a few 2^-31, far inside the bar)"""
+    ch, T, frames = 2, 380, 120000
+    ratio = 48000 / 44100
+    x, _ = noise(frames * ch, state=0xA11CE | 1)
+    x = (x.reshape(frames, ch) * (amplitude / 0.5)).astype(np.float32)
+    r = HipResampler(ch, T, T, 0.0, BH | INTERP, kernel=2); r.advance(T / 2)
+    o = OracleResampler(ch, T, T, 0.0, BH | INTERP | PRECISE); o.advance(T / 2)
+    u, g, y = r.process(x, int(frames * ratio) + 4000, ratio)
+    uo, go, yo = o.process(x, int(frames * ratio) + 4000, ratio, threads=2)
+    assert (u, g) == (uo, go) and r.fixed_point() [0] == 1
+    y64, t64 = np.array(y, np.float64), np.array(yo, np.float64)
+    assert np.all(np.abs(y64 - t64) <= _spacing(t64) + (2.0 ** -24 if amplitude > 1 else 2.0 ** -28)), float(np.abs(y64 - t64).max())
+    assert tolerance_ok(np.array(y), np.array(yo)) [0]
+
+
+BAD = [("above the range", 2.5), ("below the range", -1.99), ("infinity", np.inf), ("NaN", np.nan)]
+
+
+@pytest.mark.parametrize("what,value", BAD, ids=[b [0].replace(" ", "_") for b in BAD])
+def test_samples_the_digits_cannot_hold_hand_the_launch_to_the_f32_kernel(what, value):
+    """one such sample anywhere in the call, or in the history it still convolves with: the fixed-point kernel stands down on the
+    device and the f32 streaming kernel behind it produces the call — the same bits as with that kernel pinned; calls that do
+    not touch the sample run in fixed point again"""
+    ch, T, frames = 8, 988, 60000
+    ratio = 48000 / 44100
+    x, _ = noise(4 * frames * ch, state=0xBAD5A | 1)
+    x = x.reshape(4 * frames, ch).copy()
+    x [frames + frames // 2, 3] = value                      # in the second call
+    x [3 * frames - 40, 5] = value                           # at the end of the third: still in the fourth call's history
+    states, outs = [], {}
+    for kernel in (2, 6):
+        r = HipResampler(ch, T, T, 0.0, BH | INTERP, kernel=kernel); r.advance(T / 2)
+        outs [kernel] = []
+        for k in range(4):
+            u, g, y = r.process(x [k * frames:(k + 1) * frames], int(frames * ratio) + 4000, ratio)
+            assert u == frames and r.last_kernel() == 2
+            if kernel == 2:
+                states.append(r.fixed_point() [0])
+            outs [kernel].append(np.array(y).copy())
+    assert states == [1, 2, 2, 2], states
+    for k in (1, 2, 3):
+        a, b = outs [2] [k], outs [6] [k]
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (what, k)
+    # the first call never saw the sample: fixed point, and within half an ulp of the f32 kernel's neighbourhood
+    assert not np.array_equal(outs [2] [0].view(np.uint32), outs [6] [0].view(np.uint32))
+    assert np.all(np.abs(outs [2] [0].astype(np.float64) - outs [6] [0].astype(np.float64)) <= 2.0 ** -22)
+
+
+def test_fixed_point_kernel_skips_the_zero_digit_plane_away_from_the_centre():
+    """diagnostics: of the 13 digit-pair products per chunk, the 4 with the rows' most significant digit are only issued in the
+    chunks around the rows' centres (taps fall off as 1 / distance) — on the headline filter, fewer than 10 of 13 on average"""
+    ch, T, frames = 8, 988, 100000
+    ratio = 48000 / 44100
+    x, _ = noise(frames * ch)
+    r = HipResampler(ch, T, T, 0.0, BH | INTERP); r.advance(T / 2)
+    u, g, y = r.process(x.reshape(frames, ch), int(frames * ratio) + 4000, ratio)
+    state, pairs = r.fixed_point()
+    assert state == 1 and 9.0 < pairs < 10.0, (state, pairs)

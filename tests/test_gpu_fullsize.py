@@ -96,12 +96,13 @@ def test_bench_line_keeps_its_contract():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
-    assert d["unit"] == "Msamples/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
-    assert "workload" in d["config"] and d["config"]["fir_kernel"] == "mfma" and d["config"]["block_frames"] == 1 << 20
+    # (the arithmetic type the path computes in: regular launches of the matrix path run in 32-bit fixed point on the int8 matrix cores)
+    assert d["unit"] == "Msamples/s" and d["dtype"].startswith("i8 x 4 digits") and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and d["config"]["fir_kernel"] == "mfma-i8 (fixed point)" and d["config"]["block_frames"] == 1 << 20
     r = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["peak"] > 5000 and 9.0 < r["digit_pairs_per_chunk"] < 13.0
     # a roofline fraction: what the matrix cores execute over their peak, never above 1; the reference-formulation figure is separate
     assert 0.0 < r["frac"] <= 1.0 and r["useful_frac"] <= r["frac"] and "algorithmic_vs_reference_formulation" in r
     assert "value_cold" in d and d["value_cold"] > 0
@@ -120,6 +121,6 @@ def test_bench_strong_mode_is_one_32_channel_stream():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["scaling"] == "strong" and d["config"]["stream_channels"] == 32 and d["config"]["channels_per_gpu"] == 32
-    assert "STRONG" in d["config"]["workload"] and d["config"]["fir_kernel"] == "mfma" and d["roofline"]["frac"] <= 1.0
+    assert "STRONG" in d["config"]["workload"] and d["config"]["fir_kernel"] == "mfma-i8 (fixed point)" and d["roofline"]["frac"] <= 1.0
     per_step = d["value"] * 1e6 * d["ms_per_step"] * 1e-3
     assert abs(per_step - 262144 * 32 * 48000 / 44100) / per_step < 0.01

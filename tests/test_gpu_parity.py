@@ -77,7 +77,9 @@ def test_mfma_kernel_within_one_ulp_fullscale_of_precise(name):
     ok, worst, rms = tolerance_ok(y, truth)
     assert ok, (worst, rms)
     ref_float, _ = G.replay(G.make(OracleResampler, name), name)
-    assert rms <= tolerance_ok(ref_float, truth)[2] * 1.25 + 1e-12
+    # (+ 1e-9: regular launches run in fixed point, whose rows sit on a 2^-31 grid — a floor of ~1e-10..3e-9 rms where the float
+    # arithmetic of a tiny filter happens to be exact; the parity bar is 1.2e-7)
+    assert rms <= tolerance_ok(ref_float, truth)[2] * 1.25 + 1e-9
 
 
 def test_mfma_kernel_is_the_one_running_the_headline_config():

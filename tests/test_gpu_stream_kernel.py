@@ -1,5 +1,6 @@
-"""GPU (-m gpu): the persistent ("streaming") form of the matrix-core kernel (sinc_fir.hip, fir_mfma_stream_kernel) against the
-one-tile-per-workgroup kernel it replaces for regular launches (kernel preference 5 pins the latter): the same tiles, K order
+"""GPU (-m gpu): the persistent ("streaming") f32 form of the matrix-core kernel (fir_matrix.hip, fir_mfma_stream_kernel; kernel
+preference 6 pins it: by default regular launches run the fixed-point kernel, tests/test_gpu_fixed_point.py) against the
+one-tile-per-workgroup kernel (kernel preference 5 pins that one): the same tiles, K order
 and flush schedule, so every bit must agree — over channel counts (all compiled column groups), tap counts with odd and
 even chunk counts, nearest-filter mode with and without pass-through samples, small and multi-launch calls, streaming across
 calls (history seam) and flushes."""
@@ -55,7 +56,7 @@ def test_streaming_kernel_equals_tile_kernel_bit_for_bit(case):
         r.advance(T / 2)
         return r
 
-    y_stream = _play(make(2), x, blocks, ratio, fixed)
+    y_stream = _play(make(6), x, blocks, ratio, fixed)
     y_tile = _play(make(5), x, blocks, ratio, fixed)
     assert y_stream.shape == y_tile.shape
     assert np.array_equal(y_stream.view(np.uint32), y_tile.view(np.uint32))
@@ -69,7 +70,7 @@ def test_streaming_kernel_long_call_with_many_ring_epochs_matches_oracle():
     x, _ = noise(frames * ch)
     x = x.reshape(frames, ch)
     outs = []
-    for kernel in (2, 5):
+    for kernel in (6, 5):
         r = HipResampler(ch, T, T, 0.0, BH | INTERP, kernel=kernel)
         r.advance(T / 2)
         u, g, y = r.process(x, int(frames * ratio) + 4000, ratio)
