@@ -102,8 +102,9 @@ float arthip_event_elapsed_ms (void *start, void *stop);   /* synchronises on `s
 /* ---- sinc_fir.hip ---- */
 /* returns the kernel actually used (ART_KERNEL_*), <0 on launch failure */
 int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, void *stream);
-/* bytes a->planes must hold for the fixed-point matrix kernel to run a call of this shape (C, T, H, in_frames, period; 0: never) */
-size_t arthip_fir_planes_bytes (const ArtFirArgs *a);
+/* bytes a->planes must hold for the fixed-point matrix kernel to run a call of this shape (C, T, H, in_frames, period) making
+ * `outputs` frames; 0: the call is not for it (shape, size, kernel preference) */
+size_t arthip_fir_planes_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref);
 /* n independent general-kernel calls (default / precise mode) in one launch per kernel variant; d_table = device scratch of
  * n * arthip_fir_batch_item_bytes () bytes (reused call after call: stream order protects it); asynchronous like arthip_fir */
 size_t arthip_fir_batch_item_bytes (void);

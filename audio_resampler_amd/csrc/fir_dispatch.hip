@@ -5,7 +5,7 @@ extern "C" {
 
 int arthip_fir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref) { return artfir_takes_matrix_path (a, segs, kernel_pref) ? 1 : 0; }
 
-size_t arthip_fir_planes_bytes (const ArtFirArgs *a) { return artfir_planes_bytes (a); }
+size_t arthip_fir_planes_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref) { return artfir_planes_bytes (a, outputs, kernel_pref); }
 
 int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, void *stream)
 {

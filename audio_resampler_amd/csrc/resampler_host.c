@@ -1149,7 +1149,7 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
             if (!hip->d_scratch) hip->d_scratch = grow (hip->d_scratch, &hip->scratch_cap, (size_t) 8 << 20);
             a.scratch = hip->d_scratch; a.scratch_bytes = hip->d_scratch ? hip->scratch_cap : 0;
             /* digit planes for the fixed-point kernel (about the size of the call's input; without them the f32 kernels run) */
-            const size_t want = hip->kernel_pref == 5 || hip->kernel_pref == 6 ? 0 : arthip_fir_planes_bytes (&a);
+            const size_t want = arthip_fir_planes_bytes (&a, res.output_generated, hip->kernel_pref);
             if (want > hip->planes_cap) {
                 hip->d_planes = grow (hip->d_planes, &hip->planes_cap, want);
                 if (hip->d_planes) arthip_zero (hip->d_planes, 256, hip->stream);

@@ -48,7 +48,8 @@ void resampleHipSynchronize (Resample *cxt);
  * rational (the persistent streaming kernel for regular launches, the one-tile-per-workgroup kernel otherwise; falls back to
  * 1 elsewhere), 5 = as 2 but always the one-tile-per-workgroup f32 kernel, 6 = as 2 but never the fixed-point kernel: the f32
  * streaming kernel for regular launches (5 and 6 give the same bits; the fixed-point kernel rounds once per output and
- * differs from them in the last place) */
+ * differs from them in the last place), 7 = as 2 and the fixed-point kernel wherever it can run (automatically it takes
+ * filters of 512 taps and more in calls of about a billion output-sample taps and more, where it is the faster one) */
 void resampleHipSetKernel (Resample *cxt, int which);
 int  resampleHipLastKernel (Resample *cxt);          /* which kernel produced the bulk of the last call */
 /* the matrix-core path's fixed-point kernel (regular launches, 4-byte samples): 0 = the last call did not use it, 1 = it ran,

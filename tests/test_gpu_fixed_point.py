@@ -1,6 +1,6 @@
 """GPU (-m gpu): the fixed-point form of the matrix-core path (fir_matrix_i8.hip: samples and effective rows as four signed
-8-bit digits, exact integer accumulation on v_mfma_i32_32x32x32_i8, one float rounding per output) — the default kernel of
-regular launches.  Its only errors are the 2^-31 quantisation of the effective rows (about 3e-9 rms at +-0.5 noise, whatever the
+8-bit digits, exact integer accumulation on v_mfma_i32_32x32x32_i8, one float rounding per output) — the kernel of big
+regular launches with long filters (kernel preference 7: of every regular launch).  Its only errors are the 2^-31 quantisation of the effective rows (about 3e-9 rms at +-0.5 noise, whatever the
 output's size) and ONE float rounding, so against the double-accumulate oracle's float it must sit within one float spacing
 + 2^-25 everywhere and at about half the f32 kernels' rms error or less (they carry ~T roundings and only promise the parity
 bar); samples the digits cannot hold (beyond +-1.98,
@@ -67,7 +67,7 @@ def test_fixed_point_kernel_is_correctly_rounded_against_the_double_accumulate_o
     x, _ = noise(total * ch, state=0xFACADE5EED | 1)
     x = x.reshape(total, ch)
     # (calls of a few hundred frames go to the general kernel: only the results are checked there)
-    y = np.concatenate(_play(_make(case, 2), x, blocks, ratio, fixed, want_state=1 if min(blocks) >= 20000 else None))
+    y = np.concatenate(_play(_make(case, 7), x, blocks, ratio, fixed, want_state=1 if min(blocks) >= 20000 else None))
     t = np.concatenate(_play(_make(case, 0, oracle=True), x, blocks, ratio, fixed))
     assert y.shape == t.shape
     y64, t64 = y.astype(np.float64), t.astype(np.float64)
@@ -89,7 +89,7 @@ def test_fixed_point_kernel_over_the_amplitude_range(amplitude):
     ratio = 48000 / 44100
     x, _ = noise(frames * ch, state=0xA11CE | 1)
     x = (x.reshape(frames, ch) * (amplitude / 0.5)).astype(np.float32)
-    r = HipResampler(ch, T, T, 0.0, BH | INTERP, kernel=2); r.advance(T / 2)
+    r = HipResampler(ch, T, T, 0.0, BH | INTERP, kernel=7); r.advance(T / 2)
     o = OracleResampler(ch, T, T, 0.0, BH | INTERP | PRECISE); o.advance(T / 2)
     u, g, y = r.process(x, int(frames * ratio) + 4000, ratio)
     uo, go, yo = o.process(x, int(frames * ratio) + 4000, ratio, threads=2)
@@ -114,31 +114,34 @@ def test_samples_the_digits_cannot_hold_hand_the_launch_to_the_f32_kernel(what, 
     x [frames + frames // 2, 3] = value                      # in the second call
     x [3 * frames - 40, 5] = value                           # at the end of the third: still in the fourth call's history
     states, outs = [], {}
-    for kernel in (2, 6):
+    for kernel in (7, 6):
         r = HipResampler(ch, T, T, 0.0, BH | INTERP, kernel=kernel); r.advance(T / 2)
         outs [kernel] = []
         for k in range(4):
             u, g, y = r.process(x [k * frames:(k + 1) * frames], int(frames * ratio) + 4000, ratio)
             assert u == frames and r.last_kernel() == 2
-            if kernel == 2:
+            if kernel == 7:
                 states.append(r.fixed_point() [0])
             outs [kernel].append(np.array(y).copy())
     assert states == [1, 2, 2, 2], states
     for k in (1, 2, 3):
-        a, b = outs [2] [k], outs [6] [k]
+        a, b = outs [7] [k], outs [6] [k]
         assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (what, k)
     # the first call never saw the sample: fixed point, and within half an ulp of the f32 kernel's neighbourhood
-    assert not np.array_equal(outs [2] [0].view(np.uint32), outs [6] [0].view(np.uint32))
-    assert np.all(np.abs(outs [2] [0].astype(np.float64) - outs [6] [0].astype(np.float64)) <= 2.0 ** -22)
+    assert not np.array_equal(outs [7] [0].view(np.uint32), outs [6] [0].view(np.uint32))
+    assert np.all(np.abs(outs [7] [0].astype(np.float64) - outs [6] [0].astype(np.float64)) <= 2.0 ** -22)
 
 
-def test_fixed_point_kernel_skips_the_zero_digit_plane_away_from_the_centre():
+def test_fixed_point_kernel_skips_the_zero_digit_plane_and_is_chosen_where_it_pays():
     """diagnostics: of the 13 digit-pair products per chunk, the 4 with the rows' most significant digit are only issued in the
-    chunks around the rows' centres (taps fall off as 1 / distance) — on the headline filter, fewer than 10 of 13 on average"""
-    ch, T, frames = 8, 988, 100000
+    chunks around the rows' centres (taps fall off as 1 / distance) — on the headline filter, fewer than 10 of 13 on average.
+    The automatic choice takes the fixed-point kernel for long filters in big calls only (fir_matrix.hip, artfir_planes_bytes)."""
     ratio = 48000 / 44100
-    x, _ = noise(frames * ch)
-    r = HipResampler(ch, T, T, 0.0, BH | INTERP); r.advance(T / 2)
-    u, g, y = r.process(x.reshape(frames, ch), int(frames * ratio) + 4000, ratio)
-    state, pairs = r.fixed_point()
-    assert state == 1 and 9.0 < pairs < 10.0, (state, pairs)
+    for ch, T, frames, want in ((8, 988, 300000, 1), (8, 988, 60000, 0), (2, 380, 1000000, 0)):
+        x, _ = noise(frames * ch)
+        r = HipResampler(ch, T, T, 0.0, BH | INTERP); r.advance(T / 2)
+        u, g, y = r.process(x.reshape(frames, ch), int(frames * ratio) + 4000, ratio)
+        state, pairs = r.fixed_point()
+        assert u == frames and r.last_kernel() == 2 and state == want, (ch, T, frames, state)
+        if want:
+            assert 9.0 < pairs < 10.0, pairs

@@ -66,18 +66,20 @@ def test_fast_mode_within_one_ulp_fullscale_of_precise(name):
     assert rms <= rms_ref * 1.25 + 1e-12, (rms, rms_ref)
 
 
+@pytest.mark.parametrize("kernel", [2, 7], ids=["matrix", "matrix_fixed_point"])
 @pytest.mark.parametrize("name", G.NAMES)
-def test_mfma_kernel_within_one_ulp_fullscale_of_precise(name):
+def test_mfma_kernel_within_one_ulp_fullscale_of_precise(name, kernel):
     """same contract with the MFMA periodic-phase kernel forced on wherever the ratio is rational
-    (short calls included; non-rational calls fall back to the general kernel inside the library)"""
-    r = G.make(HipResampler, name, kernel=2)
+    (short calls included; non-rational calls fall back to the general kernel inside the library) — and with its
+    fixed-point form forced on wherever that can run (kernel preference 7)"""
+    r = G.make(HipResampler, name, kernel=kernel)
     y, trace = G.replay(r, name)
     truth, _ = G.replay(G.make(OracleResampler, name, PRECISE), name)
     assert np.array_equal(trace[:, :4], G.load("resample")[name + "/trace"][:, :4])
     ok, worst, rms = tolerance_ok(y, truth)
     assert ok, (worst, rms)
     ref_float, _ = G.replay(G.make(OracleResampler, name), name)
-    # (+ 1e-9: regular launches run in fixed point, whose rows sit on a 2^-31 grid — a floor of ~1e-10..3e-9 rms where the float
+    # (+ 1e-9: with preference 7 regular launches run in fixed point, whose rows sit on a 2^-31 grid — a floor of ~1e-10..3e-9 rms where the float
     # arithmetic of a tiny filter happens to be exact; the parity bar is 1.2e-7)
     assert rms <= tolerance_ok(ref_float, truth)[2] * 1.25 + 1e-9
 

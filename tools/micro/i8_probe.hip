@@ -32,6 +32,7 @@ __global__ __launch_bounds__ (512) void k_rate (int *out, int chunks)
     __syncthreads ();
     if (wave >= 4) {
         if (MODE < 2) return;
+        if (MODE == 3) { for (int c = 0; c < chunks; ++c) __syncthreads (); return; }
         // staging stand-in: 16 b32 writes + 1 b128 write per thread and chunk (X: 16 KB, A: 4 KB), then the barrier
         const int pt = tid & 255;
         int v = pt;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__ (512) void k_rate (int *out, int chunks)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (i + j < CLASSES) acc [i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8 (a [i], b [j], acc [i + j], 0, 0, 0);
-        if (MODE == 2) __syncthreads ();
+        if (MODE >= 2) __syncthreads ();
     }
     int s = 0; for (int q = 0; q < 5; ++q) for (int r = 0; r < 16; ++r) s += acc [q] [r];
     out [blockIdx.x * 256 + tid] = s;
@@ -108,9 +109,10 @@ int main ()
         const int grid = 256 * wgs_per_cu;
 #define RUN(MODE, CLASSES, NM) do { double ms = timeit ([&] { hipLaunchKernelGGL ((k_rate<MODE, CLASSES>), dim3 (grid), dim3 (512), 0, 0, out, chunks); }); \
         printf ("wg/cu %d  mode %d (%s) classes %d: %7.3f ms  %8.1f Tops/s  (%.0f cycles per 32-tap chunk at 2.4 GHz per workgroup slot)\n", wgs_per_cu, MODE, NM, CLASSES, ms, \
-                (double) grid * 4 * chunks * (CLASSES == 5 ? 13 : 10) * 65536.0 / ms / 1e9, ms * 1e-3 * 2.4e9 / chunks / wgs_per_cu); } while (0)
+                (double) grid * 4 * chunks * (CLASSES == 5 ? 13 : CLASSES == 4 ? 10 : 1) * 65536.0 / ms / 1e9, ms * 1e-3 * 2.4e9 / chunks / wgs_per_cu); } while (0)
         RUN (0, 5, "registers"); RUN (1, 5, "LDS reads"); RUN (2, 5, "LDS reads + staging writes + barrier");
         RUN (0, 4, "registers"); RUN (1, 4, "LDS reads"); RUN (2, 4, "LDS reads + staging writes + barrier");
+        RUN (1, 1, "LDS reads, one product"); RUN (2, 1, "LDS reads + staging writes + barrier, one product"); RUN (3, 1, "LDS reads + barrier (8 waves), one product"); RUN (3, 5, "LDS reads + barrier (8 waves)");
     }
     return 0;
 }
