@@ -103,7 +103,7 @@ def main():
                          "strong: ONE stream of --total-channels, total/N per GPU (BASELINE.json configs[3]: 32 channels, 4 per GPU at N = 8)")
     ap.add_argument("--total-channels", type=int, default=32, help="strong scaling: channels of the stream")
     ap.add_argument("--block-frames", type=int, default=1 << 20, help="input frames per call")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 general, 2 MFMA")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 general, 2 matrix path, 5 f32 tile kernel, 6 f32 streaming kernel, 7 fixed point wherever possible")
     ap.add_argument("--preroll-ms", type=float, default=200.0, help="untimed device pre-roll before the warmup steps (clock ramp); 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

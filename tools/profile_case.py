@@ -1,5 +1,5 @@
 """One named workload, a few dozen launches, for rocprofv3 (kernel stats and --pmc passes): the kernels bench.py does not reach.
-Usage: python tools/profile_case.py CASE [steps]     CASE in: general_E general_P general_A matrix_B matrix_D4 matrix_D32 wide biquad biquad_serial decimate strict
+Usage: python tools/profile_case.py CASE [steps]     CASE in: general_E general_P general_A matrix_B matrix_D4 matrix_D32 fixed_D4 fixed_D32 wide biquad biquad_serial decimate strict
 Prints one JSON line: what ran, samples per launch, algorithmic flop and bytes per sample (tools/roofline_report.py reads it)."""
 import ctypes as C, json, math, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -39,11 +39,15 @@ elif case == "matrix_B":       # BASELINE configs[1]: stereo preset -3 (380 x 38
     step, rs = resampler_case(2, 380, 380, BH | IN, 1 << 20)
     info.update(kernel="fir_mfma_stream_kernel", flop_per_sample=2 * 416, bytes_per_sample=4 * 44100 / 48000 + 4, peak="fp32")
 elif case == "matrix_D4":      # BASELINE configs[3]: the 4-channel shard one GPU of 8 owns (988 x 988 interpolating)
-    step, rs = resampler_case(4, 988, 988, BH | IN, 1 << 20)
+    step, rs = resampler_case(4, 988, 988, BH | IN, 1 << 20, kernel=6)          # (6: the f32 streaming kernel; left alone the call runs in fixed point)
     info.update(kernel="fir_mfma_stream_kernel", flop_per_sample=2 * 1024, bytes_per_sample=4 * 44100 / 48000 + 4, peak="fp32")
 elif case == "matrix_D32":     # BASELINE configs[3] on ONE GPU: all 32 channels
-    step, rs = resampler_case(32, 988, 988, BH | IN, 1 << 18)
+    step, rs = resampler_case(32, 988, 988, BH | IN, 1 << 18, kernel=6)
     info.update(kernel="fir_mfma_stream_kernel", flop_per_sample=2 * 1024, bytes_per_sample=4 * 44100 / 48000 + 4, peak="fp32")
+elif case in ("fixed_D4", "fixed_D32"):     # the same two shapes as the library runs them: the fixed-point kernel (integer matrix cores)
+    step, rs = resampler_case(4, 988, 988, BH | IN, 1 << 20) if case == "fixed_D4" else resampler_case(32, 988, 988, BH | IN, 1 << 18)
+    step(); state, pairs = rs.fixed_point(); assert state == 1, state
+    info.update(kernel="fir_i8_stream_kernel", flop_per_sample=round(2 * 1024 * pairs, 1), bytes_per_sample=4 * 44100 / 48000 + 4, peak="i8")
 elif case == "strict":         # RESAMPLE_STRICT_ORDER: the parity instrument
     step, rs = resampler_case(8, 988, 988, BH | IN | A.RESAMPLE_STRICT_ORDER, 1 << 16)
     info.update(kernel="fir_strict_kernel", flop_per_sample=4 * 988 + 3, bytes_per_sample=4 * 44100 / 48000 + 4, peak="fp32")

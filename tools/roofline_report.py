@@ -6,7 +6,7 @@ bench.py), and copies the rocprofv3 summaries it used (kernel stats, per-kernel 
 import collections, csv, glob, json, os, shutil, sys
 
 src, dst, rnd = sys.argv[1], sys.argv[2], sys.argv[3]
-PEAKS = {"fp32": (157.3, "TFLOP/s f32 (vector = matrix)"), "fp64_mfma": (78.6, "TFLOP/s f64 matrix"), "hbm": (8000.0, "GB/s HBM")}
+PEAKS = {"i8": (5033.0, "TOP/s int8 matrix (dense)"), "fp32": (157.3, "TFLOP/s f32 (vector = matrix)"), "fp64_mfma": (78.6, "TFLOP/s f64 matrix"), "hbm": (8000.0, "GB/s HBM")}
 os.makedirs(dst, exist_ok=True)
 
 
@@ -51,8 +51,10 @@ for f in ("bench100.json", "bench.json"):
 
 # ---- headline
 st = stats("headline")
-kname, (calls, avg_ns, pct) = find(st, "fir_mfma")
-c = counters("headline", "fir_mfma")
+fixed = str(bench.get("dtype", "")).startswith("i8")
+frag = "fir_i8_stream" if fixed else "fir_mfma"
+kname, (calls, avg_ns, pct) = find(st, frag)
+c = counters("headline", frag)
 spl = bench["roofline"]["algorithmic_bytes_per_launch"] / bench["roofline"]["bytes_per_sample"]
 exec_flop = bench["roofline"]["flop_per_sample_executed"]
 tf = spl * exec_flop / (avg_ns * 1e-9) / 1e12
@@ -60,8 +62,9 @@ traffic = None
 if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
     traffic = int(c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024)          # KB -> bytes; gfx950 wide-read correction on the fetch side
 rows.append(("headline: 8 ch 44.1k->48k, -4 (988x988 interp), 1M-frame calls", kname, calls, avg_ns, f"{exec_flop} executed (4T+3 = 3955 in the reference formulation)",
-             bench["roofline"]["bytes_per_sample"], f"{tf:.1f} TFLOP/s = {tf / 157.3:.3f} of f32 matrix peak", traffic, bench["roofline"]["algorithmic_bytes_per_launch"]))
-tj = {"kernel": kname, "workload": {"block_frames": bench["config"]["block_frames"], "channels": bench["config"]["channels_per_gpu"], "taps": 988, "filters": 988, "src": 44100, "dst": 48000},
+             bench["roofline"]["bytes_per_sample"], (f"{tf:.0f} TOP/s = {tf / 5033.0:.3f} of the dense int8 matrix peak (the same samples/s as 2 x Kpad f32 flop: {spl * 2048 / (avg_ns * 1e-9) / 1e12 / 157.3:.3f} of the f32 matrix peak)" if fixed
+              else f"{tf:.1f} TFLOP/s = {tf / 157.3:.3f} of f32 matrix peak"), traffic, bench["roofline"]["algorithmic_bytes_per_launch"]))
+tj = {"kernel": kname, "fixed_point": fixed, "workload": {"block_frames": bench["config"]["block_frames"], "channels": bench["config"]["channels_per_gpu"], "taps": 988, "filters": 988, "src": 44100, "dst": 48000},
       "FETCH_SIZE_KB": c.get("FETCH_SIZE"), "WRITE_SIZE_KB": c.get("WRITE_SIZE"), "fetch_correction": 2.0,
       "note": "gfx950 rocprofv3 FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads (MI355X_MICROARCH.md, HBM): doubled; WRITE_SIZE as reported",
       "traffic_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
@@ -73,11 +76,24 @@ if c.get("SQ_VALU_MFMA_BUSY_CYCLES") and c.get("GRBM_GUI_ACTIVE"):
     tj["mfma_pipe_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (c["GRBM_GUI_ACTIVE"] / 8), 3)
 json.dump(tj, open(os.path.join(dst, f"{rnd}_traffic.json"), "w"), indent=1)
 summary.append(("headline", kname, c))
-pk, (pcalls, pavg, _) = find(st, "mfma_prepare")
-if pk: rows.append(("  (its prepare launch)", pk, pcalls, pavg, "-", "-", "-", None, None))
+for frag2, what in (("mfma_prepare", "its prepare launch"), ("i8_stage", "its staging pass: digit planes of the rows and of history ++ input"), ("fir_mfma_stream", "its f32 stand-by, dismissed on the device")):
+    pk, v = find(st, frag2)
+    if pk and pk != kname: rows.append((f"  ({what})", pk, v[0], v[1], "-", "-", "-", None, None))
+# the f32 streaming kernel on the same workload (bench.py --kernel 6)
+p6 = os.path.join(src, "bench_f32.json")
+if os.path.exists(p6):
+    b6 = json.load(open(p6)); shutil.copy(p6, os.path.join(dst, f"{rnd}_final_bench_f32.json"))
+    st6 = stats("headline_f32"); k6, v6 = find(st6, "fir_mfma_stream")
+    if k6:
+        c6 = counters("headline_f32", "fir_mfma_stream")
+        tf6 = spl * b6["roofline"]["flop_per_sample_executed"] / (v6[1] * 1e-9) / 1e12
+        tr6 = int(c6["FETCH_SIZE"] * 1024 * 2 + c6["WRITE_SIZE"] * 1024) if ("FETCH_SIZE" in c6 and "WRITE_SIZE" in c6) else None
+        rows.append((f"headline workload on the f32 streaming kernel (--kernel 6): {b6['value']} Msamples/s", k6, v6[0], v6[1], b6["roofline"]["flop_per_sample_executed"],
+                     b6["roofline"]["bytes_per_sample"], f"{tf6:.1f} TFLOP/s = {tf6 / 157.3:.3f} of f32 matrix peak", tr6, b6["roofline"]["algorithmic_bytes_per_launch"]))
+        summary.append(("headline_f32", k6, c6))
 
 # ---- the other kernels
-for case in ("matrix_B", "matrix_D4", "matrix_D32", "general_E", "general_P", "general_A", "strict", "wide", "biquad", "biquad_serial", "decimate"):
+for case in ("fixed_D4", "fixed_D32", "matrix_B", "matrix_D4", "matrix_D32", "general_E", "general_P", "general_A", "strict", "wide", "biquad", "biquad_serial", "decimate"):
     p = os.path.join(src, f"case_{case}.json")
     if not os.path.exists(p): continue
     try: info = json.loads(open(p).read().strip().splitlines()[-1])
@@ -92,7 +108,7 @@ for case in ("matrix_B", "matrix_D4", "matrix_D32", "general_E", "general_P", "g
     if info["peak"] == "hbm":
         ach = n * info["bytes_per_sample"] / (avg_ns * 1e-9) / 1e9; frac = f"{ach:.1f} GB/s = {ach / peak:.4f} of HBM peak"
     else:
-        ach = n * info["flop_per_sample"] / (avg_ns * 1e-9) / 1e12; frac = f"{ach:.2f} TFLOP/s = {ach / peak:.3f} of {punit}"
+        ach = n * info["flop_per_sample"] / (avg_ns * 1e-9) / 1e12; frac = f"{ach:.2f} {'TOP/s' if info['peak'] == 'i8' else 'TFLOP/s'} = {ach / peak:.3f} of {punit}"
     traffic = int(c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024) if ("FETCH_SIZE" in c and "WRITE_SIZE" in c) else None
     rows.append((f"{case}: {info['Msamples_per_s']} Msamples/s end to end", kname, calls, avg_ns, info["flop_per_sample"], round(info["bytes_per_sample"], 3), frac, traffic,
                  int(n * info["bytes_per_sample"])))
@@ -106,7 +122,7 @@ with open(os.path.join(dst, f"{rnd}_roofline.md"), "w") as f:
     f.write(f"bench.py (100 steps): **{bench['value']} Msamples/s** ({bench['ms_per_step']} ms/step; from cold clocks {bench['value_cold']}), "
             f"default run (20 steps): {bench20['value']}; roofline.frac {bench['roofline']['frac']} (HIP events {bench['roofline']['avg_kernel_ms']} ms per launch); "
             f"cpu_baseline {bench20.get('cpu_baseline', {}).get('value')} Msamples/s ({bench20.get('cpu_baseline', {}).get('kind')}, {bench20.get('cpu_baseline', {}).get('cores')} threads)\n\n")
-    f.write("Peaks: f32 vector/matrix 157.3 TFLOP/s, f64 matrix 78.6 TFLOP/s, HBM 8 TB/s (MI355X_MICROARCH.md).  HBM traffic = FETCH_SIZE x 2 (gfx950 wide-read "
+    f.write("Peaks: int8 matrix 5033 TOP/s dense (2 x the bf16 rate), f32 vector/matrix 157.3 TFLOP/s, f64 matrix 78.6 TFLOP/s, HBM 8 TB/s (MI355X_MICROARCH.md).  HBM traffic = FETCH_SIZE x 2 (gfx950 wide-read "
             "correction) + WRITE_SIZE of the kernel's last dispatch, separate --pmc passes.\n\n")
     f.write("| config | kernel | launches | avg us (rocprofv3) | flop / sample | bytes / sample | achieved vs peak | HBM traffic / algorithmic bytes |\n|---|---|---|---|---|---|---|---|\n")
     for (cfg, k, calls, avg, fl, by, frac, traffic, alg) in rows:
@@ -118,6 +134,6 @@ with open(os.path.join(dst, f"{rnd}_pmc_summary.txt"), "w") as f:
         f.write(f"== {case}: {k}\n   last dispatch {c.get('_ns', 0) / 1e3:.1f} us  grid {c.get('_grid')} vgpr {c.get('_vgpr')} lds {c.get('_lds')} scratch {c.get('_scratch')}\n")
         for name, v in sorted(c.items()):
             if not name.startswith("_"): f.write(f"   {name:28s} {v:.6g}\n")
-for extra in ("configs.jsonl", "wide.jsonl", "host_api.txt", "art_timing.txt"):
+for extra in ("configs.jsonl", "wide.jsonl", "host_api.txt", "art_timing.txt", "fixed_point_shapes.txt"):
     if os.path.exists(os.path.join(src, extra)): shutil.copy(os.path.join(src, extra), os.path.join(dst, f"{rnd}_{extra}"))
 print(open(os.path.join(dst, f"{rnd}_roofline.md")).read())
