@@ -28,9 +28,8 @@ struct MfmaGeom {
 
 // fir_matrix_i8.hip: the fixed-point kernel of regular launches
 size_t artfir_i8_bytes (const ArtFirArgs *a, const MfmaGeom &g, int cgt);         // device bytes of a launch's digit planes (0: not for it)
-// stage + main kernel of one launch; *gate / *gate_value: the f32 streaming kernel enqueued behind runs iff *gate == gate_value
-int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGeom &g, int cgt, unsigned int roll_blocks,
-                      const int **gate, int *gate_value, hipStream_t st);
+// stage + main kernel of one launch (1), or 0: not for this path (no planes, shape)
+int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGeom &g, int cgt, unsigned int roll_blocks, hipStream_t st);
 
 namespace {
 

@@ -26,7 +26,7 @@
 // takes every g-th period (g = 4 / gcd (Q, 4)) so that all its columns start at the same offset r in their first block; r is
 // absorbed by the tile's filter rows, which exist once per (slot tile, residue) shifted r taps to the right.  A digit planes:
 // [slot tile * g + residue][chunk][p][row][32 taps]: the 4 KB a workgroup stages per chunk are contiguous.
-#include "fir_matrix_common.hip.h"
+#include "fir_matrix_stream.hip.h"
 #include <atomic>
 #include <cstdlib>
 
@@ -224,7 +224,14 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
         }
         return;
     }
-    if (*q.flag == q.epoch) return;                                      // (uniform) samples the digits cannot hold: the f32 kernel behind this one runs
+    // Samples the digits cannot hold (flag raised by the staging pass; uniform): the launch is produced in f32 by the streaming
+    // kernel's own tile loop on this kernel's workgroups and LDS (its 2 x 32 rows and 2 x 128 columns of 36 floats fit the
+    // digit buffers), from the tables the staging pass has left for it — the bits of fir_mfma_stream_kernel.
+    if (*q.flag == q.epoch) {
+        static_assert (sizeof (As_) >= 2 * 32 * MF_LD * sizeof (float) && sizeof (Bs_) >= 2 * MF_COLS * MF_LD * sizeof (float), "the f32 tiles live in the digit buffers");
+        mfma_stream_tiles<CG, PASS> (a, g, wgs_per_xcd, reinterpret_cast<float (*) [32 * MF_LD]> (&As_ [0] [0] [0]), reinterpret_cast<float (*) [MF_COLS * MF_LD]> (&Bs_ [0] [0] [0]));
+        return;
+    }
 
     const int xcd = blockIdx.x & 7, rank = blockIdx.x >> 3;
     const int tiles_per_xcd = q.sg_per_xcd * q.g * g.slot_tiles;
@@ -448,8 +455,7 @@ size_t artfir_i8_bytes (const ArtFirArgs *a, const MfmaGeom &g, int cgt)
     return i8_layout (a, g, cgt, q, nullptr);
 }
 
-int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGeom &g, int cgt, unsigned int roll_blocks,
-                      const int **gate, int *gate_value, hipStream_t st)
+int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGeom &g, int cgt, unsigned int roll_blocks, hipStream_t st)
 {
     static std::atomic<int> launches {0};
     I8Geom q;
@@ -460,7 +466,6 @@ int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGe
     if (ep <= 0) { launches = 1; ep = 1; }                             // (the flag word is zero when the buffer is allocated)
     q.epoch = ep;
     if (a->fixed_out) { a->fixed_out [0] = ep; a->fixed_out [1] = g.slot_tiles * q.g * 32; a->fixed_out [2] = g.ktot / I8_KC; }
-    *gate = q.flag; *gate_value = ep;
 
     const unsigned int x_wgs = (unsigned int)(((size_t) q.x_blocks * a->C + 255) / 256);
     const dim3 pgrid ((unsigned int)(g.slot_tiles * q.g) * 32u + x_wgs);
