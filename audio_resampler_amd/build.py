@@ -22,7 +22,7 @@ C_SOURCES = ["resampler_host.c", "pcm_host.c", "extrapolate_host.c", "stretch_ho
 HIP_SOURCES = ["device_rt.hip", "fir_general.hip", "fir_matrix.hip", "fir_matrix_i8.hip", "fir_matrix64.hip", "fir_dispatch.hip", "pcm_kernels.hip", "stretch_kernels.hip"]
 # per-file extra flags (tried: -fno-slp-vectorize on pcm_kernels.hip — 10 % slower, so none)
 EXTRA_FLAGS = {}
-HEADERS = [os.path.join(CSRC, h) for h in ("art_internal.h", "fir_internal.h", "fir_common.hip.h", "fir_matrix_common.hip.h", "fir_matrix_stream.hip.h")] + [os.path.join(INC, h) for h in ("art_hip.h", "resampler.h", "biquad.h", "decimator.h", "stretch.h")]
+HEADERS = [os.path.join(CSRC, h) for h in ("art_internal.h", "fir_internal.h", "fir_common.hip.h", "fir_matrix_common.hip.h", "fir_matrix_stream.hip.h", "fir_matrix_stream_body.inc")] + [os.path.join(INC, h) for h in ("art_hip.h", "resampler.h", "biquad.h", "decimator.h", "stretch.h")]
 
 
 def _stale(target, deps):

@@ -497,9 +497,14 @@ __global__ __launch_bounds__ (2 * MF_THREADS) __attribute__ ((amdgpu_waves_per_e
 void fir_mfma_stream_kernel (ArtFirArgs a, MfmaGeom g, int wgs_per_xcd)
 {
     constexpr int THREADS = 2 * MF_THREADS;
+    constexpr int PPW = MF_COLS / CG > MF_MAX_PPW ? MF_MAX_PPW : MF_COLS / CG;
+    constexpr int NCOLS = PPW * CG;
     __shared__ __attribute__ ((aligned (16))) float As_ [2] [32 * MF_LD];
     __shared__ __attribute__ ((aligned (16))) float Bs_ [2] [MF_COLS * MF_LD];
-    const int tid = threadIdx.x;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool loader = wave >= 4;
+    const int pt = tid & (MF_THREADS - 1);
 
     const unsigned int stream_blocks = 8u * (unsigned int) wgs_per_xcd;
     if (blockIdx.x >= stream_blocks) {                        // extra workgroups: the history roll (as in fir_mfma_kernel)
@@ -516,8 +521,8 @@ void fir_mfma_stream_kernel (ArtFirArgs a, MfmaGeom g, int wgs_per_xcd)
         return;
     }
 
-    // (the tile loop: fir_matrix_stream.hip.h — also the fixed-point kernel's stand-by)
-    mfma_stream_tiles<CG, PASS> (a, g, wgs_per_xcd, As_, Bs_);
+    // (the tile loop, shared as text with the fixed-point kernel's stand-by)
+#include "fir_matrix_stream_body.inc"
 }
 } // namespace
 

@@ -196,6 +196,21 @@ template <> struct PlaneLoad<4> { static __device__ __forceinline__ void load (u
 // Persistent workgroups over the tiles of a regular launch, as fir_mfma_stream_kernel: waves 4-7 stage (global -> registers ->
 // LDS, two chunks ahead, one chunk stream across all of the workgroup's tiles), waves 0-3 multiply (32 slots x 32 columns each).
 // A tile = (slot tile st, residue jr, super group sg): slots st*32.., periods sg*g*PPW + jr + g*m for column group m.
+// the f32 streaming kernel's tile loop on this kernel's workgroups (the LDS handed in: the digit buffers, big enough for its
+// 2 x 32 rows and 2 x 128 columns of MF_LD floats); inlined: as a real call it cost the main loop 12 spilt registers and a stack frame, 72 -> 59 Gsamples/s
+template <int CG, bool PASS>
+__device__ __forceinline__ void stand_by_tiles (const ArtFirArgs &a, const MfmaGeom &g, int wgs_per_xcd, float (&As_) [2] [32 * MF_LD], float (&Bs_) [2] [MF_COLS * MF_LD])
+{
+    constexpr int THREADS = 2 * MF_THREADS;
+    constexpr int PPW = MF_COLS / CG > MF_MAX_PPW ? MF_MAX_PPW : MF_COLS / CG;
+    constexpr int NCOLS = PPW * CG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool loader = wave >= 4;
+    const int pt = tid & (MF_THREADS - 1);
+    (void) THREADS;
+#include "fir_matrix_stream_body.inc"
+}
+
 template <int CG, bool PASS>
 __global__ __launch_bounds__ (2 * MF_THREADS) __attribute__ ((amdgpu_waves_per_eu (4, 4)))
 void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
@@ -229,7 +244,7 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
     // digit buffers), from the tables the staging pass has left for it — the bits of fir_mfma_stream_kernel.
     if (*q.flag == q.epoch) {
         static_assert (sizeof (As_) >= 2 * 32 * MF_LD * sizeof (float) && sizeof (Bs_) >= 2 * MF_COLS * MF_LD * sizeof (float), "the f32 tiles live in the digit buffers");
-        mfma_stream_tiles<CG, PASS> (a, g, wgs_per_xcd, reinterpret_cast<float (*) [32 * MF_LD]> (&As_ [0] [0] [0]), reinterpret_cast<float (*) [MF_COLS * MF_LD]> (&Bs_ [0] [0] [0]));
+        stand_by_tiles<CG, PASS> (a, g, wgs_per_xcd, *reinterpret_cast<float (*) [2] [32 * MF_LD]> (&As_ [0] [0] [0]), *reinterpret_cast<float (*) [2] [MF_COLS * MF_LD]> (&Bs_ [0] [0] [0]));
         return;
     }
 
