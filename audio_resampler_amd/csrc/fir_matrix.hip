@@ -609,10 +609,10 @@ size_t artfir_planes_bytes (const ArtFirArgs *a, unsigned int outputs, int kerne
     if (!a->period_out || a->mode != ART_MODE_FAST || kernel_pref == 5 || kernel_pref == 6) return 0;
     // Where it pays (MI355X, tools/bench_shapes.py with and without ARTAMD_NO_FIXED, profiles/r2_fixed_point_shapes.txt): the
     // integer kernel gains in proportion to outputs x channels x taps, its staging pass costs in proportion to the input
-    // and its launches ~8 us: long filters and big calls win (8 ch x 988 taps: from ~110k frames per call, +20 % at 1M;
+    // and its extra launch ~4 us: long filters and big calls win (8 ch x 988 taps: from ~90k frames per call, +27 % at 1M;
     // 4 and 32 channels alike), 380-tap and shorter filters lose at every size (13 chunks per tile: the f32 kernel is not
     // matrix-bound there).  kernel_pref 7 takes the fixed-point kernel wherever it can run.
-    if (kernel_pref != 7 && (a->T < 512 || (double) outputs * a->C * a->T < 1.0e9)) return 0;
+    if (kernel_pref != 7 && (a->T < 512 || (double) outputs * a->C * a->T < 8.5e8)) return 0;
     static const bool off = [] { const char *e = getenv ("ARTAMD_NO_FIXED"); return e && *e && *e != '0'; } ();
     if (off) return 0;
     MfmaGeom g;
