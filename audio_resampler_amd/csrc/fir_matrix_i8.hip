@@ -361,6 +361,11 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
     }
 
     // ---- matrix waves ----
+    {   // the two workgroups of a CU share each SIMD's matrix pipe: left alone their matrix waves fall into step (both multiply, then
+        // both wait for the LDS and the barrier); different issue priorities make them alternate instead
+        const unsigned int hw_id = __builtin_amdgcn_s_getreg ((4 - 1) << 11 | 16 << 6 | 4);      // HW_ID.TG_ID: bits 19:16
+        if (hw_id & 1u) __builtin_amdgcn_s_setprio (3); else __builtin_amdgcn_s_setprio (0);
+    }
     const int aoff = (lane & 31) * I8_PITCH + (lane >> 5) * 16;
     const int col = wave * 32 + (lane & 31);
     const bool col_live = col < NCOLS;
