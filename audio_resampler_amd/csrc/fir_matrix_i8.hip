@@ -494,10 +494,13 @@ int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGe
     if (a->ev_start) arthip_event_record (a->ev_start, (void *) st);
 
     const int tiles_per_xcd = q.sg_per_xcd * q.g * g.slot_tiles;
-    const int resident = 64;                                           // 32 CUs per XCD x 2 workgroups (60 KB of LDS each)
-    int rounds = (tiles_per_xcd + resident - 1) / resident;
-    { static const int k_env = [] { const char *e = getenv ("ARTAMD_TILES_PER_WG"); return e && *e ? atoi (e) : 0; } (); if (k_env > 0) rounds = k_env; }
-    const int wgs_per_xcd = (tiles_per_xcd + rounds - 1) / rounds;
+    // As many workgroups as the XCD holds (32 CUs x 2: 60 KB of LDS, 128 registers each), each striding the XCD's tile list;
+    // the last, partly filled round then runs with one workgroup per CU and its tiles finish sooner.  (Equal shares — 56
+    // workgroups x 5 tiles for the headline's 280 — kept 8 slots idle for the whole launch: 0.1078 vs 0.1039 ms; 4 and 32
+    // channels, 256k..1M frames, 96k -> 44.1k: 3..9 % the same way.  ARTAMD_I8_WGS overrides, for experiments.)
+    const int resident = 64;
+    int wgs_per_xcd = tiles_per_xcd < resident ? tiles_per_xcd : resident;
+    { static const int k_env = [] { const char *e = getenv ("ARTAMD_I8_WGS"); return e && *e ? atoi (e) : 0; } (); if (k_env > 0 && k_env < tiles_per_xcd) wgs_per_xcd = k_env; }
     const dim3 sgrid ((unsigned int)(8 * wgs_per_xcd) + roll_blocks);
     const bool pass = !a->interpolate && !a->lowpass;
 #define I8_GO(CGT) do { if (pass) hipLaunchKernelGGL ((fir_i8_stream_kernel<CGT, true>), sgrid, dim3 (2 * MF_THREADS), 0, st, *a, g, q, wgs_per_xcd); \

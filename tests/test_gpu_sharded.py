@@ -46,11 +46,13 @@ def _run(r, x, blocks, cap):
     return np.concatenate(outs)
 
 
-@pytest.mark.parametrize("mode", ["strict", "general", "mfma"])
+@pytest.mark.parametrize("mode", ["strict", "general", "mfma", "fixed_point"])
 def test_eight_four_channel_contexts_equal_one_32_channel_context(mode):
     """slice-then-resample == resample-then-slice for the PRODUCT: 8 HIP contexts of 4 channels (what 8 GPUs would run) against
-    one 32-channel HIP context, bit for bit — strict order, and each fast kernel with itself"""
-    flags, kernel = (BH | INTERP | STRICT, 0) if mode == "strict" else (BH | INTERP, 1 if mode == "general" else 2)
+    one 32-channel HIP context, bit for bit — strict order, and each fast kernel with itself (6: the f32 matrix kernels — left alone
+    the 32-channel calls are big enough for the fixed-point kernel, the 4-channel ones are not; 7: the fixed-point kernel on both
+    sides, whose exact sums do not depend on how channels are grouped into tiles)"""
+    flags, kernel = (BH | INTERP | STRICT, 0) if mode == "strict" else (BH | INTERP, {"general": 1, "mfma": 6, "fixed_point": 7} [mode])
     frames = 6000 if mode == "strict" else 40000
     x = _stream(32, frames)
     blocks = [frames // 3, frames - frames // 3]
