@@ -678,14 +678,13 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
         // one-tile-per-workgroup kernel (identical results; comparisons, tests).
         if (regular) {
             const int tiles_per_xcd = g.groups_per_xcd * g.slot_tiles;
-            const int resident = 96;                                        // 32 CUs per XCD x 3 workgroups (80 VGPRs, 46 KB of LDS)
-            // a static share per workgroup costs up to one tile time at the end: worth it from three rounds on, or when the
-            // second of two rounds is nearly full (measured: 4 channels x 1M frames = 139 tiles per XCD, one tile per
-            // workgroup 0.095 ms, two 0.110; 8 channels = 280 tiles, three per workgroup 0.167, one 0.171)
-            int rounds = (tiles_per_xcd + resident - 1) / resident;
-            if (rounds == 2 && tiles_per_xcd < 170) rounds = 1;
-            { static const int k_env = [] { const char *e = getenv ("ARTAMD_TILES_PER_WG"); return e && *e ? atoi (e) : 0; } (); if (k_env > 0) rounds = k_env; }
-            const int wgs_per_xcd = (tiles_per_xcd + rounds - 1) / rounds;
+            // As many workgroups as stay resident — 32 CUs per XCD x 3 (80 VGPRs, 46 KB of LDS), less two slots for the history-roll
+            // workgroups of the same grid — each striding the XCD's tile list: a partly filled last round runs with fewer
+            // workgroups per CU and finishes sooner.  (Measured: 4 channels x 1M frames = 139 tiles per XCD: 0.0888 ms, one tile
+            // per workgroup 0.0948, two each 0.110; 8 channels = 280 tiles: the same 94 workgroups as equal shares of three.)
+            const int resident = 94;
+            int wgs_per_xcd = tiles_per_xcd < resident ? tiles_per_xcd : resident;
+            { static const int k_env = [] { const char *e = getenv ("ARTAMD_TILES_PER_WG"); return e && *e ? atoi (e) : 0; } (); if (k_env > 0) wgs_per_xcd = (tiles_per_xcd + k_env - 1) / k_env; }
             const dim3 sgrid ((unsigned int)(8 * wgs_per_xcd) + roll_blocks);
 #define MS_GO_(I, CGT, PS) hipLaunchKernelGGL ((fir_mfma_stream_kernel<I, CGT, PS>), sgrid, dim3 (2 * MF_THREADS), 0, st, *a, g, wgs_per_xcd)
 #define MS_GO(I, CGT) do { if (!I && !a->lowpass) MS_GO_ (false, CGT, true); else MS_GO_ (I, CGT, false); } while (0)

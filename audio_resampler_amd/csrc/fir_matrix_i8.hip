@@ -494,11 +494,12 @@ int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGe
     if (a->ev_start) arthip_event_record (a->ev_start, (void *) st);
 
     const int tiles_per_xcd = q.sg_per_xcd * q.g * g.slot_tiles;
-    // As many workgroups as the XCD holds (32 CUs x 2: 60 KB of LDS, 128 registers each), each striding the XCD's tile list;
-    // the last, partly filled round then runs with one workgroup per CU and its tiles finish sooner.  (Equal shares — 56
-    // workgroups x 5 tiles for the headline's 280 — kept 8 slots idle for the whole launch: 0.1078 vs 0.1039 ms; 4 and 32
-    // channels, 256k..1M frames, 96k -> 44.1k: 3..9 % the same way.  ARTAMD_I8_WGS overrides, for experiments.)
-    const int resident = 64;
+    // As many workgroups as the XCD holds (32 CUs x 2: 60 KB of LDS, 128 registers each) less two slots for the history-roll
+    // workgroups of the same grid, each striding the XCD's tile list; the last, partly filled round then runs with one
+    // workgroup per CU and its tiles finish sooner.  (Equal shares — 56 workgroups x 5 tiles for the headline's 280 — kept 8
+    // slots idle for the whole launch: 0.1078 ms, 64 workgroups 0.1039, 62 0.1029; 4 and 32 channels, 256k..1M frames,
+    // 96k -> 44.1k: 3..9 % the same way.  ARTAMD_I8_WGS overrides, for experiments.)
+    const int resident = 62;
     int wgs_per_xcd = tiles_per_xcd < resident ? tiles_per_xcd : resident;
     { static const int k_env = [] { const char *e = getenv ("ARTAMD_I8_WGS"); return e && *e ? atoi (e) : 0; } (); if (k_env > 0 && k_env < tiles_per_xcd) wgs_per_xcd = k_env; }
     const dim3 sgrid ((unsigned int)(8 * wgs_per_xcd) + roll_blocks);
