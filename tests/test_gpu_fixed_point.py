@@ -145,3 +145,26 @@ def test_fixed_point_kernel_skips_the_zero_digit_plane_and_is_chosen_where_it_pa
         assert u == frames and r.last_kernel() == 2 and state == want, (ch, T, frames, state)
         if want:
             assert 9.0 < pairs < 10.0, pairs
+
+
+def test_fixed_point_long_call_with_many_ring_epochs():
+    """one call of 2.2 M frames x 2 channels x 988 taps: > 192 ring epochs, so several launches with n_begin > 0, each with its own
+    staging pass — every launch in fixed point, the whole call inside the bar of the double-accumulate oracle and within a
+    rounding or two of the f32 matrix kernel"""
+    ch, T, frames = 2, 988, 2200000
+    ratio = 48000 / 44100
+    x, _ = noise(frames * ch)
+    x = x.reshape(frames, ch)
+    outs = {}
+    for kernel in (7, 6):
+        r = HipResampler(ch, T, T, 0.0, BH | INTERP, kernel=kernel); r.advance(T / 2)
+        u, g, y = r.process(x, int(frames * ratio) + 4000, ratio)
+        assert u == frames and r.last_kernel() == 2 and r.fixed_point() [0] == (1 if kernel == 7 else 0)
+        outs [kernel] = np.array(y)
+    assert outs [7].shape == outs [6].shape
+    assert np.all(np.abs(outs [7].astype(np.float64) - outs [6].astype(np.float64)) <= 2.0 ** -22)
+    o = OracleResampler(ch, T, T, 0.0, BH | INTERP | PRECISE); o.advance(T / 2)
+    n = 300000                                               # (the oracle on the first 300k frames: the first launches' seams)
+    uo, go, yo = o.process(x [:n], int(n * ratio) + 4000, ratio, threads=2)
+    yo = np.array(yo)
+    assert tolerance_ok(outs [7] [:len(yo) - 2000], yo [:len(yo) - 2000]) [0]

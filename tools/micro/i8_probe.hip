@@ -72,6 +72,70 @@ __global__ __launch_bounds__ (512) void k_rate (int *out, int chunks)
     out [blockIdx.x * 256 + tid] = s;
 }
 
+// The same work organised as ONE 12-wave workgroup per CU: waves 0-7 multiply two independent tiles (waves 0-3 / 4-7), each with
+// TWO operand register sets (the reads of chunk c + 1 land while the products of chunk c issue), waves 8-11 stage both tiles.
+// NINE products per chunk (the common case of the kernel: the top digit plane of the rows is zero).  TWIN = false: the
+// eight-wave form above with nine products, for comparison (run at two workgroups per CU).
+template <bool TWIN>
+__global__ __launch_bounds__ (TWIN ? 768 : 512) void k_shape (int *out, int chunks)
+{
+    constexpr int TILES = TWIN ? 2 : 1;
+    __shared__ __attribute__ ((aligned (16))) unsigned char As [TILES] [2] [4] [32 * PITCH];
+    __shared__ __attribute__ ((aligned (16))) unsigned char Bs [TILES] [2] [4] [128 * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < (int) sizeof (As) / 4; e += blockDim.x) reinterpret_cast<int *> (As) [e] = e * 2654435761u;
+    for (int e = tid; e < (int) sizeof (Bs) / 4; e += blockDim.x) reinterpret_cast<int *> (Bs) [e] = e * 40503u;
+    __syncthreads ();
+    if (wave >= 4 * TILES) {
+        const int pt = tid & 255;
+        int v = pt;
+        for (int c = 0; c < chunks; ++c) {
+            const int buf = (c & 1) ^ 1;
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        *reinterpret_cast<int *> (&Bs [t] [buf] [u] [((pt >> 4) * 8 + (pt & 1) * 4 + e) * PITCH + ((pt >> 1) & 7) * 4]) = v + e;
+                i32x4 w = { v, v + 1, v + 2, v + 3 };
+                *reinterpret_cast<i32x4 *> (&As [t] [buf] [pt >> 6] [((pt >> 1) & 31) * PITCH + (pt & 1) * 16]) = w;
+            }
+            v += 7;
+            __syncthreads ();
+        }
+        return;
+    }
+    const int tile = wave >> 2, w4 = wave & 3;
+    i32x16 acc [5];
+    for (int s = 0; s < 5; ++s) for (int r = 0; r < 16; ++r) acc [s] [r] = 0;
+    const int aoff = (lane & 31) * PITCH + (lane >> 5) * 16, boff = (w4 * 32 + (lane & 31)) * PITCH + (lane >> 5) * 16;
+    auto rd = [&] (i32x4 (&a) [4], i32x4 (&b) [4], int buf) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { a [p] = *reinterpret_cast<const i32x4 *> (&As [tile] [buf] [p] [aoff]); b [p] = *reinterpret_cast<const i32x4 *> (&Bs [tile] [buf] [p] [boff]); }
+    };
+    auto mm = [&] (const i32x4 (&a) [4], const i32x4 (&b) [4]) {
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (i + j < 5) acc [i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8 (a [i], b [j], acc [i + j], 0, 0, 0);
+    };
+    i32x4 a0 [4], b0 [4], a1 [4], b1 [4];
+    if (TWIN) {
+        rd (a0, b0, 0);
+        for (int c = 0; c < chunks; c += 2) {
+            rd (a1, b1, 1); mm (a0, b0); __syncthreads ();
+            rd (a0, b0, 0); mm (a1, b1); __syncthreads ();
+        }
+    }
+    else {
+        for (int c = 0; c < chunks; ++c) { rd (a0, b0, c & 1); __syncthreads (); mm (a0, b0); }
+    }
+    int s = 0; for (int q = 0; q < 5; ++q) for (int r = 0; r < 16; ++r) s += acc [q] [r];
+    out [blockIdx.x * 256 + (tid & 255)] = s;
+}
+
 template <typename F> double timeit (F launch)
 {
     hipEvent_t e0, e1; hipEventCreate (&e0); hipEventCreate (&e1);
@@ -113,6 +177,12 @@ int main ()
         RUN (0, 5, "registers"); RUN (1, 5, "LDS reads"); RUN (2, 5, "LDS reads + staging writes + barrier");
         RUN (0, 4, "registers"); RUN (1, 4, "LDS reads"); RUN (2, 4, "LDS reads + staging writes + barrier");
         RUN (1, 1, "LDS reads, one product"); RUN (2, 1, "LDS reads + staging writes + barrier, one product"); RUN (3, 1, "LDS reads + barrier (8 waves), one product"); RUN (3, 5, "LDS reads + barrier (8 waves)");
+    }
+    {
+        double ms = timeit ([&] { hipLaunchKernelGGL ((k_shape<false>), dim3 (512), dim3 (512), 0, 0, out, chunks); });
+        printf ("two 8-wave workgroups per CU, 9 products per chunk, one operand set : %7.3f ms  %6.0f cycles per chunk and tile at 2.4 GHz\n", ms, ms * 1e-3 * 2.4e9 / chunks / 2);
+        ms = timeit ([&] { hipLaunchKernelGGL ((k_shape<true>), dim3 (256), dim3 (768), 0, 0, out, chunks); });
+        printf ("one 12-wave workgroup per CU (two tiles), 9 products, two operand sets : %7.3f ms  %6.0f cycles per chunk and tile at 2.4 GHz\n", ms, ms * 1e-3 * 2.4e9 / chunks / 2);
     }
     return 0;
 }
