@@ -229,3 +229,28 @@ def test_context_uses_its_own_device_whatever_the_caller_selected():
     x = _stream(2, 500)
     u, g, y = r.process(x, 2000, R)
     assert u == 500 and g > 0 and torch.cuda.current_device() == A.lib().resampleHipGetDevice(r.p)
+
+
+def test_sharded_context_runs_its_shards_in_fixed_point_with_the_same_bits(eight_shards):
+    """a 32-channel RESAMPLE_MULTITHREADED context whose 4-channel shards are each big enough for the fixed-point matrix kernel
+    (kernel preference 7 on both sides): exact integer sums do not care how the channels are grouped, so the sharded context —
+    eight leaves, eight streams, eight sets of digit planes — equals the ordinary one bit for bit, host-pointer calls and
+    device-pointer calls alike"""
+    ch, frames = 32, 120000
+    x = _stream(ch, frames)
+    plain, sharded = _pair(ch, BH | INTERP)
+    assert len(sharded.shards()) == 8
+    cap = int(frames * R) + 2000
+    outs = []
+    for r in (plain, sharded):
+        r.advance(T / 2)
+        r.set_kernel(7)
+        u, g, y = r.process(x, cap, R)
+        assert u == frames and r.last_kernel() == 2 and r.fixed_point() [0] == 1
+        d_in, d_out = torch.from_numpy(x).cuda(), torch.zeros(cap, ch, device="cuda")
+        u2, g2 = r.process_device(d_in, frames, d_out, cap, R)
+        r.synchronize(); torch.cuda.synchronize()
+        outs.append((g, np.array(y).copy(), g2, d_out [:g2].cpu().numpy()))
+    assert outs [0] [0] == outs [1] [0] and outs [0] [2] == outs [1] [2]
+    assert np.array_equal(outs [0] [1].view(np.uint32), outs [1] [1].view(np.uint32))
+    assert np.array_equal(outs [0] [3].view(np.uint32), outs [1] [3].view(np.uint32))
