@@ -1,7 +1,7 @@
 """Long randomised comparison of the matrix-core FIR path against the oracle on LARGE blocks (the pytest fuzz uses blocks of a
 few taps, which mostly exercise the tiles at the history seam): random channel counts (every compiled column group and
 generic ones), taps, rational ratios, block sizes up to a few hundred thousand frames, several calls per stream + flush.
-Default sample width and the 8-byte build.  Usage: python tools/fuzz_long.py [--seconds S] [--seed N]  (GPU box; CPU oracle)."""
+Default sample width and the 8-byte build.  Usage: python tools/fuzz_long.py [--seconds S] [--seed N] [--kernel 7]  (GPU box; CPU oracle)."""
 import argparse, os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -10,7 +10,7 @@ import audio_resampler_amd as A
 import _oracle
 from _hip import tolerance_ok
 
-ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=240); ap.add_argument("--seed", type=int, default=1); ap.add_argument("--budget", type=float, default=4e8)
+ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=240); ap.add_argument("--seed", type=int, default=1); ap.add_argument("--budget", type=float, default=4e8); ap.add_argument("--kernel", type=int, default=2, help="kernel preference of the 4-byte contexts: 2 matrix path (automatic among its kernels), 7 fixed point wherever it can run")
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
 BH, INTERP, LOWPASS, PRECISE = _oracle.BH, _oracle.INTERP, _oracle.LOWPASS, _oracle.PRECISE
@@ -42,7 +42,7 @@ while time.time() < t_end:
         h, o = mk_h(), mk_o()
     except Exception as e:
         continue
-    h.set_kernel(2)
+    h.set_kernel(2 if wide else args.kernel)
     adv = T / 2
     h.advance(adv); o.advance(adv)
     x = (rng.random((sum(calls) + 8, ch)) - 0.5).astype(dt)
