@@ -102,20 +102,22 @@ def test_fixed_point_kernel_over_the_amplitude_range(amplitude):
 BAD = [("above the range", 2.5), ("below the range", -1.99), ("infinity", np.inf), ("NaN", np.nan)]
 
 
+@pytest.mark.parametrize("shape", [(8, 988, 988, BH | INTERP), (2, 380, 320, BH)], ids=["c8_t988_interp", "c2_t380_f320_nearest_passthrough"])
 @pytest.mark.parametrize("what,value", BAD, ids=[b [0].replace(" ", "_") for b in BAD])
-def test_samples_the_digits_cannot_hold_hand_the_launch_to_the_f32_kernel(what, value):
+def test_samples_the_digits_cannot_hold_hand_the_launch_to_the_f32_kernel(what, value, shape):
     """one such sample anywhere in the call, or in the history it still convolves with: the fixed-point kernel stands down on the
     device and the f32 streaming kernel behind it produces the call — the same bits as with that kernel pinned; calls that do
     not touch the sample run in fixed point again"""
-    ch, T, frames = 8, 988, 60000
+    ch, T, F, flags = shape
+    frames = 60000
     ratio = 48000 / 44100
     x, _ = noise(4 * frames * ch, state=0xBAD5A | 1)
     x = x.reshape(4 * frames, ch).copy()
-    x [frames + frames // 2, 3] = value                      # in the second call
-    x [3 * frames - 40, 5] = value                           # at the end of the third: still in the fourth call's history
+    x [frames + frames // 2, ch // 2] = value                 # in the second call
+    x [3 * frames - 40, ch - 1] = value                           # at the end of the third: still in the fourth call's history
     states, outs = [], {}
     for kernel in (7, 6):
-        r = HipResampler(ch, T, T, 0.0, BH | INTERP, kernel=kernel); r.advance(T / 2)
+        r = HipResampler(ch, T, F, 0.0, flags, kernel=kernel); r.advance(T / 2)
         outs [kernel] = []
         for k in range(4):
             u, g, y = r.process(x [k * frames:(k + 1) * frames], int(frames * ratio) + 4000, ratio)
