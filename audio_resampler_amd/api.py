@@ -117,6 +117,7 @@ def _bind(width):
         "resampleHipLastFixedPoint": (C.c_int, [RP, C.POINTER(C.c_double)]),
         "resampleHipSetTiming": (None, [RP, C.c_int]),
         "resampleHipReadTiming": (C.c_double, [RP, C.POINTER(C.c_int)]),
+        "resampleHipReadPrepTiming": (C.c_double, [RP]),
         "resampleProcessInterleavedDevice": (ResampleResult, [RP, ptr, C.c_int, ptr, C.c_int, C.c_double]),
         "resampleProcessAndFlushInterleavedDevice": (ResampleResult, [RP, ptr, C.c_int, ptr, C.c_int, C.c_double]),
         "resampleProcessPlanarDevice": (ResampleResult, [RP, ptr, C.c_long, C.c_int, ptr, C.c_long, C.c_int, C.c_double]),
@@ -269,6 +270,10 @@ def _bind(width):
             n = C.c_int()
             ms = self.L.resampleHipReadTiming(self.p, C.byref(n))
             return ms, n.value
+
+        def read_prep_timing(self):
+            """milliseconds the launches of the last read_timing() spent before their dominant kernel (table / staging passes)"""
+            return self.L.resampleHipReadPrepTiming(self.p)
 
         # -- host-pointer API (numpy) --
         def process(self, x, out_cap, ratio, flush=False, and_flush=False, threads=1):

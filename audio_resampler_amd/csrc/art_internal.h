@@ -18,6 +18,13 @@ typedef artsample_t art_s;   /* the sample type of this build */
 extern "C" {
 #endif
 
+/* header of a context's digit-plane buffer (fixed-point matrix kernel, fir_matrix_i8.hip), zeroed when the buffer is allocated:
+ * [0] stand-down flag word; [256..384) per-channel peak |x| of the launch being staged (bits of the float magnitude, zero between
+ * launches); [512..640) per-channel binary exponent the launch's samples were scaled by.  The rows' mask words follow the header. */
+#define ART_I8_HEAD_BYTES 1024
+#define ART_I8_PEAK_OFFSET 256
+#define ART_I8_SHIFT_OFFSET 512
+
 #define ART_MAX_SEGS 192         /* ring-epoch segments per kernel launch (passed by value: 16 B each, kernel arguments stay below 4 KB) */
 
 /* numeric modes of the FIR */
@@ -63,7 +70,8 @@ typedef struct {
     /* device memory for the fixed-point matrix kernel's digit planes of one launch (arthip_fir_planes_bytes; NULL: f32 kernels) */
     void *planes; size_t planes_bytes;
     /* host, optional, 3 ints filled when the fixed-point kernel is enqueued: the launch's flag value (the first word of
-     * `planes` equals it afterwards iff the kernel stood down), mask words behind the flag (at planes + 256), chunks per tile */
+     * `planes` equals it afterwards iff the kernel stood down), mask words behind the header (at planes + ART_I8_HEAD_BYTES),
+     * chunks per tile */
     int *fixed_out;
     /* optional HIP events recorded immediately before/after the dominant kernel's launch (host side only) */
     void *ev_start, *ev_stop;

@@ -1,8 +1,11 @@
 // fir_matrix_i8.hip — the fixed-point form of the matrix-core path (4-byte samples, gfx950): regular launches of the rational-ratio
 // GEMM (see fir_matrix.hip) evaluated EXACTLY on the integer matrix cores instead of in chained f32.
 //
-// Effective filter rows (lerp folded in, fp64) and input samples are both rounded once to 32-bit fixed point with 30 fraction
-// bits — exact for every float sample of magnitude >= 2^-7, 2^-31 absolute otherwise — and written as four signed base-256
+// Effective filter rows (lerp folded in, fp64) are rounded once to 32-bit fixed point with 30 fraction bits; input samples are
+// rounded once to 32-bit BLOCK floating point: every channel of a launch has its own binary exponent, taken from the channel's
+// peak |x| over the launch's history ++ input (i8_peak_kernel) so that the peak lands in [2^29, 2^31 - 2^23) — exact for every
+// float sample within 2^-6 of its channel's peak, (peak) x 2^-31 absolute below that: the error model is RELATIVE to the
+// channel's level in the launch, as float arithmetic's is, not tied to full scale.  Both are written as four signed base-256
 // digits each (d0 most significant: value = sum_i d_i 256^(3-i)).  The dot product of two such numbers is
 //     sum_k h_k x_k = sum_{i,j} 256^(6-i-j) sum_k a_i[k] b_j[k],
 // and each inner sum over k is one v_mfma_i32_32x32x32_i8 chain: integer, exact, order-free (|sum| < 2^14 * K * pairs < 2^31).
@@ -17,9 +20,9 @@
 // tools/micro/i8_probe.hip: 3.5 Pop/s sustained with operands from LDS beside the staging traffic), paid for with one extra
 // pass over the call's input (i8_stage_kernel: quantise + digit planes, memory-bound).
 //
-// Samples outside (-1.98, 1.98), infinities and NaNs cannot be represented: the staging pass raises a flag in device memory,
-// the fixed-point kernel then leaves the launch to the f32 streaming kernel, which is always enqueued behind it and returns
-// at once when the flag is clear (no host round trip: the device-pointer calls stay asynchronous).
+// Infinities and NaNs cannot be represented (any finite amplitude can: the exponent follows the peak): the staging pass then
+// raises a flag in device memory and the fixed-point kernel's workgroups run the f32 streaming kernel's tile loop instead (no
+// host round trip: the device-pointer calls stay asynchronous).
 //
 // Data layout.  X digit planes: plane p (digit d_p), 4-frame block b, channel c -> one dword holding frames 4b..4b+3 of that
 // channel (byte q = frame 4b + q): [p][b][c].  Linear frame lin (history ++ input) lives in block (lin + I8_PADF) / 4.  A tile
@@ -42,8 +45,8 @@ constexpr int I8_PITCH = 48;              // LDS bytes per (row or column, plane
 constexpr int I8_COLS = 128;              // columns per workgroup
 constexpr int I8_MAX_PPW = 64;
 constexpr int I8_PADF = 64;               // zero frames in front of linear frame 0 in the digit planes
-constexpr float I8_SCALE = 1073741824.0f; // 2^30
-constexpr float I8_LIMIT = 1.98f;         // |value| the digits can hold: (2^31 - 2^23) / 2^30, rounded down
+constexpr float I8_SCALE = 1073741824.0f; // 2^30: the filter rows' fixed point
+constexpr float I8_LIMIT = 1.98f;         // |row value| the digits can hold: (2^31 - 2^23) / 2^30, rounded down
 
 struct I8Geom {
     int g;                                // period stride inside a tile
@@ -57,7 +60,63 @@ struct I8Geom {
     unsigned int x_blocks;                // 4-frame blocks per plane
     size_t x_plane_bytes;                 // x_blocks * C * 4
     int *flag; int epoch;                 // *flag == epoch: this launch cannot run in fixed point (set by the staging pass)
+    unsigned int *peak;                   // [C] bits of the channel's peak |x| over history ++ input (i8_peak_kernel; zeroed again by the main kernel)
+    int *shifts;                          // [C] the channel's samples are quantised as rint (x * 2^shift) (written by the staging pass)
 };
+
+// binary exponent for a channel whose peak magnitude has these float bits: peak * 2^shift in [2^29, 2^31 - 2^23) — as large as the
+// digits hold (the top digit of (q + 0x80808080) must not overflow).  Zero and denormal peaks take the smallest normal's exponent.
+__device__ __forceinline__ int shift_of_peak (unsigned int bits)
+{
+    const int e = max ((int)(bits >> 23), 1);
+    return 157 - e - ((bits & 0x7f0000u) == 0x7f0000u ? 1 : 0);
+}
+
+// Per-channel peak |x| of a launch's history ++ input (both interleaved, 16-byte aligned, C a power of two <= 32): magnitudes
+// compared as unsigned bit patterns — monotone for finite values, infinities above them, NaNs above those.  One pass at HBM
+// speed; the staging pass behind it re-reads the same bytes from the Infinity Cache.
+constexpr int I8_PEAK_THREADS = 1024;
+__global__ __launch_bounds__ (I8_PEAK_THREADS)
+void i8_peak_kernel (ArtFirArgs a, unsigned int *peak)
+{
+    __shared__ unsigned int s_peak [32];
+    const int tid = threadIdx.x;
+    if (tid < 32) s_peak [tid] = 0u;
+    __syncthreads ();
+    const size_t stride = (size_t) gridDim.x * I8_PEAK_THREADS;   // (in 4-float vectors: 4 * stride is a multiple of C, a thread's channels never change)
+    const size_t v0 = (size_t) blockIdx.x * I8_PEAK_THREADS + tid;
+    unsigned int m [4] = { 0u, 0u, 0u, 0u };
+    auto take = [&] (const u32x4 &v) {
+        m [0] = max (m [0], v.x & 0x7fffffffu); m [1] = max (m [1], v.y & 0x7fffffffu);
+        m [2] = max (m [2], v.z & 0x7fffffffu); m [3] = max (m [3], v.w & 0x7fffffffu);
+    };
+    for (int part = 0; part < 2; ++part) {
+        const float *src = part ? a.in : a.hist;
+        const size_t n = part ? (size_t) a.in_frames * a.C : (size_t) a.H * a.C;
+        if (!src || !n) continue;
+        const u32x4 *sv = reinterpret_cast<const u32x4 *> (src);
+        const size_t nv = n / 4;
+        size_t v = v0;
+        for (; v + 3 * stride < nv; v += 4 * stride) {         // four loads in flight per thread
+            const u32x4 x0 = sv [v], x1 = sv [v + stride], x2 = sv [v + 2 * stride], x3 = sv [v + 3 * stride];
+            take (x0); take (x1); take (x2); take (x3);
+        }
+        for (; v < nv; v += stride) take (sv [v]);
+        if (v0 == 0)                                            // (up to 3 values behind the last whole vector)
+            for (size_t i = nv * 4; i < n; ++i) atomicMax (&s_peak [i % a.C], __float_as_uint (src [i]) & 0x7fffffffu);
+    }
+    // lanes that share a channel set first (xor offsets that are multiples of C / 4 lanes), then one LDS atomic per wave and channel
+    const int lanes_per_set = a.C >= 4 ? a.C / 4 : 1;
+    for (int off = 32; off >= lanes_per_set; off >>= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m [e] = max (m [e], (unsigned int) __shfl_xor ((int) m [e], off));
+    if ((tid & 63) < lanes_per_set)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (m [e]) atomicMax (&s_peak [(int)((v0 * 4 + e) % a.C)], m [e]);
+    __syncthreads ();
+    // (most workgroups find a peak some other has already reported: the plain read spares the contended atomic)
+    if (tid < a.C && s_peak [tid] > __builtin_nontemporal_load (&peak [tid])) atomicMax (&peak [tid], s_peak [tid]);
+}
 
 // digits of a fixed-point value as one dword: byte 3 = d0 ... byte 0 = d3, each signed
 __device__ __forceinline__ unsigned int digits_of (int q) { return ((unsigned int) q + 0x80808080u) ^ 0x80808080u; }
@@ -105,6 +164,11 @@ void i8_stage_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g, I8Geom q)
             if (tid == 0) {
                 g.tile_w0 [3 * st] = p0.ip - a.T / 2 + 1;
                 if (st == 0) a.fix_count [0] = 0;
+            }
+            if (st == 0 && tid < a.C) {                        // the launch's per-channel exponents, for the main kernel's final scaling
+                const unsigned int pk = q.peak [tid];
+                q.shifts [tid] = shift_of_peak (pk);
+                if (pk >= 0x7f800000u) bad = true;              // an infinity or a NaN somewhere in the channel: no exponent holds it
             }
             if (!INTERP && !a.lowpass && tid < rows_valid) {
                 const Pos pq = locate<INTERP> (a, segs, a.n_begin + st * 32 + tid);
@@ -167,7 +231,8 @@ void i8_stage_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g, I8Geom q)
     if (e >= total) return;
     const int b = (int)(e / a.C), c = (int)(e - (size_t) b * a.C);
     unsigned int s [4], pl [4];
-    bool bad = false;
+    // the channel's block exponent: |x| <= peak, so |x * 2^shift| < 2^31 - 2^23 and the scaling itself is exact (v_ldexp_f32)
+    const int shift = shift_of_peak (q.peak [c]);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int lin = 4 * b + t - I8_PADF;
@@ -176,13 +241,11 @@ void i8_stage_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g, I8Geom q)
         else if (lin >= a.H && lin - a.H < a.in_frames) v = a.in [(size_t)(lin - a.H) * a.C + c];
         // (the call's head as one contiguous float array, for the stand-by kernel's tiles that reach into the history)
         if (g.head && lin + MF_HEAD_PAD >= 0 && lin + MF_HEAD_PAD < g.head_frames) g.head [(size_t)(lin + MF_HEAD_PAD) * a.C + c] = v;
-        if (!(fabsf (v) < I8_LIMIT)) { bad = true; v = 0.0f; }
-        s [t] = digits_of (__float2int_rn (v * I8_SCALE));
+        s [t] = digits_of (__float2int_rn (ldexpf (v, shift)));   // (a channel with an infinity or a NaN: garbage, the launch is flagged)
     }
     to_planes (s, pl);
 #pragma unroll
     for (int pn = 0; pn < 4; ++pn) q.x_planes_w [(size_t) pn * (q.x_plane_bytes / 4) + e] = pl [pn];
-    if (bad) *q.flag = q.epoch;
 }
 
 template <int VEC> struct PlaneLoad;
@@ -226,6 +289,8 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
     const int pt = tid & (MF_THREADS - 1);
 
     const unsigned int stream_blocks = 8u * (unsigned int) wgs_per_xcd;
+    // (the staging pass has turned the peaks into exponents: the next launch's peak pass finds them at zero again)
+    if (blockIdx.x == 0 && tid < 32) q.peak [tid] = 0u;
     if (blockIdx.x >= stream_blocks) {                        // extra workgroups: the history roll (as in fir_mfma_kernel)
         if (a.roll_dst) {
             const int e = (int)(blockIdx.x - stream_blocks) * THREADS + tid;
@@ -374,6 +439,8 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
     // output offset of this lane inside a tile: (period jl * g, slot 4 * (lane >> 5), channel c); the row's own 0..3 / +8 / +16 / +24
     // slots are immediates of the store
     const unsigned int out_off = (unsigned int)((jl * q.g * g.P + 4 * (lane >> 5)) * CG + c) * 4u;
+    // rows carry 30 fraction bits, this lane's channel `shift`; the class sums are combined at weight 256^(4 - s) of 2^16 units
+    const double out_scale = __builtin_ldexp (1.0, -14 - q.shifts [c]);
 
     __syncthreads ();                                        // the staging waves have committed chunk 0
     int qn = 0;                                              // chunks consumed so far: chunk qn sits in LDS buffer qn & 1
@@ -426,11 +493,12 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i_const = (r & 3) + 8 * (r >> 2);      // compile-time part of the slot
-            // class sums, weights 256^(4 - s), in fp64 (|total| < 2^58: the four roundings are 2^-53 relative), scaled by 2^-44
+            // class sums, weights 256^(4 - s), in fp64 (|total| < 2^58: the four roundings are 2^-53 relative), scaled back by the
+            // rows' and the channel's exponents (a power of two: exact) and rounded ONCE to float
             double v = (double) acc [0] [r];
 #pragma unroll
             for (int s = 1; s < 5; ++s) v = v * 256.0 + (double) acc [s] [r];
-            float y = (float)(v * 0x1p-44);
+            float y = (float)(v * out_scale);
             const int i = i_const + 4 * (lane >> 5);
             if constexpr (PASS) {
                 // nearest-filter mode, the position falls exactly on an input sample: the reference copies it (resampler.c:1166-1170)
@@ -444,7 +512,8 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
 
 } // namespace
 
-// The planes buffer of a launch: [flag, 256 B][A digit planes][X digit planes]; returns its size, 0 if the launch is not for this path
+// The planes buffer of a launch: [header: flag, peaks, exponents (art_internal.h)][row masks][A digit planes][X digit planes];
+// returns its size, 0 if the launch is not for this path
 static size_t i8_layout (const ArtFirArgs *a, const MfmaGeom &g, int cgt, I8Geom &q, char *base)
 {
     if (!cgt || g.tile_rows != 32 || (g.ktot % I8_KC)) return 0;
@@ -461,9 +530,10 @@ static size_t i8_layout (const ArtFirArgs *a, const MfmaGeom &g, int cgt, I8Geom
     q.x_plane_bytes = (size_t) q.x_blocks * a->C * 4;
     if (4 * q.x_plane_bytes >= 0xffff0000ull) return 0;               // (plane offsets are 32-bit)
     if (g.ktot / I8_KC > 64) return 0;                                  // (one mask bit per chunk)
-    const size_t head = (256 + (size_t) g.slot_tiles * q.g * 32 * 8 + 255) & ~(size_t) 255;
+    const size_t head = (ART_I8_HEAD_BYTES + (size_t) g.slot_tiles * q.g * 32 * 8 + 255) & ~(size_t) 255;
     q.flag = (int *) base; q.epoch = 0;
-    q.a_masks = (unsigned long long *)(base + 256);
+    q.peak = (unsigned int *)(base + ART_I8_PEAK_OFFSET); q.shifts = (int *)(base + ART_I8_SHIFT_OFFSET);
+    q.a_masks = (unsigned long long *)(base + ART_I8_HEAD_BYTES);
     q.a_planes = (unsigned char *) base + head;
     q.x_planes_w = (unsigned int *)(base + head + a_bytes); q.x_planes = (const unsigned char *) q.x_planes_w;
     return head + a_bytes + 4 * q.x_plane_bytes;
@@ -487,6 +557,13 @@ int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGe
     q.epoch = ep;
     if (a->fixed_out) { a->fixed_out [0] = ep; a->fixed_out [1] = g.slot_tiles * q.g * 32; a->fixed_out [2] = g.ktot / I8_KC; }
 
+    {   // per-channel peaks first: enough workgroups to pull at HBM speed, each thread a few vectors deep
+        const size_t vecs = ((size_t) a->in_frames + a->H) * a->C / 4;
+        unsigned int wgs = (unsigned int)((vecs + I8_PEAK_THREADS * 8 - 1) / (I8_PEAK_THREADS * 8));
+        if (wgs > 512u) wgs = 512u;                                     // two per CU: 32 waves per CU, four 16-byte loads in flight each
+        if (wgs < 1u) wgs = 1u;
+        hipLaunchKernelGGL (i8_peak_kernel, dim3 (wgs), dim3 (I8_PEAK_THREADS), 0, st, *a, q.peak);
+    }
     const unsigned int x_wgs = (unsigned int)(((size_t) q.x_blocks * a->C + 255) / 256);
     const dim3 pgrid ((unsigned int)(g.slot_tiles * q.g) * 32u + x_wgs);
     if (a->interpolate) hipLaunchKernelGGL (i8_stage_kernel<true>, pgrid, dim3 (256), 0, st, *a, *segs, g, q);

@@ -60,7 +60,7 @@ struct artamd_resampler {
     /* cached rational structure of the current ratio */
     double period_ratio; int period_out, period_in;
     /* optional HIP-event timing of FIR launches */
-    int timing; void **ev; int ev_count, ev_cap;
+    int timing; void **ev; int ev_count, ev_cap; double prep_ms;
     art_s *d_patch; size_t patch_cap;        /* end-point extrapolation: samples computed on the host */
     void *d_scratch; size_t scratch_cap;     /* MFMA path: effective rows + canonical positions of one launch */
     void *d_planes; size_t planes_cap;       /* fixed-point matrix kernel: digit planes of one launch (flag word first) */
@@ -804,18 +804,34 @@ double resampleHipReadTiming (Resample *cxt, int *numLaunches)
     }
     ENTER_DEVICE (hip);
     arthip_sync (hip->stream);
-    for (int i = 0; i + 1 < hip->ev_count; i += 2)
-        total += arthip_event_elapsed_ms (hip->ev [i], hip->ev [i + 1]);
+    hip->prep_ms = 0.0;
+    for (int i = 0; i + 2 < hip->ev_count; i += 3) {         /* (before the launch's first kernel, before its dominant kernel, after it) */
+        hip->prep_ms += arthip_event_elapsed_ms (hip->ev [i], hip->ev [i + 1]);
+        total += arthip_event_elapsed_ms (hip->ev [i + 1], hip->ev [i + 2]);
+    }
     LEAVE_DEVICE (hip);
-    if (numLaunches) *numLaunches = hip->ev_count / 2;
+    if (numLaunches) *numLaunches = hip->ev_count / 3;
     hip->ev_count = 0;
     return total;
+}
+
+/* what the launches of the last resampleHipReadTiming spent BEFORE their dominant kernel: the table / staging passes of the
+ * matrix-core paths (for the fixed-point kernel: peak pass + digit-plane pass) and the gaps between them */
+double resampleHipReadPrepTiming (Resample *cxt)
+{
+    struct artamd_resampler *hip = cxt->hip;
+    double worst = hip->prep_ms;
+    for (int k = 0; k < hip->nshards; ++k) {
+        const double ms = resampleHipReadPrepTiming (hip->shards [k]);
+        if (ms > worst) worst = ms;
+    }
+    return worst;
 }
 
 static void *timing_event (struct artamd_resampler *hip)
 {
     if (hip->ev_count == hip->ev_cap) {
-        const int cap = hip->ev_cap ? hip->ev_cap * 2 : 64;
+        const int cap = hip->ev_cap ? hip->ev_cap * 2 : 96;
         void **grown = realloc (hip->ev, sizeof (void *) * cap);
         if (!grown) return NULL;
         hip->ev = grown;
@@ -838,7 +854,7 @@ int resampleHipLastFixedPoint (Resample *cxt, double *pairsPerChunk)
     const int words = hip->last_fixed [1], chunks = hip->last_fixed [2];
     unsigned long long *masks = malloc (sizeof (unsigned long long) * (size_t)(words > 0 ? words : 1));
     arthip_d2h (&flag, hip->d_planes, sizeof (flag), hip->stream);
-    if (masks && words > 0) arthip_d2h (masks, (char *) hip->d_planes + 256, sizeof (unsigned long long) * (size_t) words, hip->stream);
+    if (masks && words > 0) arthip_d2h (masks, (char *) hip->d_planes + ART_I8_HEAD_BYTES, sizeof (unsigned long long) * (size_t) words, hip->stream);
     arthip_sync (hip->stream);
     if (pairsPerChunk && masks && words > 0 && chunks > 0) {
         double full = 0.0;
@@ -1152,7 +1168,7 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
             const size_t want = arthip_fir_planes_bytes (&a, res.output_generated, hip->kernel_pref);
             if (want > hip->planes_cap) {
                 hip->d_planes = grow (hip->d_planes, &hip->planes_cap, want);
-                if (hip->d_planes) arthip_zero (hip->d_planes, 256, hip->stream);
+                if (hip->d_planes) arthip_zero (hip->d_planes, ART_I8_HEAD_BYTES, hip->stream);
             }
             a.planes = want ? hip->d_planes : NULL; a.planes_bytes = hip->d_planes ? hip->planes_cap : 0;
             a.fixed_out = hip->last_fixed;
@@ -1171,8 +1187,10 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
             a.n_begin = hip->segs [s0].first_output;
             a.n_end = s1 < nseg ? hip->segs [s1].first_output : res.output_generated;
             if (a.n_end > a.n_begin) {
+                void *ev_pre = hip->timing ? timing_event (hip) : NULL;
                 a.ev_start = hip->timing ? timing_event (hip) : NULL;
                 a.ev_stop = hip->timing ? timing_event (hip) : NULL;
+                if (ev_pre) arthip_event_record (ev_pre, hip->stream);
                 /* the last FIR launch of the call may take the history roll along (one launch less on the stream) */
                 a.roll_dst = (s1 == nseg && appended > 0) ? hip->d_hist [hip->cur ^ 1] : NULL;
                 a.roll_appended = appended;

@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 general, 2 matrix path, 5 f32 tile kernel, 6 f32 streaming kernel, 7 fixed point wherever possible")
     ap.add_argument("--preroll-ms", type=float, default=200.0, help="untimed device pre-roll before the warmup steps (clock ramp); 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pmc-json", default=None, help="traffic file written by tools/pmc_traffic.py in the same lease (else the committed profiles/ figure is reported, labelled as such)")
     args = ap.parse_args()
 
     import torch
@@ -160,23 +161,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_region():
+    def timed_region(blk=None, steps=None):
         """W untimed warmup steps, then EXACTLY K steps between barrier + synchronize on both sides"""
+        blk = block if blk is None else blk
+        steps = args.steps if steps is None else steps
+        cap_b = int(math.floor((blk + TAPS // 2) * ratio + 10))
         for _ in range(args.warmup):
-            used, made = rs.process_device(d_in, block, d_out, cap, ratio)
-            assert used == block and made < cap
+            used, made = rs.process_device(d_in, blk, d_out, cap_b, ratio)
+            assert used == blk and made < cap_b
         barrier()
         rs.set_timing(True)
         frames = 0
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            used, made = rs.process_device(d_in, block, d_out, cap, ratio)
+        for _ in range(steps):
+            used, made = rs.process_device(d_in, blk, d_out, cap_b, ratio)
             frames += made
         barrier()
         dt = time.perf_counter() - t0
         kernel_ms, launches = rs.read_timing()
+        prep_ms = rs.read_prep_timing()
         rs.set_timing(False)
-        return dt, frames, kernel_ms, launches
+        return dt, frames, kernel_ms, launches, prep_ms
 
     # From cold first (reported as value_cold): MI355X raises its clocks over the first tens of milliseconds of sustained load —
     # measured on this workload: 0.213 ms per kernel in the first 5 ms, 0.179 ms after 100 ms — so a K of a few dozen 0.2 ms
@@ -190,13 +195,27 @@ def main():
             for _ in range(8):
                 rs.process_device(d_in, block, d_out, cap, ratio)
             torch.cuda.synchronize()
-    dt, out_frames, kernel_ms, launches = timed_region()
+    dt, out_frames, kernel_ms, launches, prep_ms = timed_region()
     kernel_used = rs.last_kernel()
     fixed_state, fixed_pairs = rs.fixed_point()           # 1: the matrix path ran in fixed point on the integer matrix cores
+
+    # Beside the headline, in the same run and on the same context (never `value`):
+    #  * the same call at the block size the CPU baseline uses (65,536 frames): the like-for-like figure;
+    #  * the f32 matrix-core kernel pinned (kernel preference 6): exact-f32 FMA chains, the path of launches below the
+    #    fixed-point kernel's threshold and its stand-by.
+    small_block = min(65536, block)
+    small = timed_region(small_block, max(args.steps, 50)) if not args.kernel else None
+    f32 = None
+    if not args.kernel and kernel_used == 2 and fixed_state == 1:
+        rs.set_kernel(6)
+        f32 = timed_region()
+        rs.set_kernel(0)
 
     dev = "cuda" if backend == "nccl" else "cpu"
     agg = agree_and_aggregate(dist, dev, dt, out_frames, Cn, kernel_ms, launches)
     agg_cold = agree_and_aggregate(dist, dev, cold[0], cold[1], Cn, cold[2], cold[3])
+    agg_small = agree_and_aggregate(dist, dev, small[0], small[1], Cn, small[2], small[3]) if small else None
+    agg_f32 = agree_and_aggregate(dist, dev, f32[0], f32[1], Cn, f32[2], f32[3]) if f32 else None
     dt_max, samples_total = agg["seconds_max"], agg["samples_total"]
     assert agg["frames_consistent"] and agg_cold["frames_consistent"], "ranks disagree on the number of generated frames"
 
@@ -222,13 +241,15 @@ def main():
         # HBM traffic of the dominant kernel is a PMC measurement (tools/pmc.sh: separate rocprofv3 --pmc passes, FETCH_SIZE
         # with the gfx950 wide-read correction + WRITE_SIZE); it cannot be taken inside this process, so the committed
         # per-launch figure is reported when — and only when — this run is the workload it was measured on.
-        traffic = None
-        for name in ("r2_traffic.json", "r1_traffic.json"):
+        traffic = traffic_source = None
+        for name in ([args.pmc_json] if args.pmc_json else []) + ["r3_traffic.json", "r2_traffic.json"]:
             try:
-                tr = json.load(open(os.path.join(ROOT, "profiles", name)))
+                tr = json.load(open(name if os.path.isabs(name) or os.path.exists(name) else os.path.join(ROOT, "profiles", name)))
                 w = tr["workload"]
                 if kernel_used == 2 and bool(tr.get("fixed_point", False)) == fixed and (w["block_frames"], w["channels"], w["taps"]) == (block, Cn, TAPS) and launches == args.steps:
                     traffic = tr["traffic_bytes_per_launch"]
+                    traffic_source = (f"--pmc-json {name}: rocprofv3 --pmc passes of this command in the same lease" if name == args.pmc_json else
+                                      f"committed profiles/{name}: rocprofv3 --pmc passes of this command on an earlier box (not measured in this run)")
                 break
             except Exception:
                 continue
@@ -251,15 +272,20 @@ def main():
                        "stream_channels": total_ch, "channels_per_gpu": Cn, "block_frames": block, "taps": TAPS, "filters": FILTERS,
                        "fir_kernel": "mfma-i8 (fixed point)" if fixed else {1: "general", 2: "mfma"}.get(kernel_used, str(kernel_used)),
                        "parallelism": f"channel-shard x{world}, no data-path collective",
-                       "accuracy": ("default mode, fixed-point matrix kernel: |y - fp64-accumulate| <= half a float ulp + 2^-29; "
-                                    "RESAMPLE_STRICT_ORDER is bit-exact") if fixed else
+                       "accuracy": ("default mode, fixed-point matrix kernel, block floating point (one power-of-two exponent per channel and launch, "
+                                    "from the channel's peak |x|): |y - fp64-accumulate| <= half a float ulp of y + 2^-26 x that peak — RELATIVE to the "
+                                    "channel's level in the call like float arithmetic (rms error ~0.5 x the reference float loop's at any "
+                                    "amplitude), not an absolute grid; within one call a passage far below the channel's peak keeps the peak's "
+                                    "grid (floor 2^-31 x peak); RESAMPLE_STRICT_ORDER is bit-exact") if fixed else
                                    ("default mode: |y - fp64-accumulate| <= 2^-23 max(1,|y|) (2 ulp on < 0.1 % of samples when |y| > 1, as the "
                                     "reference's own float build); RESAMPLE_STRICT_ORDER is bit-exact")},
             "roofline": {"bound": "mfma", "achieved": round(tflops_exec, 3), "peak": peak, "unit": "TFLOP/s",
                          "unit_note": "integer multiply-adds of v_mfma_i32_32x32x32_i8, 2 ops each (TOP/s), against the dense int8 MFMA peak" if fixed else "f32 MFMA",
-                         "frac": round(tflops_exec / peak, 4), "traffic": traffic,
+                         "frac": round(tflops_exec / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_unit": "bytes/launch (HBM, PMC)", "algorithmic_bytes_per_launch": int(per_launch_samples * BYTES_PER_SAMPLE),
                          "kernel": "fir_i8_stream_kernel" if fixed else "fir", "avg_kernel_ms": round(avg_ms, 4), "launches": launches,
+                         "avg_prep_ms": round(prep_ms / max(launches, 1), 4),
+                         "prep_note": "HIP events: what each launch spends before its dominant kernel (fixed point: peak pass + digit-plane staging pass; f32: row-table pass)",
                          "flop_per_sample_executed": round(executed_per_sample, 1), "bytes_per_sample": round(BYTES_PER_SAMPLE, 3),
                          "digit_pairs_per_chunk": round(fixed_pairs, 3) if fixed else None,
                          "f32_mfma_equivalent_frac": round(rate * 2 * kpad / 1e12 / PEAK_FP32_TFLOPS, 4) if kernel_used == 2 else None,
@@ -274,6 +300,19 @@ def main():
                                  "sample (SURVEY 8d) and is not a roofline fraction",
                          "hbm_algorithmic_GBps": round(gbs, 2), "hbm_frac": round(gbs / PEAK_HBM_GBS, 5)},
         }
+        if agg_small:
+            line["value_block65536"] = round(agg_small["samples_total"] / agg_small["seconds_max"] / 1e6, 2)
+            line["value_block65536_note"] = (f"the same call with {small_block} input frames (the CPU baseline's block size), {max(args.steps, 50)} timed steps "
+                                             "after the headline's, same context; the like-for-like figure beside cpu_baseline")
+        if agg_f32:
+            f_launches = max(f32[3], 1)
+            f_rate = f32[1] * Cn / f_launches / (f32[2] / f_launches * 1e-3)
+            line["value_f32"] = round(agg_f32["samples_total"] / agg_f32["seconds_max"] / 1e6, 2)
+            line["f32_frac"] = round(f_rate * 2 * kpad / 1e12 / PEAK_FP32_TFLOPS, 4)
+            line["f32_avg_kernel_ms"] = round(f32[2] / f_launches, 4)
+            line["value_f32_note"] = ("same W + K steps with the f32 matrix-core kernel pinned (kernel preference 6: exact-f32 FMA chains with fp64 flushes — "
+                                      "what launches below the fixed-point threshold, and the fixed-point kernel's stand-by, run); f32_frac = executed "
+                                      "2 x Kpad flop per sample over the f32-MFMA peak")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(Cn)
         print(json.dumps(line), flush=True)

@@ -62,6 +62,9 @@ unsigned int resampleHipLastHandedBack (Resample *cxt);   /* outputs the matrix-
  * since timing was (re-)enabled; the read synchronises. */
 void resampleHipSetTiming (Resample *cxt, int enable);
 double resampleHipReadTiming (Resample *cxt, int *numLaunches);
+/* milliseconds the launches covered by the last resampleHipReadTiming spent BEFORE their dominant kernel (table / staging
+ * passes of the matrix-core paths — peak pass + digit-plane pass of the fixed-point kernel — and the gaps between them) */
+double resampleHipReadPrepTiming (Resample *cxt);
 
 ResampleResult resampleProcessInterleavedDevice (Resample *cxt, const artsample_t *d_input, int numInputFrames,
                                                  artsample_t *d_output, int numOutputFrames, double ratio);
