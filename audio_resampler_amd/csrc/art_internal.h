@@ -19,11 +19,8 @@ extern "C" {
 #endif
 
 /* header of a context's digit-plane buffer (fixed-point matrix kernel, fir_matrix_i8.hip), zeroed when the buffer is allocated:
- * [0] stand-down flag word; [256..384) per-channel peak |x| of the launch being staged (bits of the float magnitude, zero between
- * launches); [512..640) per-channel binary exponent the launch's samples were scaled by.  The rows' mask words follow the header. */
-#define ART_I8_HEAD_BYTES 1024
-#define ART_I8_PEAK_OFFSET 256
-#define ART_I8_SHIFT_OFFSET 512
+ * [0] stand-down flag word.  The rows' mask words follow the header. */
+#define ART_I8_HEAD_BYTES 256
 
 #define ART_MAX_SEGS 192         /* ring-epoch segments per kernel launch (passed by value: 16 B each, kernel arguments stay below 4 KB) */
 

@@ -61,16 +61,18 @@ void mfma_prepare_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
         if (row == 0 && g.tile_w0) g.tile_w0 [3 * st] = p0.ip - a.T / 2 + 1;
     }
     if (row == 0 && g.tile_w0) {
-        // (positions i Q / P + const are whole numbers for exactly one slot per period, and a tile never spans two periods)
-        __shared__ int s_pass [2];
-        if (tid == 0) { s_pass [0] = -1; s_pass [1] = 0; }
+        // nearest-filter mode without a low-pass: the slots of this tile whose ROUNDED filter index is a whole sample (reference
+        // resampler.c:1141: fi % F == 0 — one slot per period when F = P, several when F < P), one bit per row; such a slot's
+        // sample index is its canonical ip + fi / F
+        __shared__ unsigned int s_pass;
+        if (tid == 0) s_pass = 0u;
         __syncthreads ();
-        if (!INTERP && !a.lowpass && tid < rows_valid) {
+        if (!INTERP && !a.lowpass && tid < rows_valid && tid < 32) {
             const Pos q = locate<INTERP> (a, segs, a.n_begin + st * R + tid);
-            if ((q.fi % a.F) == 0) { s_pass [0] = tid; s_pass [1] = q.ip + q.fi / a.F; }
+            if ((q.fi % a.F) == 0) atomicOr (&s_pass, 1u << tid);
         }
         __syncthreads ();
-        if (tid == 0) { g.tile_w0 [3 * st + 1] = s_pass [0]; g.tile_w0 [3 * st + 2] = s_pass [1]; }
+        if (tid == 0) { g.tile_w0 [3 * st + 1] = (int) s_pass; g.tile_w0 [3 * st + 2] = 0; }
     }
     const float *h0 = a.bank + (size_t) p.fi * a.T;
     const int shift = p.ip - p0.ip;
@@ -617,7 +619,7 @@ size_t artfir_planes_bytes (const ArtFirArgs *a, unsigned int outputs, int kerne
     if (off) return 0;
     MfmaGeom g;
     const int cgt = matrix_geometry (a, g);
-    return cgt ? artfir_i8_bytes (a, g, cgt) : 0;
+    return cgt ? artfir_i8_bytes (a, g, cgt, outputs) : 0;
 }
 
 // Launch the matrix-core path for this call if it applies: returns ART_KERNEL_MFMA (| ART_FIR_ROLLED), -1 on a launch failure,

@@ -20,14 +20,14 @@ struct MfmaGeom {
     // the head of the call as ONE contiguous array (history ++ first input frames, MF_HEAD_PAD zero frames in front): tiles that
     // reach into the history stage from it exactly as all others stage from `in` (written by mfma_prepare_kernel)
     float *head; int head_frames;
-    // per slot tile, 3 ints: [0] linear index of K column 0 in period 0 of the launch; [1] the tile's pass-through row (nearest-
-    // filter mode without a low-pass: the one slot per period whose position falls exactly on an input sample), -1 if none;
-    // [2] that sample's linear index in period 0 (streaming kernel)
+    // per slot tile, 3 ints: [0] linear index of K column 0 in period 0 of the launch; [1] the tile's pass-through rows (nearest-
+    // filter mode without a low-pass: the slots whose rounded filter index is a whole input sample, which the reference copies),
+    // one bit per row — such a row's sample in period 0 is canon_ip + canon_fi / F; [2] unused (streaming kernels)
     int *tile_w0;
 };
 
 // fir_matrix_i8.hip: the fixed-point kernel of regular launches
-size_t artfir_i8_bytes (const ArtFirArgs *a, const MfmaGeom &g, int cgt);         // device bytes of a launch's digit planes (0: not for it)
+size_t artfir_i8_bytes (const ArtFirArgs *a, const MfmaGeom &g, int cgt, unsigned int outputs);   // device bytes of the digit planes of a call making `outputs` frames (0: not for it)
 // stage + main kernel of one launch (1), or 0: not for this path (no planes, shape)
 int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGeom &g, int cgt, unsigned int roll_blocks, hipStream_t st);
 

@@ -2,11 +2,13 @@
 // GEMM (see fir_matrix.hip) evaluated EXACTLY on the integer matrix cores instead of in chained f32.
 //
 // Effective filter rows (lerp folded in, fp64) are rounded once to 32-bit fixed point with 30 fraction bits; input samples are
-// rounded once to 32-bit BLOCK floating point: every channel of a launch has its own binary exponent, taken from the channel's
-// peak |x| over the launch's history ++ input (i8_peak_kernel) so that the peak lands in [2^29, 2^31 - 2^23) — exact for every
-// float sample within 2^-6 of its channel's peak, (peak) x 2^-31 absolute below that: the error model is RELATIVE to the
-// channel's level in the launch, as float arithmetic's is, not tied to full scale.  Both are written as four signed base-256
-// digits each (d0 most significant: value = sum_i d_i 256^(3-i)).  The dot product of two such numbers is
+// rounded once to 32-bit BLOCK floating point: the launch's periods are cut into exponent blocks (~10k input frames: a fraction
+// of a second; the length depends on the ratio and the filter only, never on the channel count, so a channel's bits do not
+// depend on which other channels share its context), and inside a block every channel has its own binary exponent, taken
+// from the channel's peak |x| over the frames the block's outputs read, so that the peak lands in [2^29, 2^31 - 2^23) — exact
+// for every float sample within 2^-6 of that peak, (peak) x 2^-31 absolute below it: the error model is RELATIVE to the
+// channel's level around the output, as float arithmetic's is, not tied to full scale.  Both are written as four signed
+// base-256 digits each (d0 most significant: value = sum_i d_i 256^(3-i)).  The dot product of two such numbers is
 //     sum_k h_k x_k = sum_{i,j} 256^(6-i-j) sum_k a_i[k] b_j[k],
 // and each inner sum over k is one v_mfma_i32_32x32x32_i8 chain: integer, exact, order-free (|sum| < 2^14 * K * pairs < 2^31).
 // The 13 digit pairs with i + j <= 4 are kept (five accumulators, one per weight class i + j); the three dropped pairs carry
@@ -24,8 +26,11 @@
 // raises a flag in device memory and the fixed-point kernel's workgroups run the f32 streaming kernel's tile loop instead (no
 // host round trip: the device-pointer calls stay asynchronous).
 //
-// Data layout.  X digit planes: plane p (digit d_p), 4-frame block b, channel c -> one dword holding frames 4b..4b+3 of that
-// channel (byte q = frame 4b + q): [p][b][c].  Linear frame lin (history ++ input) lives in block (lin + I8_PADF) / 4.  A tile
+// Data layout.  X digit planes, per exponent block e (its own copy of the frames its periods read: neighbouring blocks overlap by
+// one period + one window, quantised with each block's own exponents; a tile column stages from ITS period's block): plane p
+// (digit d_p), 4-frame block b, channel c -> one
+// dword holding frames 4b..4b+3 of that channel (byte q = frame 4b + q): [e][p][b - b0 - e * step][c].  Linear frame lin
+// (history ++ input) lives in block (lin + I8_PADF) / 4.  A tile
 // takes every g-th period (g = 4 / gcd (Q, 4)) so that all its columns start at the same offset r in their first block; r is
 // absorbed by the tile's filter rows, which exist once per (slot tile, residue) shifted r taps to the right.  A digit planes:
 // [slot tile * g + residue][chunk][p][row][32 taps]: the 4 KB a workgroup stages per chunk are contiguous.
@@ -57,11 +62,19 @@ struct I8Geom {
     unsigned long long *a_masks;          // [variant][row]: bit c set = chunk c of the row has a non-zero most significant digit
     const unsigned char *x_planes;        // (written through x_planes_w by the staging pass)
     unsigned int *x_planes_w;
-    unsigned int x_blocks;                // 4-frame blocks per plane
-    size_t x_plane_bytes;                 // x_blocks * C * 4
+    // exponent blocks: block e = periods [e * eb_periods, (e + 1) * eb_periods) of the launch; its planes hold 4-frame blocks
+    // [b0 + e * eb_step, b0 + e * eb_step + eb_blocks) — everything those periods' windows read, from any slot tile
+    int eb_periods, ebs;
+    int eb_blocks, eb_step;
+    int b0;                               // block of the launch's first window start (host: the reference's position arithmetic)
+    int cgrp;                             // channels one staging workgroup handles (a power of two <= C)
+    int slices;                           // staging workgroups per (exponent block, channel group): consecutive slices of its 4-frame blocks
+    int slice_blocks;                     // blocks per slice
+    unsigned int *peaks;                  // [ebs][slices][C] bits of each slice's peak |x| per channel (peak pass -> quantise pass)
+    unsigned int eb_plane_bytes;          // eb_blocks * C * 4
+    size_t x_bytes;                       // ebs * 4 * eb_plane_bytes
     int *flag; int epoch;                 // *flag == epoch: this launch cannot run in fixed point (set by the staging pass)
-    unsigned int *peak;                   // [C] bits of the channel's peak |x| over history ++ input (i8_peak_kernel; zeroed again by the main kernel)
-    int *shifts;                          // [C] the channel's samples are quantised as rint (x * 2^shift) (written by the staging pass)
+    int *shifts;                          // [ebs][C]: the block's samples of channel c are quantised as rint (x * 2^shift)
 };
 
 // binary exponent for a channel whose peak magnitude has these float bits: peak * 2^shift in [2^29, 2^31 - 2^23) — as large as the
@@ -72,51 +85,8 @@ __device__ __forceinline__ int shift_of_peak (unsigned int bits)
     return 157 - e - ((bits & 0x7f0000u) == 0x7f0000u ? 1 : 0);
 }
 
-// Per-channel peak |x| of a launch's history ++ input (both interleaved, 16-byte aligned, C a power of two <= 32): magnitudes
-// compared as unsigned bit patterns — monotone for finite values, infinities above them, NaNs above those.  One pass at HBM
-// speed; the staging pass behind it re-reads the same bytes from the Infinity Cache.
-constexpr int I8_PEAK_THREADS = 1024;
-__global__ __launch_bounds__ (I8_PEAK_THREADS)
-void i8_peak_kernel (ArtFirArgs a, unsigned int *peak)
-{
-    __shared__ unsigned int s_peak [32];
-    const int tid = threadIdx.x;
-    if (tid < 32) s_peak [tid] = 0u;
-    __syncthreads ();
-    const size_t stride = (size_t) gridDim.x * I8_PEAK_THREADS;   // (in 4-float vectors: 4 * stride is a multiple of C, a thread's channels never change)
-    const size_t v0 = (size_t) blockIdx.x * I8_PEAK_THREADS + tid;
-    unsigned int m [4] = { 0u, 0u, 0u, 0u };
-    auto take = [&] (const u32x4 &v) {
-        m [0] = max (m [0], v.x & 0x7fffffffu); m [1] = max (m [1], v.y & 0x7fffffffu);
-        m [2] = max (m [2], v.z & 0x7fffffffu); m [3] = max (m [3], v.w & 0x7fffffffu);
-    };
-    for (int part = 0; part < 2; ++part) {
-        const float *src = part ? a.in : a.hist;
-        const size_t n = part ? (size_t) a.in_frames * a.C : (size_t) a.H * a.C;
-        if (!src || !n) continue;
-        const u32x4 *sv = reinterpret_cast<const u32x4 *> (src);
-        const size_t nv = n / 4;
-        size_t v = v0;
-        for (; v + 3 * stride < nv; v += 4 * stride) {         // four loads in flight per thread
-            const u32x4 x0 = sv [v], x1 = sv [v + stride], x2 = sv [v + 2 * stride], x3 = sv [v + 3 * stride];
-            take (x0); take (x1); take (x2); take (x3);
-        }
-        for (; v < nv; v += stride) take (sv [v]);
-        if (v0 == 0)                                            // (up to 3 values behind the last whole vector)
-            for (size_t i = nv * 4; i < n; ++i) atomicMax (&s_peak [i % a.C], __float_as_uint (src [i]) & 0x7fffffffu);
-    }
-    // lanes that share a channel set first (xor offsets that are multiples of C / 4 lanes), then one LDS atomic per wave and channel
-    const int lanes_per_set = a.C >= 4 ? a.C / 4 : 1;
-    for (int off = 32; off >= lanes_per_set; off >>= 1)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) m [e] = max (m [e], (unsigned int) __shfl_xor ((int) m [e], off));
-    if ((tid & 63) < lanes_per_set)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (m [e]) atomicMax (&s_peak [(int)((v0 * 4 + e) % a.C)], m [e]);
-    __syncthreads ();
-    // (most workgroups find a peak some other has already reported: the plain read spares the contended atomic)
-    if (tid < a.C && s_peak [tid] > __builtin_nontemporal_load (&peak [tid])) atomicMax (&peak [tid], s_peak [tid]);
-}
+constexpr int I8_STAGE_THREADS = 256;     // workgroup of the two staging passes
+constexpr int I8_STAGE_K = 4;             // units (4 frames of one channel) per staging thread
 
 // digits of a fixed-point value as one dword: byte 3 = d0 ... byte 0 = d3, each signed
 __device__ __forceinline__ unsigned int digits_of (int q) { return ((unsigned int) q + 0x80808080u) ^ 0x80808080u; }
@@ -134,18 +104,135 @@ __device__ __forceinline__ void to_planes (const unsigned int (&s) [4], unsigned
     pl [3] = __builtin_amdgcn_perm (t23_lo, t01_lo, 0x07060302u);
 }
 
-// Staging pass, one launch, two roles by block index:
-//   blocks [0, slot_tiles * 32): one effective row each (same arithmetic as mfma_prepare_kernel up to the rounding: the fp64
-//       blend goes straight to fixed point, not through float) -> A digit planes;
-//   the rest: X digit planes of history ++ input, one thread per (4-frame block, channel).
-template <bool INTERP>
-__global__ __launch_bounds__ (256)
+// The X side of the two staging passes: a workgroup takes one slice of one exponent block's frames (x a channel group), a thread
+// I8_STAGE_K units of 4 frames x 1 channel.  All addresses are one per-thread offset + a scalar: raw buffer loads / stores, whose
+// range check also supplies the zeros past the call's end.
+//   PEAK pass: per-channel peak |x| of the slice (magnitudes compared as unsigned bit patterns: monotone for finite values,
+//       infinities above them, NaNs above those) -> a table entry per (block, slice, channel);
+//   quantise pass (the launch behind it): the block's exponent from the maximum over its slices' entries (no device-wide
+//       atomics: contended ones cost the peak pass 12 us), digit planes of the slice.
+// HEAD: the slice starts inside the history (two source arrays) or inside the head the stand-by's f32 tiles stage from.
+template <bool HEAD, bool PEAK>
+__device__ __forceinline__ void stage_slice (const ArtFirArgs &a, const MfmaGeom &g, const I8Geom &q, int eb, int cgi, int slice, int gb0)
+{
+    __shared__ unsigned int s_peak [32];
+    const int tid = threadIdx.x;
+    const int c = cgi * q.cgrp + (tid & (q.cgrp - 1));
+    const int per_k = I8_STAGE_THREADS / q.cgrp;               // blocks between a thread's consecutive units
+    const int bl0 = slice * q.slice_blocks + tid / q.cgrp;      // (block index inside the region)
+    const int bl_end = min ((slice + 1) * q.slice_blocks, q.eb_blocks);
+    const int lin0 = 4 * (gb0 + bl0) - I8_PADF;                 // the thread's first frame (>= -I8_PADF)
+    const unsigned int row = (unsigned int) a.C * 4u;           // bytes per frame
+    const __amdgpu_buffer_rsrc_t r_in = make_rsrc (a.in, (unsigned int)((size_t) a.in_frames * row));
+    const __amdgpu_buffer_rsrc_t r_hist = make_rsrc (a.hist, (unsigned int) a.H * row);
+    if (tid < 32) s_peak [tid] = 0u;
+    __syncthreads ();
+    if constexpr (!PEAK) {                                      // the block's peaks: maximum over its slices (issued ahead of the sample loads)
+        for (int i = tid; i < q.slices * q.cgrp; i += I8_STAGE_THREADS) {
+            const int sl = i / q.cgrp, cc = i - sl * q.cgrp;
+            const unsigned int pkv = q.peaks [(size_t)(eb * q.slices + sl) * a.C + cgi * q.cgrp + cc];
+            if (pkv) atomicMax (&s_peak [cc], pkv);
+        }
+    }
+    if constexpr (PEAK && !HEAD) {
+        // the peak pass of a plain slice needs no frame x channel transposition: whole 16-byte vectors (4 channels of one frame)
+        if (q.cgrp >= 4) {
+            const int vpf = q.cgrp >> 2, cq = tid & (vpf - 1), per_f = I8_STAGE_THREADS / vpf;
+            const int f0 = 4 * (gb0 + slice * q.slice_blocks) - I8_PADF - a.H + tid / vpf, f_end = 4 * (gb0 + bl_end) - I8_PADF - a.H;
+            const unsigned int voff = (unsigned int)(f0 * a.C + cgi * q.cgrp + 4 * cq) * 4u;
+            unsigned int m4 [4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+            for (int k = 0; k < I8_STAGE_K; ++k)
+                if (f0 + k * per_f < f_end) {
+                    const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128 (r_in, (int) voff, (int)((unsigned int)(k * per_f) * row), 0);
+                    m4 [0] = max (m4 [0], x.x & 0x7fffffffu); m4 [1] = max (m4 [1], x.y & 0x7fffffffu);
+                    m4 [2] = max (m4 [2], x.z & 0x7fffffffu); m4 [3] = max (m4 [3], x.w & 0x7fffffffu);
+                }
+            for (int off = 32; off >= vpf; off >>= 1)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m4 [e] = max (m4 [e], (unsigned int) __shfl_xor ((int) m4 [e], off));
+            if ((tid & 63) < vpf)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (m4 [e]) atomicMax (&s_peak [4 * cq + e], m4 [e]);
+            __syncthreads ();
+            if (tid < q.cgrp) q.peaks [(size_t)(eb * q.slices + slice) * a.C + c] = s_peak [tid];
+            return;
+        }
+    }
+    unsigned int v [I8_STAGE_K] [4];
+    unsigned int m = 0u;
+    const unsigned int voff_in = (unsigned int)((lin0 - a.H) * a.C + c) * 4u;       // (plain slices: lin0 >= H)
+#pragma unroll
+    for (int k = 0; k < I8_STAGE_K; ++k) {
+        const bool live = bl0 + k * per_k < bl_end;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            unsigned int x = 0u;
+            if (live) {
+                if constexpr (HEAD) {
+                    const int lin = lin0 + 4 * k * per_k + t;
+                    const unsigned int xi = __builtin_amdgcn_raw_buffer_load_b32 (r_in, lin >= a.H ? (int)((unsigned int)((lin - a.H) * a.C + c) * 4u) : -16, 0, 0);
+                    const unsigned int xh = __builtin_amdgcn_raw_buffer_load_b32 (r_hist, lin >= 0 && lin < a.H ? (int)((unsigned int)(lin * a.C + c) * 4u) : -16, 0, 0);
+                    x = xi | xh;                                // (one of the two is out of its array's range: zero)
+                }
+                else x = __builtin_amdgcn_raw_buffer_load_b32 (r_in, (int) voff_in, (int)((unsigned int)(4 * k * per_k + t) * row), 0);
+            }
+            v [k] [t] = x;
+            m = max (m, x & 0x7fffffffu);
+        }
+    }
+    if constexpr (PEAK) {
+        // threads of one channel: lanes cgrp apart first, then one LDS atomic per wave and channel
+        for (int off = 32; off >= q.cgrp; off >>= 1) m = max (m, (unsigned int) __shfl_xor ((int) m, off));
+        if ((tid & 63) < q.cgrp && m) atomicMax (&s_peak [tid & (q.cgrp - 1)], m);
+        __syncthreads ();
+        if (tid < q.cgrp) q.peaks [(size_t)(eb * q.slices + slice) * a.C + c] = s_peak [tid];
+        return;
+    }
+    __syncthreads ();
+    const unsigned int pk = s_peak [tid & (q.cgrp - 1)];
+    // the channel's exponent in this block: |x| <= peak, so |x * 2^shift| < 2^31 - 2^23 and the scaling itself is exact (v_ldexp_f32)
+    const int shift = shift_of_peak (pk);
+    if (tid < q.cgrp && slice == 0) {
+        q.shifts [eb * a.C + c] = shift;
+        if (pk >= 0x7f800000u) *q.flag = q.epoch;               // an infinity or a NaN among the block's frames: no exponent holds it
+    }
+    const __amdgpu_buffer_rsrc_t r_out = make_rsrc (q.x_planes_w + (size_t) eb * q.eb_plane_bytes, 4u * q.eb_plane_bytes);    // (the block's 4 planes)
+    const unsigned int voff_out = (unsigned int)(bl0 * a.C + c) * 4u;       // (bl0 counts from the region's start)
+    // (the call's head as one contiguous float array, for the stand-by's tiles that reach into the history)
+    const __amdgpu_buffer_rsrc_t r_head = make_rsrc (g.head, g.head ? (unsigned int) g.head_frames * row : 0u);
+    const unsigned int voff_head = (unsigned int)((lin0 + MF_HEAD_PAD) * a.C + c) * 4u;
+#pragma unroll
+    for (int k = 0; k < I8_STAGE_K; ++k) {
+        if (bl0 + k * per_k < bl_end) {
+            unsigned int sd [4], pl [4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if constexpr (HEAD) __builtin_amdgcn_raw_buffer_store_b32 (v [k] [t], r_head, (int) voff_head, (int)((unsigned int)(4 * k * per_k + t) * row), 0);
+                sd [t] = digits_of (__float2int_rn (ldexpf (__uint_as_float (v [k] [t]), shift)));   // (a channel with an infinity or a NaN: garbage, the launch is flagged)
+            }
+            to_planes (sd, pl);
+#pragma unroll
+            for (int pn = 0; pn < 4; ++pn) __builtin_amdgcn_raw_buffer_store_b32 (pl [pn], r_out, (int) voff_out, (int)((unsigned int) pn * q.eb_plane_bytes + (unsigned int)(k * per_k) * row), 0);
+        }
+    }
+}
+
+// Staging, two launches.  The first (PEAK): X workgroups find the exponent blocks' peaks; behind them in the same grid, one
+// workgroup per effective row (same arithmetic as mfma_prepare_kernel up to the rounding: the fp64 blend goes straight to fixed
+// point, not through float) -> A digit planes, masks and the tables the streaming kernels read.  The second: X workgroups only,
+// the same slices again (their second read comes from the Infinity Cache) -> X digit planes.
+template <bool INTERP, bool PEAK>
+__global__ __launch_bounds__ (I8_STAGE_THREADS)
 void i8_stage_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g, I8Geom q)
 {
     const int tid = threadIdx.x;
-    const unsigned int a_blocks = (unsigned int)(g.slot_tiles * q.g) * 32u;
-    if (blockIdx.x < a_blocks) {
-        const int variant = blockIdx.x >> 5, row = blockIdx.x & 31;
+    // (PEAK launch: the row workgroups come first in the grid — latency chains, they finish under the X workgroups' traffic)
+    const unsigned int a_wgs = PEAK ? (unsigned int)(g.slot_tiles * q.g) * 32u : 0u;
+    if (blockIdx.x < a_wgs) {
+        // ---- A role ----
+        const int ab = (int) blockIdx.x;
+        const int variant = ab >> 5, row = ab & 31;
         const int st = variant / q.g, jr = variant - st * q.g;
         const int rows_valid = min (32, g.P - st * 32);
         const Pos p0 = locate<INTERP> (a, segs, a.n_begin + st * 32);
@@ -156,8 +243,8 @@ void i8_stage_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g, I8Geom q)
         const int shift = p.ip - p0.ip + r;
         bool bad = false;
         __shared__ unsigned long long s_mask;
-        __shared__ int s_pass [2];
-        if (tid == 0) { s_mask = 0ull; s_pass [0] = -1; s_pass [1] = 0; }
+        __shared__ unsigned int s_pass;
+        if (tid == 0) { s_mask = 0ull; s_pass = 0u; }
         __syncthreads ();
         // what mfma_prepare_kernel leaves for the streaming kernels is written here: that kernel is not launched at all then
         if (jr == 0 && row == 0) {
@@ -165,14 +252,11 @@ void i8_stage_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g, I8Geom q)
                 g.tile_w0 [3 * st] = p0.ip - a.T / 2 + 1;
                 if (st == 0) a.fix_count [0] = 0;
             }
-            if (st == 0 && tid < a.C) {                        // the launch's per-channel exponents, for the main kernel's final scaling
-                const unsigned int pk = q.peak [tid];
-                q.shifts [tid] = shift_of_peak (pk);
-                if (pk >= 0x7f800000u) bad = true;              // an infinity or a NaN somewhere in the channel: no exponent holds it
-            }
+            // nearest-filter mode without a low-pass: the slots whose position falls exactly on an input sample (one bit per row;
+            // their sample index is the row's canonical ip + fi / F)
             if (!INTERP && !a.lowpass && tid < rows_valid) {
                 const Pos pq = locate<INTERP> (a, segs, a.n_begin + st * 32 + tid);
-                if ((pq.fi % a.F) == 0) { s_pass [0] = tid; s_pass [1] = pq.ip + pq.fi / a.F; }
+                if ((pq.fi % a.F) == 0) atomicOr (&s_pass, 1u << tid);
             }
         }
         if (jr == 0) {
@@ -221,31 +305,19 @@ void i8_stage_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g, I8Geom q)
         __syncthreads ();
         if (tid == 0) {
             q.a_masks [variant * 32 + row] = s_mask;
-            if (jr == 0 && row == 0) { g.tile_w0 [3 * st + 1] = s_pass [0]; g.tile_w0 [3 * st + 2] = s_pass [1]; }
+            if (jr == 0 && row == 0) { g.tile_w0 [3 * st + 1] = (int) s_pass; g.tile_w0 [3 * st + 2] = 0; }
         }
         if (bad) *q.flag = q.epoch;
         return;
     }
-    const size_t e = (size_t)(blockIdx.x - a_blocks) * 256 + tid;
-    const size_t total = (size_t) q.x_blocks * a.C;
-    if (e >= total) return;
-    const int b = (int)(e / a.C), c = (int)(e - (size_t) b * a.C);
-    unsigned int s [4], pl [4];
-    // the channel's block exponent: |x| <= peak, so |x * 2^shift| < 2^31 - 2^23 and the scaling itself is exact (v_ldexp_f32)
-    const int shift = shift_of_peak (q.peak [c]);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int lin = 4 * b + t - I8_PADF;
-        float v = 0.0f;
-        if (lin >= 0 && lin < a.H) v = a.hist [(size_t) lin * a.C + c];
-        else if (lin >= a.H && lin - a.H < a.in_frames) v = a.in [(size_t)(lin - a.H) * a.C + c];
-        // (the call's head as one contiguous float array, for the stand-by kernel's tiles that reach into the history)
-        if (g.head && lin + MF_HEAD_PAD >= 0 && lin + MF_HEAD_PAD < g.head_frames) g.head [(size_t)(lin + MF_HEAD_PAD) * a.C + c] = v;
-        s [t] = digits_of (__float2int_rn (ldexpf (v, shift)));   // (a channel with an infinity or a NaN: garbage, the launch is flagged)
-    }
-    to_planes (s, pl);
-#pragma unroll
-    for (int pn = 0; pn < 4; ++pn) q.x_planes_w [(size_t) pn * (q.x_plane_bytes / 4) + e] = pl [pn];
+    // ---- X role ----
+    const int groups = a.C / q.cgrp;
+    const int xid = (int)(blockIdx.x - a_wgs);
+    const int slice = xid % q.slices, xb = xid / q.slices, eb = xb / groups, cgi = xb - eb * groups;
+    const int gb0 = q.b0 + eb * q.eb_step;                      // the region's first block
+    // (slices that start inside the history ++ head span — the first few — read two arrays and leave the stand-by its head)
+    if (4 * (gb0 + slice * q.slice_blocks) - I8_PADF < max (a.H, g.head_frames - MF_HEAD_PAD)) stage_slice<true, PEAK> (a, g, q, eb, cgi, slice, gb0);
+    else stage_slice<false, PEAK> (a, g, q, eb, cgi, slice, gb0);
 }
 
 template <int VEC> struct PlaneLoad;
@@ -289,8 +361,6 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
     const int pt = tid & (MF_THREADS - 1);
 
     const unsigned int stream_blocks = 8u * (unsigned int) wgs_per_xcd;
-    // (the staging pass has turned the peaks into exponents: the next launch's peak pass finds them at zero again)
-    if (blockIdx.x == 0 && tid < 32) q.peak [tid] = 0u;
     if (blockIdx.x >= stream_blocks) {                        // extra workgroups: the history roll (as in fir_mfma_kernel)
         if (a.roll_dst) {
             const int e = (int)(blockIdx.x - stream_blocks) * THREADS + tid;
@@ -344,14 +414,20 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
         const int a_plane = pt >> 6, a_row = (pt >> 1) & 31, a_half = pt & 1;
         const unsigned int a_off0 = (unsigned int) pt * 16u;
         const int adst = a_plane * (32 * I8_PITCH) + a_row * I8_PITCH + a_half * 16;
-        unsigned int boff [NB]; int bdst [NB];
+        unsigned int boff [NB], bdel [NB]; int bdst [NB], bper [NB];
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             const int v = pt + u * MF_THREADS;
             const int m = v / VPP, rem = v % VPP, kb = rem / VPF, cv = rem % VPF;
             boff [u] = (unsigned int)((m * q.gq4 + kb) * CG + cv * VEC) * 4u;       // (the tile's first block sits in the resource base)
             bdst [u] = (m * CG + cv * VEC) * I8_PITCH + kb * 4;
+            bper [u] = m * q.g;                                                   // the unit's column: this many periods behind the tile's first
+            bdel [u] = 0u;
         }
+        // a column whose period lies d exponent blocks behind the tile's first column stages from that block's own planes: d regions
+        // further on, where the same 4-frame block sits d * eb_step blocks earlier
+        const unsigned int x_total = 4u * q.eb_plane_bytes;
+        const unsigned int eb_hop = x_total - (unsigned int) q.eb_step * (unsigned int)(CG * 4);
         // two register stages: the loads of chunk c + 3 are issued while those of c + 2 are still in flight (a chunk is ~0.5 us
         // of matrix work, less than a loaded L2 round trip: with one stage the kernel ran at the memory latency, 139 us)
         unsigned int ra0 [2] [4], rb0 [2] [4] [NB * VEC];
@@ -360,7 +436,6 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
         bool f_live = false;
         const unsigned char *fa_base = nullptr, *fb_base = nullptr;
         unsigned int fa_bytes = 0, fb_bytes = 0;
-        const size_t x_total = 4 * q.x_plane_bytes;
         auto open_tile = [&] () {                             // next tile of this workgroup's list that holds outputs
             int st = 0, j0 = 0;
             f_live = false;
@@ -370,9 +445,14 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
             // (readfirstlane: the table entry arrives in a vector register, and a resource built from it would make every load a
             // waterfall loop; the value is the same in all lanes)
             const int la = max (__builtin_amdgcn_readfirstlane (g.tile_w0 [3 * st]) + j0 * g.Q + I8_PADF, 0);
-            size_t skip = (size_t)(la >> 2) * CG * 4;
-            if (skip > q.x_plane_bytes) skip = q.x_plane_bytes;
-            fb_base = q.x_planes + skip; fb_bytes = (unsigned int) min (x_total - skip, (size_t) 0xfffffff0u);
+            // the tile's exponent block and its first 4-frame block inside that block's own planes
+            const int eb = j0 / q.eb_periods;
+            unsigned int skip = (unsigned int) max ((la >> 2) - q.b0 - eb * q.eb_step, 0) * (unsigned int)(CG * 4);
+            if (skip > q.eb_plane_bytes) skip = q.eb_plane_bytes;
+            const size_t from = (size_t) eb * x_total + skip;
+            fb_base = q.x_planes + from; fb_bytes = (unsigned int) min (q.x_bytes - from, (size_t) 0xfffffff0u);
+#pragma unroll
+            for (int u = 0; u < NB; ++u) bdel [u] = (unsigned int)((j0 + bper [u]) / q.eb_periods - eb) * eb_hop;
             fa_bytes = (unsigned int) nchunks * 4096u;
             fa_base = q.a_planes + (size_t)(st * q.g + j0 % q.g) * fa_bytes;
         };
@@ -388,7 +468,7 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
 #pragma unroll
                 for (int pn = 0; pn < 4; ++pn)
 #pragma unroll
-                    for (int u = 0; u < NB; ++u) PlaneLoad<VEC>::load (&rb0 [SET] [pn] [u * VEC], rb_, boff [u], (unsigned int)(pn * q.x_plane_bytes));
+                    for (int u = 0; u < NB; ++u) PlaneLoad<VEC>::load (&rb0 [SET] [pn] [u * VEC], rb_, boff [u] + bdel [u], (unsigned int) pn * q.eb_plane_bytes);
                 if (++f_chunk == nchunks) { f_chunk = 0; open_tile (); }
             }
         };
@@ -439,14 +519,15 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
     // output offset of this lane inside a tile: (period jl * g, slot 4 * (lane >> 5), channel c); the row's own 0..3 / +8 / +16 / +24
     // slots are immediates of the store
     const unsigned int out_off = (unsigned int)((jl * q.g * g.P + 4 * (lane >> 5)) * CG + c) * 4u;
-    // rows carry 30 fraction bits, this lane's channel `shift`; the class sums are combined at weight 256^(4 - s) of 2^16 units
-    const double out_scale = __builtin_ldexp (1.0, -14 - q.shifts [c]);
 
     __syncthreads ();                                        // the staging waves have committed chunk 0
     int qn = 0;                                              // chunks consumed so far: chunk qn sits in LDS buffer qn & 1
     for (int within = rank; within < tiles_per_xcd; within += wgs_per_xcd) {
         int st, j0;
         if (!tile_at (within, st, j0)) continue;
+        // rows carry 30 fraction bits, this lane's channel 2^shift in its period's exponent block; the class sums are combined at
+        // weight 256^(4 - s) in units of 2^16: the result is scaled by 2^(-14 - shift) (loaded now, used after the K loop)
+        const int out_exp = -14 - q.shifts [((j0 + jl * q.g) / q.eb_periods) * CG + c];
         i32x16 acc [5];
 #pragma unroll
         for (int s = 0; s < 5; ++s)
@@ -489,7 +570,7 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
         const int rows_valid = min (32, g.P - st * 32);
         const size_t left = (size_t)(a.n_end - n_tile) * CG * 4;
         const __amdgpu_buffer_rsrc_t rs_out = make_rsrc (a.out + (size_t) n_tile * CG, left > 0xffffff00ull ? 0xffffff00u : (unsigned int) left);
-        const int pass_row = PASS ? g.tile_w0 [3 * st + 1] : -1, pass_lin = PASS ? g.tile_w0 [3 * st + 2] : 0;
+        const unsigned int pass_rows = PASS ? (unsigned int) g.tile_w0 [3 * st + 1] : 0u;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i_const = (r & 3) + 8 * (r >> 2);      // compile-time part of the slot
@@ -498,11 +579,12 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
             double v = (double) acc [0] [r];
 #pragma unroll
             for (int s = 1; s < 5; ++s) v = v * 256.0 + (double) acc [s] [r];
-            float y = (float)(v * out_scale);
+            float y = (float) __builtin_ldexp (v, out_exp);
             const int i = i_const + 4 * (lane >> 5);
             if constexpr (PASS) {
-                // nearest-filter mode, the position falls exactly on an input sample: the reference copies it (resampler.c:1166-1170)
-                if (pass_row == i) y = load_frame (a, INT_MIN, pass_lin + (j0 + jl * q.g) * g.Q, c);
+                // nearest-filter mode, the position falls exactly on an input sample: the reference copies it (resampler.c:1141-1142)
+                if ((pass_rows >> i) & 1u)
+                    y = load_frame (a, INT_MIN, g.canon_ip [st * 32 + i] + g.canon_fi [st * 32 + i] / a.F + (j0 + jl * q.g) * g.Q, c);
             }
             if (col_live && i < rows_valid)                  // (frames at or past n_end: out of the resource's range, dropped)
                 __builtin_amdgcn_raw_buffer_store_b32 (__float_as_uint (y), rs_out, (int)(out_off + (unsigned int)(i_const * CG) * 4u), 0, 0);
@@ -512,37 +594,62 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
 
 } // namespace
 
-// The planes buffer of a launch: [header: flag, peaks, exponents (art_internal.h)][row masks][A digit planes][X digit planes];
+// The planes buffer of a launch: [header: flag (art_internal.h)][row masks][exponents][A digit planes][X digit planes per exponent block];
 // returns its size, 0 if the launch is not for this path
-static size_t i8_layout (const ArtFirArgs *a, const MfmaGeom &g, int cgt, I8Geom &q, char *base)
+static size_t i8_layout (const ArtFirArgs *a, const MfmaGeom &g, int cgt, I8Geom &q, char *base, unsigned int outputs = 0)
 {
     if (!cgt || g.tile_rows != 32 || (g.ktot % I8_KC)) return 0;
     const int ppw = I8_COLS / cgt > I8_MAX_PPW ? I8_MAX_PPW : I8_COLS / cgt;
     q.g = (g.Q % 4 == 0) ? 1 : (g.Q % 2 == 0) ? 2 : 4;
     q.gq4 = q.g * g.Q / 4;
-    const unsigned int total = a->n_end - a->n_begin, periods = (total + g.P - 1) / g.P;
+    // (outputs != 0: sizing a call's buffer before its launches are cut — any launch of the call has at most this many periods)
+    const unsigned int total = outputs ? outputs + (unsigned int) g.P : a->n_end - a->n_begin, periods = (total + g.P - 1) / g.P;
     q.super_groups = (int)((periods + (unsigned int)(q.g * ppw) - 1) / (unsigned int)(q.g * ppw));
     q.sg_per_xcd = (q.super_groups + 7) / 8;
-    const size_t a_bytes = (size_t) g.slot_tiles * q.g * (g.ktot / I8_KC) * 4096;
-    // every frame a tile with an output in range can stage: the call's frames, then (ppw - 1) * g periods, K columns, slack
-    const size_t frames = (size_t) I8_PADF + a->H + a->in_frames + (size_t) ppw * q.g * g.Q + g.ktot + 160;
-    q.x_blocks = (unsigned int)((frames + 3) / 4);
-    q.x_plane_bytes = (size_t) q.x_blocks * a->C * 4;
-    if (4 * q.x_plane_bytes >= 0xffff0000ull) return 0;               // (plane offsets are 32-bit)
     if (g.ktot / I8_KC > 64) return 0;                                  // (one mask bit per chunk)
-    const size_t head = (ART_I8_HEAD_BYTES + (size_t) g.slot_tiles * q.g * 32 * 8 + 255) & ~(size_t) 255;
+    // Exponent blocks: eb_periods periods each — a multiple of g (block starts stay on 4-frame blocks) chosen from the ratio alone
+    // so that a block spans ~9,400 input frames (one 8-channel tile's periods at 44.1k -> 48k), whatever the channel count.  A
+    // block's planes hold every frame its periods read: their input span, + the span of one period's slot tiles (< Q + 2 frames),
+    // + the K columns, + alignment.  One staging workgroup holds a block (x channel group) in registers: blocks x channels <=
+    // I8_STAGE_K x 1024 units.
+    {
+        const int unit = 16 * q.g * g.Q;
+        const int k = (9408 + unit / 2) / unit;
+        q.eb_periods = 16 * q.g * (k > 1 ? k : 1);
+    }
+    q.eb_step = q.eb_periods * g.Q / 4;                                 // (g * Q is a multiple of 4)
+    const int over_blocks = (g.Q + 2 + g.ktot + 3 + 3) / 4 + 2;
+    q.eb_blocks = q.eb_step + over_blocks;
+    q.ebs = (int)((periods + (unsigned int) q.eb_periods - 1) / (unsigned int) q.eb_periods);
+    // Staging workgroups: a block's region is cut into slices of consecutive 4-frame blocks, 32-byte runs per frame (8 channels
+    // per workgroup where the stream has them), I8_STAGE_K x 256 units each.  (Measured on the way here: one 1024-thread
+    // workgroup per exponent block holding its region in registers — one pass, no peak kernel — took 37 us for 67 MB on the
+    // headline call: a CU draws from memory at ~18 GB/s however many loads it has in flight, so 111 busy CUs are not enough; teams
+    // of such workgroups agreeing on the peak through device-wide atomics and a bounded wait, all CUs busy: 31 us — every
+    // workgroup reads, then every workgroup writes.  Two massively parallel launches do better.)
+    q.cgrp = a->C < 8 ? a->C : 8;
+    q.slice_blocks = I8_STAGE_K * I8_STAGE_THREADS / q.cgrp;
+    q.slices = (q.eb_blocks + q.slice_blocks - 1) / q.slice_blocks;
+    q.eb_plane_bytes = (unsigned int) q.eb_blocks * (unsigned int) a->C * 4u;
+    q.x_bytes = (size_t) q.ebs * 4 * q.eb_plane_bytes;
+    q.b0 = 0;
+    const size_t a_bytes = (size_t) g.slot_tiles * q.g * (g.ktot / I8_KC) * 4096;
+    const size_t masks = (size_t) g.slot_tiles * q.g * 32 * 8, shifts = (size_t) q.ebs * a->C * 4;
+    const size_t teams = (size_t) q.ebs * q.slices * a->C * 4;
+    const size_t head = (ART_I8_HEAD_BYTES + masks + teams + shifts + 255) & ~(size_t) 255;
     q.flag = (int *) base; q.epoch = 0;
-    q.peak = (unsigned int *)(base + ART_I8_PEAK_OFFSET); q.shifts = (int *)(base + ART_I8_SHIFT_OFFSET);
     q.a_masks = (unsigned long long *)(base + ART_I8_HEAD_BYTES);
+    q.peaks = (unsigned int *)(base + ART_I8_HEAD_BYTES + masks);
+    q.shifts = (int *)(base + ART_I8_HEAD_BYTES + masks + teams);
     q.a_planes = (unsigned char *) base + head;
     q.x_planes_w = (unsigned int *)(base + head + a_bytes); q.x_planes = (const unsigned char *) q.x_planes_w;
-    return head + a_bytes + 4 * q.x_plane_bytes;
+    return head + a_bytes + q.x_bytes;
 }
 
-size_t artfir_i8_bytes (const ArtFirArgs *a, const MfmaGeom &g, int cgt)
+size_t artfir_i8_bytes (const ArtFirArgs *a, const MfmaGeom &g, int cgt, unsigned int outputs)
 {
     I8Geom q;
-    return i8_layout (a, g, cgt, q, nullptr);
+    return i8_layout (a, g, cgt, q, nullptr, outputs ? outputs : 1u);
 }
 
 int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGeom &g, int cgt, unsigned int roll_blocks, hipStream_t st)
@@ -557,17 +664,25 @@ int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGe
     q.epoch = ep;
     if (a->fixed_out) { a->fixed_out [0] = ep; a->fixed_out [1] = g.slot_tiles * q.g * 32; a->fixed_out [2] = g.ktot / I8_KC; }
 
-    {   // per-channel peaks first: enough workgroups to pull at HBM speed, each thread a few vectors deep
-        const size_t vecs = ((size_t) a->in_frames + a->H) * a->C / 4;
-        unsigned int wgs = (unsigned int)((vecs + I8_PEAK_THREADS * 8 - 1) / (I8_PEAK_THREADS * 8));
-        if (wgs > 512u) wgs = 512u;                                     // two per CU: 32 waves per CU, four 16-byte loads in flight each
-        if (wgs < 1u) wgs = 1u;
-        hipLaunchKernelGGL (i8_peak_kernel, dim3 (wgs), dim3 (I8_PEAK_THREADS), 0, st, *a, q.peak);
+    {   // block of the launch's first window start: the reference's position arithmetic for output n_begin (as locate ())
+        int e = 0;
+        while (e + 1 < segs->count && segs->first [e + 1] <= a->n_begin) ++e;
+        const double step = a->n_begin ? (double) a->n_begin / a->ratio : 0.0;
+        const double off = segs->base [e] + step;
+        const int ip = (int) floor (off) + segs->lin_base [e];
+        const int la = ip - a->T / 2 + 1 + I8_PADF;
+        q.b0 = (la > 0 ? la : 0) >> 2;
     }
-    const unsigned int x_wgs = (unsigned int)(((size_t) q.x_blocks * a->C + 255) / 256);
-    const dim3 pgrid ((unsigned int)(g.slot_tiles * q.g) * 32u + x_wgs);
-    if (a->interpolate) hipLaunchKernelGGL (i8_stage_kernel<true>, pgrid, dim3 (256), 0, st, *a, *segs, g, q);
-    else hipLaunchKernelGGL (i8_stage_kernel<false>, pgrid, dim3 (256), 0, st, *a, *segs, g, q);
+    const unsigned int x_wgs = (unsigned int)(q.ebs * (a->C / q.cgrp) * q.slices);
+    const dim3 pgrid (x_wgs + (unsigned int)(g.slot_tiles * q.g) * 32u), xgrid (x_wgs);
+    if (a->interpolate) {
+        hipLaunchKernelGGL ((i8_stage_kernel<true, true>), pgrid, dim3 (I8_STAGE_THREADS), 0, st, *a, *segs, g, q);
+        hipLaunchKernelGGL ((i8_stage_kernel<true, false>), xgrid, dim3 (I8_STAGE_THREADS), 0, st, *a, *segs, g, q);
+    }
+    else {
+        hipLaunchKernelGGL ((i8_stage_kernel<false, true>), pgrid, dim3 (I8_STAGE_THREADS), 0, st, *a, *segs, g, q);
+        hipLaunchKernelGGL ((i8_stage_kernel<false, false>), xgrid, dim3 (I8_STAGE_THREADS), 0, st, *a, *segs, g, q);
+    }
     if (a->ev_start) arthip_event_record (a->ev_start, (void *) st);
 
     const int tiles_per_xcd = q.sg_per_xcd * q.g * g.slot_tiles;

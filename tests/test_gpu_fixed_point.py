@@ -1,8 +1,9 @@
 """GPU (-m gpu): the fixed-point form of the matrix-core path (fir_matrix_i8.hip: samples and effective rows as four signed
 8-bit digits, exact integer accumulation on v_mfma_i32_32x32x32_i8, one float rounding per output) — the kernel of big
-regular launches with long filters (kernel preference 7: of every regular launch).  Samples are BLOCK floating point: every
-channel of a launch is scaled by its own power of two, taken from the channel's peak |x| over the launch's history ++ input, so
-the arithmetic is scale-free like the reference's float loop (any finite amplitude, quiet channels beside loud ones).  Its
+regular launches with long filters (kernel preference 7: of every regular launch).  Samples are BLOCK floating point: the
+launch is cut into exponent blocks of ~10-40k input frames, and inside a block every channel is scaled by its own power of two,
+taken from the channel's peak |x| over the frames the block's outputs read, so the arithmetic is scale-free like the
+reference's float loop (any finite amplitude, quiet channels beside loud ones, quiet passages after loud ones).  Its
 only errors are the 2^-31 quantisation of the effective rows (about 5e-9 x the signal's rms), of samples more than 2^-6 below
 their channel's peak (2^-31 x that peak) and ONE float rounding, so against the double-accumulate oracle's float it must sit
 within one float spacing + 2^-24 x the channel's peak everywhere, at about half the f32 kernels' rms error or less (they carry
@@ -28,6 +29,7 @@ CASES = [
     (2, 380, 380, 44100, 48000, True, BH | INTERP | LOWPASS, (150000, 150000)),       # ART form: nearest filter, SNAP, low-pass
     (8, 988, 988, 96000, 44100, True, BH | INTERP | LOWPASS, (140000, 140000)),       # downsampling: P = 147, Q = 320 (period stride 1)
     (2, 380, 320, 44100, 48000, False, BH, (120000, 120000)),                         # nearest filter, pass-through samples
+    (2, 380, 32, 44100, 48000, False, BH, (120000, 120000)),                          # nearest filter, F < P: five pass-through slots per period, two of them in one tile
     (2, 64, 160, 48000, 44100, False, BH, (250000,)),                                 # P = 147, Q = 160, 3 chunks
     (2, 380, 380, 48000, 40000, False, BH | INTERP, (200000,)),                       # P = 5, Q = 6: period stride 2, 5 live rows per tile
     (8, 988, 988, 44100, 48000, False, BH | INTERP, (2000, 3000, 500, 9000)),         # small calls
@@ -147,22 +149,22 @@ def test_fixed_point_exponents_are_per_channel():
             assert _rms(y64 [:, c] - t64 [:, c]) <= 1.25 * _rms(l64 [:, c] - t64 [:, c]), c
 
 
-def test_fixed_point_floor_is_relative_to_the_channels_peak_in_the_call():
-    """a call whose first half is loud and whose second half is 80 dB quieter: ONE exponent per channel and launch, so the quiet
-    half is computed on the loud half's grid — its error floor is 2^-31 x the call's peak rms (about -196 dB below that peak;
-    measured ~0.6 of it), not relative to the quiet signal; a following call that only sees the quiet signal has the quiet
-    signal's own exponent again and meets the float-loop bar"""
-    ch, T, frames = 8, 988, 70000
+def test_fixed_point_floor_is_relative_to_the_channels_peak_in_the_exponent_block():
+    """a call that starts loud and drops by 80 dB after 20,000 frames: exponents belong to blocks of ~10k input frames (8 channels x
+    988 taps), so only the outputs whose block still sees loud frames are computed on the loud grid — their error floor is
+    2^-31 x the loud peak rms (about -196 dB below that peak), not relative to the quiet signal; one block later the quiet
+    signal has its own exponent and meets the float-loop bar again, inside the same call"""
+    ch, T, frames, loud = 8, 988, 90000, 20000
     ratio = 48000 / 44100
-    x, _ = noise(3 * frames * ch, state=0xF00D | 1)
-    x = x.reshape(3 * frames, ch).copy()
-    x [frames // 2:] *= np.float32(1e-4)
+    x, _ = noise(2 * frames * ch, state=0xF00D | 1)
+    x = x.reshape(2 * frames, ch).copy()
+    x [loud:] *= np.float32(1e-4)
     cap = int(frames * ratio) + 4000
     r = HipResampler(ch, T, T, 0.0, BH | INTERP, kernel=7); r.advance(T / 2)
     o = OracleResampler(ch, T, T, 0.0, BH | INTERP | PRECISE); o.advance(T / 2)
     l = OracleResampler(ch, T, T, 0.0, BH | INTERP); l.advance(T / 2)
     errs, refs = [], []
-    for k in range(3):
+    for k in range(2):
         blk = x [k * frames:(k + 1) * frames]
         u, g, y = r.process(blk, cap, ratio)
         assert r.fixed_point() [0] == 1
@@ -171,12 +173,13 @@ def test_fixed_point_floor_is_relative_to_the_channels_peak_in_the_call():
         errs.append(np.array(y, np.float64) - np.array(yo, np.float64))
         refs.append(np.array(yl, np.float64) - np.array(yo, np.float64))
         assert tolerance_ok(np.array(y), np.array(yo)) [0]
-    quiet_from = int(frames // 2 * ratio) + 2 * T               # outputs of call 0 that only see quiet samples
-    assert _rms(errs [0] [:quiet_from - 4 * T]) <= 1.25 * _rms(refs [0] [:quiet_from - 4 * T])      # the loud half: float-loop bar
-    assert _rms(errs [0] [quiet_from:]) <= 2.0 ** -31 * 0.5                                             # the quiet half: the call's floor
-    # call 1 still convolves with (loud-grid) history only through its own exponent: its history is quiet, so is its peak
-    assert _rms(errs [2]) <= 1.25 * _rms(refs [2])
-    assert _rms(errs [1] [2 * T:]) <= 1.25 * _rms(refs [1] [2 * T:])
+    n_loud = int((loud - 2 * T) * ratio)                        # outputs that only see loud samples
+    n_mixed = int((loud + 2 * T) * ratio)                       # from here on: quiet samples only, possibly still on the loud grid
+    n_quiet = int((loud + 14000) * ratio)                       # one exponent block (9,408 frames + a window) later
+    assert _rms(errs [0] [:n_loud]) <= 1.25 * _rms(refs [0] [:n_loud])
+    assert _rms(errs [0] [n_mixed:n_quiet]) <= 2.0 ** -31 * 0.5                # the loud block's floor
+    assert _rms(errs [0] [n_quiet:]) <= 1.25 * _rms(refs [0] [n_quiet:])       # the quiet signal on its own grid, same call
+    assert _rms(errs [1]) <= 1.25 * _rms(refs [1])
 
 
 BAD = [("above the old range", 2.5, 1), ("below the old range", -1.99, 1), ("huge", -3e30, 1), ("infinity", np.inf, 2), ("NaN", np.nan, 2)]
@@ -188,7 +191,7 @@ def test_samples_the_digits_cannot_hold_hand_the_launch_to_the_f32_kernel(what, 
     """an infinity or a NaN anywhere in the call, or in the history it still convolves with: the fixed-point kernel stands down on
     the device and the f32 streaming kernel's tile loop produces the call — the same bits as with that kernel pinned; calls that
     do not touch the sample run in fixed point again.  Any FINITE sample, however large, is held: the channel's exponent follows
-    its peak (the launch stays in fixed point; the other samples of that channel and launch sit on the outlier's grid)"""
+    its peak (the launch stays in fixed point; the other samples of that channel in the same exponent block sit on the outlier's grid)"""
     ch, T, F, flags = shape
     frames = 60000
     ratio = 48000 / 44100

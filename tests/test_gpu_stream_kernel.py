@@ -24,6 +24,7 @@ CASES = [
     (2, 380, 380, 44100, 48000, True, BH | INTERP | LOWPASS, (150000, 150000)),       # ART form: 160 x 380 nearest filter, SNAP, low-pass
     (8, 988, 988, 96000, 44100, True, BH | INTERP | LOWPASS, (140000, 140000)),       # config C's resampler: 147 x 988 nearest filter
     (2, 380, 320, 44100, 48000, False, BH, (120000, 120000)),                         # nearest filter, no low-pass: pass-through samples (F = 2P)
+    (2, 380, 32, 44100, 48000, False, BH, (120000, 120000)),                          # nearest filter, F < P: five pass-through slots per period, two of them in one tile
     (2, 64, 160, 48000, 44100, False, BH, (250000,)),                                 # short filter, 3 chunks, P = 147
     (8, 988, 988, 44100, 48000, False, BH | INTERP, (2000, 3000, 500, 9000)),         # small calls: fewer tiles than workgroups
 ]
