@@ -278,7 +278,7 @@ void i8_stage_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g, I8Geom q)
             }
         }
         unsigned long long mine = 0ull;
-        unsigned char *base = q.a_planes + (size_t) variant * (g.ktot / I8_KC) * 4096 + row * 32;
+        unsigned char *base = q.a_planes + (size_t) variant * (g.ktot / I8_KC) * 4096 + row * 16;
         for (int k4 = tid * 4; k4 < g.ktot; k4 += 1024) {
             unsigned int s [4], pl [4];
 #pragma unroll
@@ -298,7 +298,7 @@ void i8_stage_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g, I8Geom q)
             }
             to_planes (s, pl);
 #pragma unroll
-            for (int pn = 0; pn < 4; ++pn) *reinterpret_cast<unsigned int *> (base + (size_t)(k4 >> 5) * 4096 + pn * 1024 + (k4 & 31)) = pl [pn];
+            for (int pn = 0; pn < 4; ++pn) *reinterpret_cast<unsigned int *> (base + (size_t)(k4 >> 5) * 4096 + pn * 1024 + ((k4 >> 4) & 1) * 512 + (k4 & 15)) = pl [pn];
             if (pl [0]) mine |= 1ull << (k4 >> 5);
         }
         if (mine) atomicOr (&s_mask, mine);
@@ -410,8 +410,8 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
         constexpr int VPF = CG / VEC, VPP = (I8_KC / 4) * VPF, NB = (PPW * VPP) / MF_THREADS;
         static_assert ((PPW * VPP) % MF_THREADS == 0 && NB >= 1, "every staging thread moves NB vectors per plane and chunk");
         constexpr unsigned int A_STEP = 4096u, B_STEP = (I8_KC / 4) * CG * 4u;
-        // A: thread -> (plane, row, 16-tap half), consecutive threads on consecutive 16 bytes of the chunk's 4 KB
-        const int a_plane = pt >> 6, a_row = (pt >> 1) & 31, a_half = pt & 1;
+        // A: thread -> (plane, 16-tap half, row), consecutive threads on consecutive 16 bytes of the chunk's 4 KB
+        const int a_plane = pt >> 6, a_half = (pt >> 5) & 1, a_row = pt & 31;
         const unsigned int a_off0 = (unsigned int) pt * 16u;
         const int adst = a_plane * (32 * I8_PITCH) + a_row * I8_PITCH + a_half * 16;
         unsigned int boff [NB], bdel [NB]; int bdst [NB], bper [NB];
@@ -592,6 +592,231 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same kernel with the staging done by the LDS-DMA path (buffer_load ... lds, 16 bytes per lane: gfx950), for streams of 4
+// channels and more.  fir_i8_stream_kernel above spends its LDS time on the staging waves' writes — per chunk and workgroup 64
+// ds_write_b32 wave-instructions (a loaded dword = 4 taps x 1 column, 4 columns per 16-byte load, each to another LDS row), two-way
+// conflicting — and holds every chunk in registers on the way.  Here the loaded 16 bytes land in the LDS as they are:
+//   B image  [plane][4-tap block kb][column][4 taps]   (a wave's 64 lanes = 2 kb x 32 column quads = 1 KB, lane-linear, which is
+//            what the hardware writes: base + lane x 16); a matrix lane picks its column's four dwords 512 bytes apart
+//            (two ds_read2st64_b32 per plane, conflict-free);
+//   A image  [plane][16-tap half][row][16 taps] — the order the staging pass already leaves in memory.
+// No staging registers, no ds_write; three LDS buffers (chunk c being multiplied, c + 1 landed, c + 2 in flight: the depth the
+// two register stages gave), the same 60 KB.  The four staging waves only issue (5 DMA instructions per chunk each), count their
+// own landings (s_waitcnt vmcnt) and meet the matrix waves at the one barrier per chunk — raw s_barrier: __syncthreads () would
+// drain the DMA in flight.
+// ---------------------------------------------------------------------------------------------------
+typedef __attribute__ ((address_space (3))) void *lds_ptr_t;
+#ifndef I8_DMA_BUFS
+#define I8_DMA_BUFS 3
+#endif
+
+template <int CG, bool PASS>
+__global__ __launch_bounds__ (2 * MF_THREADS) __attribute__ ((amdgpu_waves_per_eu (4, 4)))
+void fir_i8_dma_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
+{
+    static_assert (CG >= 4 && I8_COLS % CG == 0, "16-byte vectors of 4 channels");
+    constexpr int THREADS = 2 * MF_THREADS;
+    constexpr int PPW = I8_COLS / CG;
+    constexpr int NBUF = I8_DMA_BUFS, A_BUF = 4096, B_BUF = 16384;
+    __shared__ __attribute__ ((aligned (16))) unsigned char As_ [NBUF * A_BUF];
+    __shared__ __attribute__ ((aligned (16))) unsigned char Bs_ [NBUF * B_BUF];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool loader = wave >= 4;
+
+    const unsigned int stream_blocks = 8u * (unsigned int) wgs_per_xcd;
+    if (blockIdx.x >= stream_blocks) {                        // extra workgroups: the history roll (as in fir_mfma_kernel)
+        if (a.roll_dst) {
+            const int e = (int)(blockIdx.x - stream_blocks) * THREADS + tid;
+            if (e < a.H * a.C) {
+                const int f = e / a.C, c = e - f * a.C, lin = a.roll_appended + f;
+                float v = 0.0f;
+                if (lin < a.H) v = a.hist [(size_t) lin * a.C + c];
+                else if (a.in && lin - a.H < a.in_frames) v = a.in [(size_t)(lin - a.H) * a.C + c];
+                a.roll_dst [e] = v;
+            }
+        }
+        return;
+    }
+    // (stand-by: as fir_i8_stream_kernel)
+    if (*q.flag == q.epoch) {
+        static_assert (sizeof (As_) >= 2 * 32 * MF_LD * sizeof (float) && sizeof (Bs_) >= 2 * MF_COLS * MF_LD * sizeof (float), "the f32 tiles live in the digit buffers");
+        stand_by_tiles<CG, PASS> (a, g, wgs_per_xcd, *reinterpret_cast<float (*) [2] [32 * MF_LD]> (&As_ [0]), *reinterpret_cast<float (*) [2] [MF_COLS * MF_LD]> (&Bs_ [0]));
+        return;
+    }
+
+    const int xcd = blockIdx.x & 7, rank = blockIdx.x >> 3;
+    const int tiles_per_xcd = q.sg_per_xcd * q.g * g.slot_tiles;
+    const int nchunks = g.ktot / I8_KC;
+
+    // tile `within` of this XCD's list -> (slot tile, first period); false if the tile holds no output of the launch
+    auto tile_at = [&] (int within, int &st, int &j0) -> bool {
+        st = within % g.slot_tiles;
+        const int t2 = within / g.slot_tiles, jr = t2 % q.g, sg = xcd * q.sg_per_xcd + t2 / q.g;
+        if (sg >= q.super_groups) return false;
+        j0 = sg * q.g * PPW + jr;
+        return a.n_begin + (unsigned int) j0 * g.P + (unsigned int)(st * 32) < a.n_end;
+    };
+    int my_tiles = 0;
+    { int st, j0; for (int w = rank; w < tiles_per_xcd; w += wgs_per_xcd) my_tiles += tile_at (w, st, j0) ? 1 : 0; }
+    if (my_tiles == 0) return;
+    const int total = my_tiles * nchunks;
+
+    if (loader) {
+        constexpr int VPF = CG / 4;                           // 16-byte vectors per 4-frame block of the stream
+        constexpr unsigned int A_STEP = 4096u, B_STEP = (I8_KC / 4) * CG * 4u;
+        const int lw = wave - 4;                              // this wave: A plane lw, B 4-tap blocks 2 lw and 2 lw + 1 of every plane
+        const int kb = 2 * lw + (lane >> 5), colquad = lane & 31, m = colquad / VPF, cv = colquad - m * VPF;
+        const unsigned int boff = (unsigned int)((m * q.gq4 + kb) * CG + cv * 4) * 4u;       // (the tile's first block sits in the resource base)
+        const unsigned int a_off = (unsigned int)(lw * 1024 + lane * 16);
+        // a column whose period lies d exponent blocks behind the tile's first column stages from that block's own planes: d regions
+        // further on, where the same 4-frame block sits d * eb_step blocks earlier
+        const unsigned int x_total = 4u * q.eb_plane_bytes;
+        const unsigned int eb_hop = x_total - (unsigned int) q.eb_step * (unsigned int)(CG * 4);
+        unsigned int bdel = 0u;
+        // (the tile table through the scalar cache: a vector load here would sit on the VM counter among the DMAs)
+        const __attribute__ ((address_space (4))) int *tile_w0 = (const __attribute__ ((address_space (4))) int *) g.tile_w0;
+
+        int f_within = rank - wgs_per_xcd, f_chunk = 0;
+        bool f_live = false;
+        const unsigned char *fa_base = nullptr, *fb_base = nullptr;
+        unsigned int fa_bytes = 0, fb_bytes = 0;
+        auto open_tile = [&] () {                             // next tile of this workgroup's list that holds outputs
+            int st = 0, j0 = 0;
+            f_live = false;
+            for (f_within += wgs_per_xcd; f_within < tiles_per_xcd; f_within += wgs_per_xcd)
+                if (tile_at (f_within, st, j0)) { f_live = true; break; }
+            if (!f_live) return;
+            const int la = max (tile_w0 [3 * st] + j0 * g.Q + I8_PADF, 0);
+            const int eb = j0 / q.eb_periods;
+            unsigned int skip = (unsigned int) max ((la >> 2) - q.b0 - eb * q.eb_step, 0) * (unsigned int)(CG * 4);
+            if (skip > q.eb_plane_bytes) skip = q.eb_plane_bytes;
+            const size_t from = (size_t) eb * x_total + skip;
+            fb_base = q.x_planes + from; fb_bytes = (unsigned int) min (q.x_bytes - from, (size_t) 0xfffffff0u);
+            bdel = (unsigned int)((j0 + m * q.g) / q.eb_periods - eb) * eb_hop;
+            fa_bytes = (unsigned int) nchunks * 4096u;
+            fa_base = q.a_planes + (size_t)(st * q.g + j0 % q.g) * fa_bytes;
+        };
+        // the next chunk of the workgroup's stream -> LDS buffer `buf`: 5 DMA instructions of this wave, or none past the end
+        auto issue = [&] (int buf) -> bool {
+            if (!f_live) return false;
+            const unsigned int sa = (unsigned int) f_chunk * A_STEP, sb = min ((unsigned int) f_chunk * B_STEP, fb_bytes);
+            const __amdgpu_buffer_rsrc_t ra_ = make_rsrc (fa_base + sa, fa_bytes - sa), rb_ = make_rsrc (fb_base + sb, fb_bytes - sb);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds (ra_, (lds_ptr_t)(As_ + buf * A_BUF + lw * 1024), 16, (int) a_off, 0, 0, 0);
+#pragma unroll
+            for (int pn = 0; pn < 4; ++pn)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds (rb_, (lds_ptr_t)(Bs_ + buf * B_BUF + pn * 4096 + lw * 1024), 16, (int)(boff + bdel), (int)((unsigned int) pn * q.eb_plane_bytes), 0, 0);
+            if (++f_chunk == nchunks) { f_chunk = 0; open_tile (); }
+            return true;
+        };
+
+        open_tile ();
+        bool all = true;
+#pragma unroll
+        for (int b = 0; b < NBUF - 1; ++b) all = issue (b) && all;
+        // (NBUF - 1 chunks in flight: chunk 0 has landed once at most the NBUF - 2 behind it are outstanding, 5 instructions each)
+        if (all) { if constexpr (NBUF == 3) asm volatile ("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile ("s_waitcnt vmcnt(10)" ::: "memory"); }
+        else asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier ();                        // chunk 0 has landed
+        int fill = NBUF - 1;                                 // the buffer chunk c + NBUF - 1 goes to
+        for (int c = 0; c < total; ++c) {
+            const bool more = issue (fill);
+            fill = fill == NBUF - 1 ? 0 : fill + 1;
+            // chunk c + 1 has landed once at most the NBUF - 2 chunks behind it are outstanding (at the end of the stream: none)
+            if (more) { if constexpr (NBUF == 3) asm volatile ("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile ("s_waitcnt vmcnt(10)" ::: "memory"); }
+            else asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier ();
+        }
+        return;
+    }
+
+    // ---- matrix waves ----
+    {   // the two workgroups of a CU share each SIMD's matrix pipe: left alone their matrix waves fall into step (both multiply, then
+        // both wait for the LDS and the barrier); different issue priorities make them alternate instead
+        const unsigned int hw_id = __builtin_amdgcn_s_getreg ((4 - 1) << 11 | 16 << 6 | 4);      // HW_ID.TG_ID: bits 19:16
+        if (hw_id & 1u) __builtin_amdgcn_s_setprio (3); else __builtin_amdgcn_s_setprio (0);
+    }
+    const int col = wave * 32 + (lane & 31);
+    const int jl = col / CG, c = col - jl * CG;
+    const unsigned char *Ab0 = As_ + (lane & 31) * 16 + (lane >> 5) * 512;
+    const unsigned char *Bb0 = Bs_ + (lane >> 5) * 2048 + col * 4;
+    // output offset of this lane inside a tile: (period jl * g, slot 4 * (lane >> 5), channel c); the row's own 0..3 / +8 / +16 / +24
+    // slots are immediates of the store
+    const unsigned int out_off = (unsigned int)((jl * q.g * g.P + 4 * (lane >> 5)) * CG + c) * 4u;
+
+    __builtin_amdgcn_s_barrier ();                            // the staging waves have seen chunk 0 land
+    asm volatile ("" ::: "memory");
+    int qb = 0;                                              // LDS buffer of the next chunk
+    for (int within = rank; within < tiles_per_xcd; within += wgs_per_xcd) {
+        int st, j0;
+        if (!tile_at (within, st, j0)) continue;
+        // rows carry 30 fraction bits, this lane's channel 2^shift in its period's exponent block; the class sums are combined at
+        // weight 256^(4 - s) in units of 2^16: the result is scaled by 2^(-14 - shift) (loaded now, used after the K loop)
+        const int out_exp = -14 - q.shifts [((j0 + jl * q.g) / q.eb_periods) * CG + c];
+        i32x16 acc [5];
+#pragma unroll
+        for (int s = 0; s < 5; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc [s] [r] = 0;
+        // chunks in which some row of this tile has a non-zero most significant digit (the few around the rows' centres: taps
+        // fall off as 1 / distance): everywhere else the four products with that digit plane are exactly zero and not issued
+        unsigned long long top = q.a_masks [(st * q.g + j0 % q.g) * 32 + (lane & 31)];
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) top |= __shfl_xor (top, off);
+        const unsigned int top_lo = __builtin_amdgcn_readfirstlane ((unsigned int) top), top_hi = __builtin_amdgcn_readfirstlane ((unsigned int)(top >> 32));
+
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const unsigned char *Ab = Ab0 + qb * A_BUF, *Bb = Bb0 + qb * B_BUF;
+            qb = qb == NBUF - 1 ? 0 : qb + 1;
+            i32x4 av [4], bv [4];
+#pragma unroll
+            for (int pn = 0; pn < 4; ++pn) {
+                av [pn] = *reinterpret_cast<const i32x4 *> (Ab + pn * 1024);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bv [pn] [i] = *reinterpret_cast<const int *> (Bb + pn * 4096 + i * 512);
+            }
+            // all twelve operand reads are issued together and, once they have landed, the buffer is handed back (its next writer is
+            // the DMA of three chunks on)
+            __builtin_amdgcn_sched_group_barrier (0x100, 12, 0);
+            asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier ();
+            asm volatile ("" ::: "memory");
+#pragma unroll
+            for (int i = 1; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (i + j <= 4) acc [i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8 (av [i], bv [j], acc [i + j], 0, 0, 0);
+            if (((ch < 32 ? top_lo >> ch : top_hi >> (ch - 32)) & 1u) != 0u) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc [j] = __builtin_amdgcn_mfma_i32_32x32x32_i8 (av [0], bv [j], acc [j], 0, 0, 0);
+            }
+        }
+
+        // ---- the tile's outputs: C/D layout of 32x32: row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31
+        const unsigned int n_tile = a.n_begin + (unsigned int) j0 * g.P + (unsigned int)(st * 32);
+        const int rows_valid = min (32, g.P - st * 32);
+        const size_t left = (size_t)(a.n_end - n_tile) * CG * 4;
+        const __amdgpu_buffer_rsrc_t rs_out = make_rsrc (a.out + (size_t) n_tile * CG, left > 0xffffff00ull ? 0xffffff00u : (unsigned int) left);
+        const unsigned int pass_rows = PASS ? (unsigned int) g.tile_w0 [3 * st + 1] : 0u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i_const = (r & 3) + 8 * (r >> 2);      // compile-time part of the slot
+            double v = (double) acc [0] [r];
+#pragma unroll
+            for (int s = 1; s < 5; ++s) v = v * 256.0 + (double) acc [s] [r];
+            float y = (float) __builtin_ldexp (v, out_exp);
+            const int i = i_const + 4 * (lane >> 5);
+            if constexpr (PASS) {
+                if ((pass_rows >> i) & 1u)
+                    y = load_frame (a, INT_MIN, g.canon_ip [st * 32 + i] + g.canon_fi [st * 32 + i] / a.F + (j0 + jl * q.g) * g.Q, c);
+            }
+            if (i < rows_valid)                              // (frames at or past n_end: out of the resource's range, dropped)
+                __builtin_amdgcn_raw_buffer_store_b32 (__float_as_uint (y), rs_out, (int)(out_off + (unsigned int)(i_const * CG) * 4u), 0, 0);
+        }
+    }
+}
+
 } // namespace
 
 // The planes buffer of a launch: [header: flag (art_internal.h)][row masks][exponents][A digit planes][X digit planes per exponent block];
@@ -698,7 +923,13 @@ int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGe
     const bool pass = !a->interpolate && !a->lowpass;
 #define I8_GO(CGT) do { if (pass) hipLaunchKernelGGL ((fir_i8_stream_kernel<CGT, true>), sgrid, dim3 (2 * MF_THREADS), 0, st, *a, g, q, wgs_per_xcd); \
                         else hipLaunchKernelGGL ((fir_i8_stream_kernel<CGT, false>), sgrid, dim3 (2 * MF_THREADS), 0, st, *a, g, q, wgs_per_xcd); } while (0)
-    switch (cgt) { case 32: I8_GO (32); break; case 16: I8_GO (16); break; case 8: I8_GO (8); break; case 4: I8_GO (4); break; case 2: I8_GO (2); break; default: I8_GO (1); }
+#define I8_DMA(CGT) do { if (pass) hipLaunchKernelGGL ((fir_i8_dma_kernel<CGT, true>), sgrid, dim3 (2 * MF_THREADS), 0, st, *a, g, q, wgs_per_xcd); \
+                         else hipLaunchKernelGGL ((fir_i8_dma_kernel<CGT, false>), sgrid, dim3 (2 * MF_THREADS), 0, st, *a, g, q, wgs_per_xcd); } while (0)
+    // (ARTAMD_I8_DMA=0: the register-staged kernel for every channel count — comparisons; the results are the same bits)
+    static const bool dma = [] { const char *e = getenv ("ARTAMD_I8_DMA"); return !(e && *e == '0'); } ();
+    if (dma && cgt >= 4) switch (cgt) { case 32: I8_DMA (32); break; case 16: I8_DMA (16); break; case 8: I8_DMA (8); break; default: I8_DMA (4); }
+    else switch (cgt) { case 32: I8_GO (32); break; case 16: I8_GO (16); break; case 8: I8_GO (8); break; case 4: I8_GO (4); break; case 2: I8_GO (2); break; default: I8_GO (1); }
+#undef I8_DMA
 #undef I8_GO
     if (a->ev_stop) arthip_event_record (a->ev_stop, (void *) st);
     return 1;
