@@ -125,6 +125,8 @@ def _bind(width):
         "artamdPlanCall": (C.c_int, [C.POINTER(ArtamdPosition), C.c_int, C.c_int, C.c_double, C.POINTER(ResampleResult),
                                      C.POINTER(ArtamdSegment), C.c_int, C.POINTER(C.c_int)]),
         "biquadBankCreate": (ptr, [C.POINTER(Biquad), C.c_int, C.c_int]),
+        "biquadBankCreateMulti": (ptr, [C.POINTER(Biquad), C.c_int, C.c_int]),
+        "biquadBankShardCount": (C.c_int, [ptr]),
         "biquadBankSetStream": (None, [ptr, ptr]),
         "biquadBankApplyInterleavedDevice": (None, [ptr, ptr, C.c_int]),
         "biquadBankRead": (None, [ptr, C.POINTER(Biquad)]),
@@ -134,6 +136,7 @@ def _bind(width):
         "decimateHipSetStream": (None, [DP, ptr]),
         "decimateProcessInterleavedLEDevice": (None, [DP, ptr, C.c_int, ptr]),
         "decimateHipClipped": (C.c_long, [DP]),
+        "decimateHipShardCount": (C.c_int, [DP]),
         "floatIntegersLEDevice": (None, [ptr, C.c_double, C.c_int, C.c_int, C.c_int, ptr, C.c_int, ptr]),
         # stretch.h
         "stretchInit": (ptr, [C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -350,15 +353,18 @@ def _bind(width):
         def clipped(self):
             return self.L.decimateHipClipped(self.p)
 
+        def shards(self):
+            return self.L.decimateHipShardCount(self.p)
+
         def set_stream(self, s):
             self.L.decimateHipSetStream(self.p, s)
 
 
     class BiquadBank:
-        def __init__(self, sections, channels, nsections):
-            """sections: ctypes array (Biquad * (channels*nsections)), channel-major"""
+        def __init__(self, sections, channels, nsections, multi=False):
+            """sections: ctypes array (Biquad * (channels*nsections)), channel-major; multi: spread over the listed devices"""
             self.L = lib()
-            self.p = self.L.biquadBankCreate(sections, channels, nsections)
+            self.p = (self.L.biquadBankCreateMulti if multi else self.L.biquadBankCreate)(sections, channels, nsections)
             if not self.p:
                 raise RuntimeError("biquadBankCreate failed (no MI355X visible — there is no CPU path)")
             self.n = channels * nsections
@@ -378,6 +384,9 @@ def _bind(width):
 
         def repairs(self):
             return self.L.biquadBankRepairs(self.p)
+
+        def shards(self):
+            return self.L.biquadBankShardCount(self.p)
 
         def read(self):
             out = (Biquad * self.n)()

@@ -90,7 +90,14 @@ void  arthip_host_free (void *p);
 void *arthip_order_event_create (void);                    /* event without timing, for cross-stream ordering */
 int   arthip_stream_wait_event (void *stream, void *event);
 int   arthip_event_sync (void *event);
-void  arthip_enable_peer (int device, int peer);
+int   arthip_enable_peer (int device, int peer);            /* 1: `device` can address `peer`'s memory (or is it); 0: no route */
+int   arthip_slice_copy_bytes (void *dst, size_t dpitch, const void *src, size_t spitch, int width, size_t rows, void *stream);   /* strided rows of bytes, by a kernel */
+
+/* ---- resampler_host.c: the device list of multi-device contexts (artamdSetDevices / ARTAMD_DEVICES / ARTAMD_SHARDS) ----
+ * how many shards a MULTITHREADED context of `channels` channels gets (0 or 1: an ordinary context) and on which device shard s
+ * lives; devices that cannot address `home`'s memory are replaced by `home` */
+#define ART_MAX_DEVICES 64
+int   artamd_shard_plan (int channels, int home, int *devices_out);
 void *arthip_malloc (size_t bytes);
 void  arthip_free (void *p);
 int   arthip_h2d (void *dst, const void *src, size_t bytes, void *stream);

@@ -70,6 +70,16 @@ __global__ void slice_words_kernel (unsigned int *dst, size_t dpitch, const unsi
     }
 }
 
+// the same for rows of `width` BYTES (packed PCM of a channel slice: 2 or 3 bytes per sample need not make whole words)
+__global__ void slice_bytes_kernel (unsigned char *dst, size_t dpitch, const unsigned char *src, size_t spitch, int width, size_t rows)
+{
+    const size_t total = rows * (size_t) width, stride = (size_t) gridDim.x * blockDim.x;
+    for (size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const size_t r = e / width; const int w = (int)(e - r * width);
+        dst [r * dpitch + w] = src [r * spitch + w];
+    }
+}
+
 // dst / src: one of them page-locked host memory (hipHostMalloc: mapped, same address on the device), both 16-byte aligned,
 // bytes a multiple of 4
 int arthip_copy_by_kernel (void *dst, const void *src, size_t bytes, void *st) { return arthip_copy2_by_kernel (dst, src, bytes, nullptr, nullptr, 0, st); }
@@ -97,6 +107,20 @@ int arthip_slice_copy (void *dst, size_t dpitch_words, const void *src, size_t s
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL (slice_words_kernel, dim3 (blocks), dim3 (256), 0, (hipStream_t) st, (unsigned int *) dst, dpitch_words,
                         (const unsigned int *) src, spitch_words, width_words, rows);
+    return fail (hipGetLastError (), "slice kernel");
+}
+
+// rows of `width` bytes, row starts dpitch / spitch bytes apart (whole words where everything is word-aligned)
+int arthip_slice_copy_bytes (void *dst, size_t dpitch, const void *src, size_t spitch, int width, size_t rows, void *st)
+{
+    if (!rows || width <= 0) return 0;
+    if (!((dpitch | spitch | (size_t) width | (size_t)(uintptr_t) dst | (size_t)(uintptr_t) src) & 3))
+        return arthip_slice_copy (dst, dpitch / 4, src, spitch / 4, width / 4, rows, st);
+    const size_t total = rows * (size_t) width;
+    unsigned int blocks = (unsigned int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL (slice_bytes_kernel, dim3 (blocks), dim3 (256), 0, (hipStream_t) st, (unsigned char *) dst, dpitch,
+                        (const unsigned char *) src, spitch, width, rows);
     return fail (hipGetLastError (), "slice kernel");
 }
 
@@ -137,14 +161,23 @@ void *arthip_order_event_create (void)
 int arthip_stream_wait_event (void *st, void *ev) { return fail (hipStreamWaitEvent ((hipStream_t) st, (hipEvent_t) ev, 0), "hipStreamWaitEvent"); }
 int arthip_event_sync (void *ev) { return fail (hipEventSynchronize ((hipEvent_t) ev), "hipEventSynchronize"); }
 
-// let `device` read and write memory that lives on `peer` (xGMI); harmless when already enabled or impossible
-void arthip_enable_peer (int device, int peer)
+// let `device` read and write memory that lives on `peer` (xGMI); returns 1 when it can (same device, or peer access enabled now
+// or before), 0 when the platform refuses (no P2P route: IOMMU, containers, mixed topology) — the caller must then keep the two
+// sides on one device: a kernel dereferencing unreachable peer memory is a GPU page fault, not an error code
+int arthip_enable_peer (int device, int peer)
 {
     int can = 0, prev = 0;
-    if (device == peer || hipDeviceCanAccessPeer (&can, device, peer) != hipSuccess || !can) return;
-    if (hipGetDevice (&prev) != hipSuccess) return;
-    if (hipSetDevice (device) == hipSuccess) { (void) hipDeviceEnablePeerAccess (peer, 0); (void) hipGetLastError (); }
+    if (device == peer) return 1;
+    if (hipDeviceCanAccessPeer (&can, device, peer) != hipSuccess || !can) { (void) hipGetLastError (); return 0; }
+    if (hipGetDevice (&prev) != hipSuccess) return 0;
+    int ok = 0;
+    if (hipSetDevice (device) == hipSuccess) {
+        const hipError_t e = hipDeviceEnablePeerAccess (peer, 0);
+        ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+        (void) hipGetLastError ();
+    }
     (void) hipSetDevice (prev);
+    return ok;
 }
 
 void *arthip_event_create (void)

@@ -261,7 +261,15 @@ struct artamd_biquad_bank {
     unsigned int *d_repairs;
     int *d_first_bad;
     void *stream;
+    int device;
+    /* a bank spread over several devices (biquadBankCreateMulti): ordinary banks with contiguous channel slices, each on its own
+     * device and stream, + the slice of the caller's buffer each works on */
+    int nshards; BiquadBank **shards; int *shard_first; void **ev_shard; void *ev_parent;
+    art_s *d_slice; size_t slice_cap;
 };
+#define BANK_ENTER(b) const int prev_device_ = arthip_current_device (); \
+                      if (prev_device_ != (b)->device) arthip_set_device ((b)->device)
+#define BANK_LEAVE(b) do { if (prev_device_ != (b)->device && prev_device_ >= 0) arthip_set_device (prev_device_); } while (0)
 
 BiquadBank *biquadBankCreate (const Biquad *sections, int numChannels, int numSections)
 {
@@ -273,6 +281,7 @@ BiquadBank *biquadBankCreate (const Biquad *sections, int numChannels, int numSe
     if (!b) return NULL;
     const size_t bytes = sizeof (Biquad) * (size_t) numChannels * numSections;
     b->C = numChannels; b->S = numSections;
+    b->device = arthip_current_device ();
     b->all_order2 = numSections <= 2;
     b->warmup = spec_disabled () ? 0 : 1;
     for (int i = 0; i < numChannels * numSections; ++i) {
@@ -293,16 +302,83 @@ BiquadBank *biquadBankCreate (const Biquad *sections, int numChannels, int numSe
     return b;
 }
 
+/* The same bank spread over the devices of artamdSetDevices () / ARTAMD_DEVICES (ARTAMD_SHARDS forces the count), the way a
+ * RESAMPLE_MULTITHREADED resampler and a DECIMATE_MULTITHREADED decimator spread (channels are independent: art.c:1011-1017
+ * filters them one by one): an ordinary bank when there is one device.  Results are those of the ordinary bank, bit for bit. */
+BiquadBank *biquadBankCreateMulti (const Biquad *sections, int numChannels, int numSections)
+{
+    int devices [ART_MAX_DEVICES];
+    const int home = arthip_current_device ();
+    const int count = numChannels > 1 && arthip_device_count () >= 1 ? artamd_shard_plan (numChannels, home, devices) : 0;
+    if (count <= 1) return biquadBankCreate (sections, numChannels, numSections);
+
+    BiquadBank *b = calloc (1, sizeof (*b));
+    if (!b) return NULL;
+    b->C = numChannels; b->S = numSections; b->device = home;
+    b->shards = calloc ((size_t) count, sizeof (BiquadBank *));
+    b->shard_first = calloc ((size_t) count + 1, sizeof (int));
+    b->ev_shard = calloc ((size_t) count, sizeof (void *));
+    b->ev_parent = arthip_order_event_create ();
+    int ok = b->shards && b->shard_first && b->ev_shard && b->ev_parent;
+    const int base = numChannels / count, extra = numChannels % count;
+    for (int s = 0; ok && s < count; ++s) {
+        const int width = base + (s < extra ? 1 : 0);
+        b->shard_first [s + 1] = b->shard_first [s] + width;
+        arthip_set_device (devices [s]);
+        b->shards [s] = biquadBankCreate (sections + (size_t) b->shard_first [s] * numSections, width, numSections);
+        b->ev_shard [s] = arthip_order_event_create ();
+        b->nshards = s + 1;
+        ok = b->shards [s] && b->ev_shard [s] && (b->shards [s]->stream = arthip_stream_create ()) != NULL;
+    }
+    if (home >= 0) arthip_set_device (home);
+    if (!ok) { fprintf (stderr, "artamd: biquadBankCreateMulti: allocation failed: %s\n", arthip_last_error ()); biquadBankFree (b); return NULL; }
+    return b;
+}
+
+int biquadBankShardCount (BiquadBank *b) { return b->nshards; }
+
 /* (work already enqueued on the old stream uses the bank's state and scratch: drained before the switch) */
 void biquadBankSetStream (BiquadBank *b, void *stream)
 {
     if (b->stream == stream) return;
+    BANK_ENTER (b);
     arthip_sync (b->stream);
+    BANK_LEAVE (b);
     b->stream = stream;
 }
 
 void biquadBankApplyInterleavedDevice (BiquadBank *b, artsample_t *d_buffer, int numFrames)
 {
+    if (numFrames <= 0) return;
+    if (b->nshards) {
+        /* every shard waits for the bank's stream, pulls its channel slice of the caller's buffer (peer-to-peer when it sits on
+         * another device), filters it in its own HBM and pushes it back; the bank's stream then waits for all of them */
+        const int prev = arthip_current_device (), wps = (int)(sizeof (art_s) / 4);
+        arthip_set_device (b->device);
+        arthip_event_record (b->ev_parent, b->stream);
+        for (int k = 0; k < b->nshards; ++k) {
+            BiquadBank *sh = b->shards [k];
+            const int first = b->shard_first [k], width = b->shard_first [k + 1] - first;
+            const size_t need = sizeof (art_s) * (size_t) numFrames * width;
+            arthip_set_device (sh->device);
+            arthip_stream_wait_event (sh->stream, b->ev_parent);
+            if (need > sh->slice_cap) {
+                arthip_sync (sh->stream);
+                arthip_free (sh->d_slice);
+                sh->slice_cap = need + need / 2;
+                if (!(sh->d_slice = arthip_malloc (sh->slice_cap))) { sh->slice_cap = 0; fprintf (stderr, "artamd: sharded biquad bank: %s\n", arthip_last_error ()); continue; }
+            }
+            arthip_slice_copy (sh->d_slice, (size_t) width * wps, d_buffer + first, (size_t) b->C * wps, width * wps, (size_t) numFrames, sh->stream);
+            biquadBankApplyInterleavedDevice (sh, sh->d_slice, numFrames);
+            arthip_slice_copy (d_buffer + first, (size_t) b->C * wps, sh->d_slice, (size_t) width * wps, width * wps, (size_t) numFrames, sh->stream);
+            arthip_event_record (b->ev_shard [k], sh->stream);
+        }
+        arthip_set_device (b->device);
+        for (int k = 0; k < b->nshards; ++k) arthip_stream_wait_event (b->stream, b->ev_shard [k]);
+        if (prev >= 0) arthip_set_device (prev);
+        return;
+    }
+    BANK_ENTER (b);
     const int L = b->warmup ? spec_chunk (b->S, b->warmup) : 0;
 
     if (L && numFrames >= 2 * L) {
@@ -319,8 +395,10 @@ void biquadBankApplyInterleavedDevice (BiquadBank *b, artsample_t *d_buffer, int
         }
         if (b->d_tmp && b->d_spec) {
             arthip_d2d (b->d_tmp, d_buffer, samples * sizeof (art_s), b->stream);
-            if (!arthip_biquad_spec (b->d_sections, b->C, b->S, b->d_tmp, b->C, d_buffer, b->C, numFrames, L, b->warmup, b->d_spec, b->d_first_bad, b->d_repairs, b->stream))
+            if (!arthip_biquad_spec (b->d_sections, b->C, b->S, b->d_tmp, b->C, d_buffer, b->C, numFrames, L, b->warmup, b->d_spec, b->d_first_bad, b->d_repairs, b->stream)) {
+                BANK_LEAVE (b);
                 return;
+            }
         }
         fprintf (stderr, "artamd: time-parallel biquad unavailable (%s): serial kernel\n", arthip_last_error ());
     }
@@ -328,26 +406,54 @@ void biquadBankApplyInterleavedDevice (BiquadBank *b, artsample_t *d_buffer, int
         arthip_biquad_order2 (b->d_sections, b->C, b->S, d_buffer, numFrames, b->C, b->stream);
     else
         arthip_biquad_chain (b->d_sections, b->C, b->S, d_buffer, numFrames, b->C, b->stream);
+    BANK_LEAVE (b);
 }
 
 void biquadBankRead (BiquadBank *b, Biquad *sections)
 {
-    arthip_d2h (sections, b->d_sections, sizeof (Biquad) * (size_t) b->C * b->S, b->stream);
-    arthip_sync (b->stream);
+    BANK_ENTER (b);
+    if (b->nshards) {
+        arthip_sync (b->stream);
+        for (int k = 0; k < b->nshards; ++k) biquadBankRead (b->shards [k], sections + (size_t) b->shard_first [k] * b->S);
+    }
+    else {
+        arthip_d2h (sections, b->d_sections, sizeof (Biquad) * (size_t) b->C * b->S, b->stream);
+        arthip_sync (b->stream);
+    }
+    BANK_LEAVE (b);
 }
 
 /* chunks the time-parallel form had to recompute for this bank so far (synchronises; diagnostics) */
 unsigned int biquadBankRepairs (BiquadBank *b)
 {
     unsigned int n = 0;
-    arthip_d2h (&n, b->d_repairs, sizeof (n), b->stream);
-    arthip_sync (b->stream);
+    BANK_ENTER (b);
+    if (b->nshards) {
+        arthip_sync (b->stream);
+        for (int k = 0; k < b->nshards; ++k) n += biquadBankRepairs (b->shards [k]);
+    }
+    else {
+        arthip_d2h (&n, b->d_repairs, sizeof (n), b->stream);
+        arthip_sync (b->stream);
+    }
+    BANK_LEAVE (b);
     return n;
 }
 
 void biquadBankFree (BiquadBank *b)
 {
-    if (b) { arthip_sync (b->stream); arthip_free (b->d_sections); arthip_free (b->d_tmp); arthip_free (b->d_spec); arthip_free (b->d_repairs); arthip_free (b->d_first_bad); free (b); }
+    if (!b) return;
+    BANK_ENTER (b);
+    arthip_sync (b->stream);
+    for (int k = 0; k < b->nshards; ++k) {
+        if (b->shards [k]) { void *st = b->shards [k]->stream; biquadBankFree (b->shards [k]); arthip_stream_destroy (st); }
+        if (b->ev_shard && b->ev_shard [k]) arthip_event_destroy (b->ev_shard [k]);
+    }
+    if (b->ev_parent) arthip_event_destroy (b->ev_parent);
+    free (b->shards); free (b->shard_first); free (b->ev_shard);
+    arthip_free (b->d_sections); arthip_free (b->d_tmp); arthip_free (b->d_spec); arthip_free (b->d_repairs); arthip_free (b->d_first_bad); arthip_free (b->d_slice);
+    BANK_LEAVE (b);
+    free (b);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -366,8 +472,16 @@ struct artamd_decimator {
     art_s *d_in; size_t in_cap;
     unsigned char *d_out; size_t out_cap;
     unsigned char *h_in, *h_out; size_t h_in_cap, h_out_cap;       /* page-locked staging of small host-pointer calls */
+    int device;                                                    /* where the state lives (and where device-pointer buffers are expected) */
+    /* DECIMATE_MULTITHREADED over several devices (or ARTAMD_SHARDS): the reference's one-worker-per-channel fan-out
+     * (decimator.c:92-93, 119-136) with GPUs for threads — `nshards` ordinary contexts with contiguous channel slices, each on
+     * its own device and stream; this context then owns no kernel state itself, only the host mirrors of all channels */
+    int nshards; Decimate **shards; int *shard_first; void **ev_shard; void *ev_parent;
 };
 #define DEC_KERNEL_COPY_LIMIT ((size_t) 1 << 20)
+#define DEC_ENTER(hip) const int prev_device_ = arthip_current_device (); \
+                       if (prev_device_ != (hip)->device) arthip_set_device ((hip)->device)
+#define DEC_LEAVE(hip) do { if (prev_device_ != (hip)->device && prev_device_ >= 0) arthip_set_device (prev_device_); } while (0)
 
 /* noise-shaping transfer function N(z) (a0 == 1) -> error-feedback filter H(z), reference decimator.c:389-409 */
 static void shaper_design (Biquad *f, double a1, double a2, double a3, double a4, double b1, double b2, double b3, double b4)
@@ -398,23 +512,17 @@ static void shaper_for (Biquad *f, int flags, int rate)
 
 static uint32_t lcg_step (uint32_t r) { return ((r << 4) - r) ^ 1; }
 
-Decimate *decimateInit (int numChannels, int outputBits, int outputBytes, double outputGain, int sampleRate, int flags)
+/* an ordinary context on the current device; `firstChannel`: its channels are channels firstChannel.. of a wider stream (the
+ * dither generators of a stream are seeded channel after channel from one byte stream, decimator.c:40-52) */
+static Decimate *dec_init_leaf (int numChannels, int outputBits, int outputBytes, double outputGain, int sampleRate, int flags, int firstChannel)
 {
-    if (numChannels < 1 || outputBits < 1 || outputBits > 24 || outputBytes < (outputBits + 7) / 8 || outputBytes > 4) {
-        fprintf (stderr, "artamd: decimateInit: unsupported channel/bit/byte combination\n");
-        return NULL;
-    }
-    if (arthip_device_count () < 1) {
-        fprintf (stderr, "artamd: no usable HIP device (this library has no CPU path): %s\n", arthip_last_error ());
-        return NULL;
-    }
-
     Decimate *cxt = calloc (1, sizeof (Decimate));
     struct artamd_decimator *hip = calloc (1, sizeof (*hip));
     const int C = numChannels;
 
     if (!cxt || !hip) { free (cxt); free (hip); return NULL; }
     cxt->hip = hip;
+    hip->device = arthip_current_device ();
     cxt->numChannels = C; cxt->outputBits = outputBits; cxt->outputBytes = outputBytes;
     cxt->outputGain = outputGain; cxt->flags = flags;
     cxt->feedback = calloc (C, sizeof (art_s));
@@ -440,9 +548,9 @@ Decimate *decimateInit (int numChannels, int outputBits, int outputBytes, double
         /* per-channel seeds: little-endian words cut from the byte stream (state >> 24), three steps per byte */
         uint32_t s = 0x31415926;
         cxt->tpdf_generators = calloc (C, sizeof (uint32_t));
-        for (int c = 0; c < C; ++c)
+        for (int c = -firstChannel; c < C; ++c)
             for (int b = 0; b < 4; ++b) {
-                cxt->tpdf_generators [c] |= (uint32_t)(s >> 24) << (8 * b);
+                if (c >= 0) cxt->tpdf_generators [c] |= (uint32_t)(s >> 24) << (8 * b);
                 s = lcg_step (lcg_step (lcg_step (s)));
             }
         cxt->dither_type = (flags & DITHER_HIGHPASS) ? -1 : (flags & DITHER_LOWPASS) ? 1 : 0;
@@ -465,14 +573,92 @@ Decimate *decimateInit (int numChannels, int outputBits, int outputBytes, double
     return cxt;
 }
 
+static Decimate *dec_init_sharded (int numChannels, int outputBits, int outputBytes, double outputGain, int sampleRate, int flags, int count, const int *devices)
+{
+    Decimate *cxt = calloc (1, sizeof (Decimate));
+    struct artamd_decimator *hip = calloc (1, sizeof (*hip));
+    const int prev = arthip_current_device (), C = numChannels;
+
+    if (!cxt || !hip) { free (cxt); free (hip); return NULL; }
+    cxt->hip = hip;
+    hip->device = prev;
+    cxt->numChannels = C; cxt->outputBits = outputBits; cxt->outputBytes = outputBytes;
+    cxt->outputGain = outputGain; cxt->flags = flags;
+    cxt->dither_type = (flags & DITHER_HIGHPASS) ? -1 : (flags & DITHER_LOWPASS) ? 1 : 0;
+    cxt->feedback = calloc (C, sizeof (art_s));
+    if (flags & DITHER_ENABLED) cxt->tpdf_generators = calloc (C, sizeof (uint32_t));
+    if (flags & SHAPING_ENABLED) cxt->noise_shapers = calloc (C, sizeof (Biquad));
+    hip->shards = calloc ((size_t) count, sizeof (Decimate *));
+    hip->shard_first = calloc ((size_t) count + 1, sizeof (int));
+    hip->ev_shard = calloc ((size_t) count, sizeof (void *));
+    hip->ev_parent = arthip_order_event_create ();
+    int ok = cxt->feedback && hip->shards && hip->shard_first && hip->ev_shard && hip->ev_parent;
+
+    /* contiguous, balanced channel slices: the first (channels % count) shards get one channel more */
+    const int base = C / count, extra = C % count;
+    for (int s = 0; ok && s < count; ++s) {
+        const int width = base + (s < extra ? 1 : 0);
+        hip->shard_first [s + 1] = hip->shard_first [s] + width;
+        arthip_set_device (devices [s]);                  /* (artamd_shard_plan has made sure it can address `prev`'s memory) */
+        Decimate *leaf = dec_init_leaf (width, outputBits, outputBytes, outputGain, sampleRate, flags & ~DECIMATE_MULTITHREADED, hip->shard_first [s]);
+        hip->shards [s] = leaf;
+        hip->ev_shard [s] = arthip_order_event_create ();
+        hip->nshards = s + 1;
+        ok = leaf && hip->ev_shard [s] && (leaf->hip->stream = arthip_stream_create ()) != NULL;
+        if (ok) {       /* the host-visible state of the whole stream, as every context shows it */
+            const int first = hip->shard_first [s];
+            if (cxt->tpdf_generators && leaf->tpdf_generators) memcpy (cxt->tpdf_generators + first, leaf->tpdf_generators, sizeof (uint32_t) * width);
+            if (cxt->noise_shapers && leaf->noise_shapers) memcpy (cxt->noise_shapers + first, leaf->noise_shapers, sizeof (Biquad) * width);
+        }
+    }
+    if (prev >= 0) arthip_set_device (prev);
+    if (!ok) {
+        fprintf (stderr, "artamd: sharded decimator: allocation failed: %s\n", arthip_last_error ());
+        decimateFree (cxt);
+        return NULL;
+    }
+    return cxt;
+}
+
+Decimate *decimateInit (int numChannels, int outputBits, int outputBytes, double outputGain, int sampleRate, int flags)
+{
+    if (numChannels < 1 || outputBits < 1 || outputBits > 24 || outputBytes < (outputBits + 7) / 8 || outputBytes > 4) {
+        fprintf (stderr, "artamd: decimateInit: unsupported channel/bit/byte combination\n");
+        return NULL;
+    }
+    if (arthip_device_count () < 1) {
+        fprintf (stderr, "artamd: no usable HIP device (this library has no CPU path): %s\n", arthip_last_error ());
+        return NULL;
+    }
+    if ((flags & DECIMATE_MULTITHREADED) && numChannels > 1) {
+        int devices [ART_MAX_DEVICES];
+        const int count = artamd_shard_plan (numChannels, arthip_current_device (), devices);
+        if (count > 1)
+            return dec_init_sharded (numChannels, outputBits, outputBytes, outputGain, sampleRate, flags, count, devices);
+    }
+    return dec_init_leaf (numChannels, outputBits, outputBytes, outputGain, sampleRate, flags, 0);
+}
+
 void decimateFree (Decimate *cxt)
 {
     if (!cxt) return;
     struct artamd_decimator *hip = cxt->hip;
     if (hip) {
+        DEC_ENTER (hip);
         arthip_sync (hip->stream);
         arthip_free (hip->d_state); arthip_host_free (hip->h_state);
         arthip_free (hip->d_in); arthip_free (hip->d_out); arthip_host_free (hip->h_in); arthip_host_free (hip->h_out);
+        for (int s = 0; s < hip->nshards; ++s) {
+            if (hip->shards [s]) {
+                void *st = hip->shards [s]->hip ? hip->shards [s]->hip->stream : NULL;
+                decimateFree (hip->shards [s]);
+                arthip_stream_destroy (st);
+            }
+            if (hip->ev_shard && hip->ev_shard [s]) arthip_event_destroy (hip->ev_shard [s]);
+        }
+        if (hip->ev_parent) arthip_event_destroy (hip->ev_parent);
+        free (hip->shards); free (hip->shard_first); free (hip->ev_shard);
+        DEC_LEAVE (hip);
         free (hip);
     }
     free (cxt->feedback); free (cxt->tpdf_generators); free (cxt->noise_shapers);
@@ -495,27 +681,81 @@ static void dec_args (Decimate *cxt, ArtDecArgs *a)
 void decimateHipSetStream (Decimate *cxt, void *stream)
 {
     if (cxt->hip->stream == stream) return;
+    DEC_ENTER (cxt->hip);
     arthip_sync (cxt->hip->stream);
+    DEC_LEAVE (cxt->hip);
     cxt->hip->stream = stream;
 }
+
+/* shards of a DECIMATE_MULTITHREADED context (0: an ordinary context) */
+int decimateHipShardCount (Decimate *cxt) { return cxt->hip->nshards; }
 
 static void dec_swap_if (Decimate *cxt, int rc)
 {
     if (rc == 1) { uint32_t *t = cxt->hip->d_gens; cxt->hip->d_gens = cxt->hip->d_gens_alt; cxt->hip->d_gens_alt = t; }
 }
 
+static int dec_reserve (Decimate *cxt, size_t in_bytes, size_t out_bytes);
+
+/* a sharded context's call on device buffers (the caller's, or this context's own staging of a host-pointer call): every shard
+ * waits for the context's stream, pulls its channel slice with a slice kernel (peer-to-peer when it sits on another device),
+ * decimates it with its own state and pushes its packed bytes into the interleaved output; the context's stream then waits for
+ * all of them */
+static void dec_sharded_device_call (Decimate *cxt, const art_s *d_input, int frames, unsigned char *d_output)
+{
+    struct artamd_decimator *hip = cxt->hip;
+    const int C = cxt->numChannels, B = cxt->outputBytes, prev = arthip_current_device ();
+    const int wps = (int)(sizeof (art_s) / 4);
+
+    arthip_set_device (hip->device);
+    arthip_event_record (hip->ev_parent, hip->stream);
+    for (int k = 0; k < hip->nshards; ++k) {
+        Decimate *leaf = hip->shards [k];
+        struct artamd_decimator *sp = leaf->hip;
+        const int first = hip->shard_first [k], width = hip->shard_first [k + 1] - first;
+        ArtDecArgs a;
+        arthip_set_device (sp->device);
+        arthip_stream_wait_event (sp->stream, hip->ev_parent);
+        if (dec_reserve (leaf, (size_t) frames * width * sizeof (art_s), (size_t) frames * width * B)) {
+            fprintf (stderr, "artamd: sharded decimator: device allocation failed: %s\n", arthip_last_error ());
+            continue;
+        }
+        arthip_slice_copy (sp->d_in, (size_t) width * wps, d_input + first, (size_t) C * wps, width * wps, (size_t) frames, sp->stream);
+        dec_args (leaf, &a);
+        dec_swap_if (leaf, arthip_decimate (&a, sp->d_in, frames, sp->d_out, sp->stream));
+        arthip_slice_copy_bytes (d_output + (size_t) first * B, (size_t) C * B, sp->d_out, (size_t) width * B, width * B, (size_t) frames, sp->stream);
+        arthip_event_record (hip->ev_shard [k], sp->stream);
+    }
+    arthip_set_device (hip->device);
+    for (int k = 0; k < hip->nshards; ++k)
+        arthip_stream_wait_event (hip->stream, hip->ev_shard [k]);
+    if (prev >= 0) arthip_set_device (prev);
+}
+
 void decimateProcessInterleavedLEDevice (Decimate *cxt, const artsample_t *d_input, int numInputFrames, unsigned char *d_output)
 {
+    if (numInputFrames <= 0) return;
+    if (cxt->hip->nshards) { dec_sharded_device_call (cxt, d_input, numInputFrames, d_output); return; }
     ArtDecArgs a;
+    DEC_ENTER (cxt->hip);
     dec_args (cxt, &a);
     dec_swap_if (cxt, arthip_decimate (&a, d_input, numInputFrames, d_output, cxt->hip->stream));
+    DEC_LEAVE (cxt->hip);
 }
 
 long decimateHipClipped (Decimate *cxt)
 {
     unsigned long long total = 0;
+    if (cxt->hip->nshards) {
+        long sum = 0;
+        arthip_sync (cxt->hip->stream);
+        for (int k = 0; k < cxt->hip->nshards; ++k) sum += decimateHipClipped (cxt->hip->shards [k]);
+        return sum;
+    }
+    DEC_ENTER (cxt->hip);
     arthip_d2h (&total, cxt->hip->d_clipped, sizeof (total), cxt->hip->stream);
     arthip_sync (cxt->hip->stream);
+    DEC_LEAVE (cxt->hip);
     return (long) total;
 }
 
@@ -564,38 +804,87 @@ static int dec_finish (Decimate *cxt, unsigned char *output, size_t out_bytes)
     return delta;
 }
 
+/* a sharded context after a host-pointer call: every shard's state block comes back on the shard's own stream; clip counts add
+ * up, the host mirrors are assembled channel slice by channel slice */
+static int dec_finish_shards (Decimate *cxt)
+{
+    struct artamd_decimator *hip = cxt->hip;
+    const int prev = arthip_current_device ();
+    int clipped = 0;
+    for (int k = 0; k < hip->nshards; ++k) {
+        struct artamd_decimator *sp = hip->shards [k]->hip;
+        arthip_set_device (sp->device);
+        arthip_d2h (sp->h_state, sp->d_state, sp->state_bytes, sp->stream);
+    }
+    for (int k = 0; k < hip->nshards; ++k) {
+        Decimate *leaf = hip->shards [k];
+        struct artamd_decimator *sp = leaf->hip;
+        const int first = hip->shard_first [k], width = hip->shard_first [k + 1] - first;
+        arthip_set_device (sp->device);
+        if (arthip_sync (sp->stream)) { fprintf (stderr, "artamd: sharded decimator: %s\n", arthip_last_error ()); continue; }
+        const unsigned char *m = sp->h_state;
+        const unsigned long long total = *(const unsigned long long *) m;
+        memcpy (cxt->feedback + first, m + ((unsigned char *) sp->d_feedback - sp->d_state), sizeof (art_s) * width);
+        if (cxt->tpdf_generators) memcpy (cxt->tpdf_generators + first, m + ((unsigned char *) sp->d_gens - sp->d_state), sizeof (uint32_t) * width);
+        if (cxt->noise_shapers) memcpy (cxt->noise_shapers + first, m + ((unsigned char *) sp->d_shapers - sp->d_state), sizeof (Biquad) * width);
+        clipped += (int)(total - sp->clipped_seen);
+        sp->clipped_seen = total;
+    }
+    if (prev >= 0) arthip_set_device (prev);
+    return clipped;
+}
+
 int decimateProcessInterleavedLE (Decimate *cxt, const artsample_t *input, int numInputFrames, unsigned char *output)
 {
     struct artamd_decimator *hip = cxt->hip;
     if (numInputFrames <= 0) return 0;
     const size_t samples = (size_t) numInputFrames * cxt->numChannels, in_bytes = samples * sizeof (art_s);
     ArtDecArgs a;
+    DEC_ENTER (hip);
 
     if (dec_reserve (cxt, in_bytes, samples * cxt->outputBytes)) {
         fprintf (stderr, "artamd: decimator device allocation failed: %s\n", arthip_last_error ());
+        DEC_LEAVE (hip);
         return 0;
     }
-    dec_args (cxt, &a);
     if (in_bytes + 16 <= DEC_KERNEL_COPY_LIMIT) {
         memcpy (hip->h_in, input, in_bytes);
         arthip_copy_by_kernel (hip->d_in, hip->h_in, in_bytes, hip->stream);
     }
     else arthip_h2d (hip->d_in, input, in_bytes, hip->stream);
-    dec_swap_if (cxt, arthip_decimate (&a, hip->d_in, numInputFrames, hip->d_out, hip->stream));
-    return dec_finish (cxt, output, samples * cxt->outputBytes);
+    int clipped;
+    if (hip->nshards) {
+        /* the whole interleaved buffer is staged on this context's device (one dense transfer each way), the shards work on it */
+        const size_t out_bytes = samples * cxt->outputBytes;
+        dec_sharded_device_call (cxt, hip->d_in, numInputFrames, hip->d_out);
+        if (out_bytes + 16 <= DEC_KERNEL_COPY_LIMIT) {
+            arthip_copy_by_kernel (hip->h_out, hip->d_out, (out_bytes + 3) & ~(size_t) 3, hip->stream);
+            arthip_sync (hip->stream);
+            memcpy (output, hip->h_out, out_bytes);
+        }
+        else { arthip_d2h (output, hip->d_out, out_bytes, hip->stream); arthip_sync (hip->stream); }
+        clipped = dec_finish_shards (cxt);
+    }
+    else {
+        dec_args (cxt, &a);
+        dec_swap_if (cxt, arthip_decimate (&a, hip->d_in, numInputFrames, hip->d_out, hip->stream));
+        clipped = dec_finish (cxt, output, samples * cxt->outputBytes);
+    }
+    DEC_LEAVE (hip);
+    return clipped;
 }
 
-int decimateProcessLE (Decimate *cxt, const artsample_t *const *input, int numInputFrames, unsigned char *const *output)
+/* planar call of an ordinary context, enqueued only (dec_finish / dec_finish_shards waits) */
+static int dec_planar_begin (Decimate *cxt, const artsample_t *const *input, int numInputFrames, unsigned char *const *output)
 {
     struct artamd_decimator *hip = cxt->hip;
-    if (numInputFrames <= 0) return 0;
     const int C = cxt->numChannels;
     const size_t n = (size_t) numInputFrames, plane_bytes = n * cxt->outputBytes;
     ArtDecArgs a;
 
     if (dec_reserve (cxt, n * C * sizeof (art_s), plane_bytes * C)) {
         fprintf (stderr, "artamd: decimator device allocation failed: %s\n", arthip_last_error ());
-        return 0;
+        return -1;
     }
     dec_args (cxt, &a);
     for (int c = 0; c < C; ++c)
@@ -603,7 +892,28 @@ int decimateProcessLE (Decimate *cxt, const artsample_t *const *input, int numIn
     arthip_decimate_planar (&a, hip->d_in, (long) n, numInputFrames, hip->d_out, (long) plane_bytes, hip->stream);
     for (int c = 0; c < C; ++c)
         arthip_d2h (output [c], hip->d_out + plane_bytes * c, plane_bytes, hip->stream);
-    return dec_finish (cxt, NULL, 0);
+    return 0;
+}
+
+int decimateProcessLE (Decimate *cxt, const artsample_t *const *input, int numInputFrames, unsigned char *const *output)
+{
+    struct artamd_decimator *hip = cxt->hip;
+    if (numInputFrames <= 0) return 0;
+    if (hip->nshards) {
+        /* planes need no slicing: a shard's channels are a run of the caller's planes; all shards are enqueued before any is waited for */
+        const int prev = arthip_current_device ();
+        arthip_sync (hip->stream);
+        for (int k = 0; k < hip->nshards; ++k) {
+            arthip_set_device (hip->shards [k]->hip->device);
+            dec_planar_begin (hip->shards [k], input + hip->shard_first [k], numInputFrames, output + hip->shard_first [k]);
+        }
+        if (prev >= 0) arthip_set_device (prev);
+        return dec_finish_shards (cxt);
+    }
+    DEC_ENTER (hip);
+    const int clipped = dec_planar_begin (cxt, input, numInputFrames, output) ? 0 : dec_finish (cxt, NULL, 0);
+    DEC_LEAVE (hip);
+    return clipped;
 }
 
 /* ------------------------------------------------------------------------------------------

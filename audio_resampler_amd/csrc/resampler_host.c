@@ -288,7 +288,7 @@ static void *grow_pinned (void *host, size_t *cap, size_t need)
  * threads.  ARTAMD_SHARDS=n forces the number of shards (several shards per device, or sharding on a single device: the
  * way the path is tested on a one-GPU box).
  * ---------------------------------------------------------------------------------------- */
-#define MAX_DEVICES 64
+#define MAX_DEVICES ART_MAX_DEVICES
 static int dev_list [MAX_DEVICES], dev_count = -1;        /* -1: not resolved yet */
 static pthread_mutex_t dev_lock = PTHREAD_MUTEX_INITIALIZER;
 
@@ -331,19 +331,33 @@ int artamdSetDevices (const int *devices, int count)
     return rc;
 }
 
-/* how many shards a RESAMPLE_MULTITHREADED context of `channels` channels gets (0 or 1: an ordinary context) and on which
- * device shard s lives */
-static int shard_plan (int channels, int *devices_out)
+/* how many shards a MULTITHREADED context of `channels` channels gets (0 or 1: an ordinary context) and on which device
+ * shard s lives.  Left to itself a context spreads over the listed devices with at least two channels per shard (a stereo
+ * stream is not worth two devices' launches: ARTAMD_MIN_SHARD_CHANNELS); ARTAMD_SHARDS forces the count.  The slice kernels
+ * of a shard read and write the caller's buffers on `home` in place: a device with no peer route to `home` (IOMMU,
+ * containers, mixed topology — a page fault, not an error code, if it were used) is replaced by `home` itself. */
+int artamd_shard_plan (int channels, int home, int *devices_out)
 {
     pthread_mutex_lock (&dev_lock);
     if (dev_count < 0) resolve_devices ();
     int n = dev_count > 1 ? dev_count : 0;
-    const char *env = getenv ("ARTAMD_SHARDS");
+    const char *env = getenv ("ARTAMD_SHARDS"), *min_env = getenv ("ARTAMD_MIN_SHARD_CHANNELS");
     if (env && *env) n = atoi (env);
+    else {
+        const int per = min_env && *min_env && atoi (min_env) > 0 ? atoi (min_env) : 2;
+        if (n > channels / per) n = channels / per;
+    }
     if (n > channels) n = channels;
     if (n > MAX_DEVICES) n = MAX_DEVICES;
     for (int s = 0; s < n; ++s) devices_out [s] = dev_count ? dev_list [s % dev_count] : 0;
     pthread_mutex_unlock (&dev_lock);
+    if (home >= 0)
+        for (int s = 0; s < n; ++s)
+            if (devices_out [s] != home && !arthip_enable_peer (devices_out [s], home)) {
+                static int warned;
+                if (!warned++) fprintf (stderr, "artamd: device %d cannot address device %d's memory (no peer access): its shards stay on device %d\n", devices_out [s], home, home);
+                devices_out [s] = home;
+            }
     return n;
 }
 
@@ -492,8 +506,7 @@ static Resample *init_sharded (int numChannels, int numTaps, int numFilters, dou
     for (int s = 0; ok && s < count; ++s) {
         const int width = base + (s < extra ? 1 : 0);
         hip->shard_first [s + 1] = hip->shard_first [s] + width;
-        arthip_set_device (devices [s]);
-        arthip_enable_peer (devices [s], prev);          /* planar device-pointer calls read the caller's buffers in place */
+        arthip_set_device (devices [s]);                  /* (artamd_shard_plan has made sure it can address `prev`'s memory) */
         hip->shards [s] = init_leaf (width, numTaps, numFilters, lowpassRatio, flags & ~RESAMPLE_MULTITHREADED, 1);
         hip->ev_shard [s] = arthip_order_event_create ();
         hip->nshards = s + 1;
@@ -553,7 +566,7 @@ Resample *resampleInit (int numChannels, int numTaps, int numFilters, double low
 
     if ((flags & RESAMPLE_MULTITHREADED) && numChannels > 1) {
         int devices [MAX_DEVICES];
-        const int count = shard_plan (numChannels, devices);
+        const int count = artamd_shard_plan (numChannels, arthip_current_device (), devices);
         if (count > 1)
             return init_sharded (numChannels, numTaps, numFilters, lowpassRatio, flags, count, devices);
     }

@@ -110,6 +110,11 @@ int artamdPlanCall (ArtamdPosition *pos, int numInputFrames, int numOutputFrames
 typedef struct artamd_biquad_bank BiquadBank;
 /* sections[c*numSections + s] is section s of channel c (state and coefficients are copied) */
 BiquadBank *biquadBankCreate (const Biquad *sections, int numChannels, int numSections);
+/* the same bank spread over the devices of artamdSetDevices () / ARTAMD_DEVICES (ARTAMD_SHARDS forces the count; at least two
+ * channels per device otherwise), contiguous channel slices, one stream per device, the way a RESAMPLE_MULTITHREADED resampler
+ * and a DECIMATE_MULTITHREADED decimator spread: same entry points, same bits; an ordinary bank when there is one device */
+BiquadBank *biquadBankCreateMulti (const Biquad *sections, int numChannels, int numSections);
+int biquadBankShardCount (BiquadBank *bank);         /* 0: an ordinary bank */
 void biquadBankSetStream (BiquadBank *bank, void *hipStream);
 /* in-place over interleaved device frames [numFrames][numChannels]; asynchronous */
 void biquadBankApplyInterleavedDevice (BiquadBank *bank, artsample_t *d_buffer, int numFrames);
@@ -126,6 +131,10 @@ void decimateHipSetStream (Decimate *cxt, void *hipStream);
 /* asynchronous; clipped-sample count accumulates on the device, read with decimateHipClipped() */
 void decimateProcessInterleavedLEDevice (Decimate *cxt, const artsample_t *d_input, int numInputFrames, unsigned char *d_output);
 long decimateHipClipped (Decimate *cxt);             /* synchronises; total clipped since init */
+/* shards of a DECIMATE_MULTITHREADED context (decimator.h: the reference's one-worker-per-channel fan-out, decimator.c:92-93,
+ * 119-136, with devices for threads — ordinary contexts with contiguous channel slices on the devices of artamdSetDevices ());
+ * 0: an ordinary context */
+int decimateHipShardCount (Decimate *cxt);
 void floatIntegersLEDevice (const unsigned char *d_input, double inputGain, int inputBits, int inputBytes, int inputStride,
                             artsample_t *d_output, int numSamples, void *hipStream);
 

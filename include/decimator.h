@@ -23,7 +23,9 @@ enum {
     SHAPING_2ND_ORDER      = 0x0200,
     SHAPING_3RD_ORDER      = 0x0400,
     SHAPING_ATH_CURVE      = 0x0800,     /* threshold-of-hearing curves for 32/44.1/48/88.2/96 kHz, else 1st order */
-    DECIMATE_MULTITHREADED = 0x1000      /* accepted, no effect */
+    DECIMATE_MULTITHREADED = 0x1000      /* the reference: one worker thread per channel (decimator.c:92-93, 119-136); here: the
+                                          * channels spread over the devices of artamdSetDevices () / ARTAMD_DEVICES (art_hip.h),
+                                          * one ordinary context per contiguous channel slice — same bytes, clip counts and state */
 };
 #define DITHER_ENABLED   (DITHER_HIGHPASS | DITHER_FLAT | DITHER_LOWPASS)
 #define SHAPING_ENABLED  (SHAPING_1ST_ORDER | SHAPING_2ND_ORDER | SHAPING_3RD_ORDER | SHAPING_ATH_CURVE)

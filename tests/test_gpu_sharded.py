@@ -254,3 +254,71 @@ def test_sharded_context_runs_its_shards_in_fixed_point_with_the_same_bits(eight
     assert outs [0] [0] == outs [1] [0] and outs [0] [2] == outs [1] [2]
     assert np.array_equal(outs [0] [1].view(np.uint32), outs [1] [1].view(np.uint32))
     assert np.array_equal(outs [0] [3].view(np.uint32), outs [1] [3].view(np.uint32))
+
+
+# ---- the other two stages spread the same way: DECIMATE_MULTITHREADED (reference decimator.c:92-93, 119-136) and a multi-device biquad bank ----
+
+DEC_FLAGS = [A.DITHER_HIGHPASS | A.SHAPING_ATH_CURVE, A.DITHER_FLAT, A.SHAPING_3RD_ORDER, 0]
+
+
+@pytest.mark.parametrize("flags", DEC_FLAGS, ids=["hp_dither_ath", "flat_dither", "shaping3", "plain"])
+@pytest.mark.parametrize("ch,bits,nbytes", [(32, 16, 2), (8, 24, 3), (5, 8, 1), (9, 20, 4)], ids=["32ch_16bit", "8ch_24bit_3B", "5ch_8bit", "9ch_20bit_4B"])
+def test_sharded_decimator_equals_ordinary_decimator(eight_shards, flags, ch, bits, nbytes):
+    """DECIMATE_MULTITHREADED on 8 shards (uneven slices where the channels do not divide; packed bytes of a slice that are not
+    whole words) against an ordinary context: the same bytes, clip counts and host-visible state (feedback, dither generators
+    — seeded channel after channel from one byte stream — noise shapers) through the interleaved, the planar and the
+    device-pointer entry points, state carried across calls"""
+    frames = 20000
+    x = (_stream(ch, 3 * frames) * 2.3).astype(np.float32)          # (loud enough to clip now and then)
+    plain = A.Decimator(ch, bits, nbytes, 1.0, 48000, flags)
+    multi = A.Decimator(ch, bits, nbytes, 1.0, 48000, flags | A.DECIMATE_MULTITHREADED)
+    assert plain.shards() == 0 and multi.shards() == min(8, ch)
+    # interleaved host call
+    a, ca = plain.process(x [:frames]); b, cb = multi.process(x [:frames])
+    assert ca == cb and np.array_equal(a, b)
+    # planar host call
+    planes = [np.ascontiguousarray(x [frames:2 * frames, c]) for c in range(ch)]
+    pa, ca = plain.process_planar(planes); pb, cb = multi.process_planar(planes)
+    assert ca == cb and all(np.array_equal(u, v) for u, v in zip(pa, pb))
+    # device-pointer call
+    d_in = torch.from_numpy(x [2 * frames:]).cuda()
+    oa = torch.zeros(frames * ch * nbytes, dtype=torch.uint8, device="cuda"); ob = torch.zeros_like(oa)
+    plain.process_device(d_in, frames, oa); multi.process_device(d_in, frames, ob)
+    assert plain.clipped() == multi.clipped()
+    assert torch.equal(oa, ob)
+    # host-visible state after one more host call (the mirrors are refreshed by host-pointer calls)
+    a, ca = plain.process(x [:777]); b, cb = multi.process(x [:777])
+    assert ca == cb and np.array_equal(a, b)
+    pc, mc = plain.p.contents, multi.p.contents
+    assert np.array_equal(np.ctypeslib.as_array(pc.feedback, (ch,)), np.ctypeslib.as_array(mc.feedback, (ch,)))
+    if flags & (A.DITHER_HIGHPASS | A.DITHER_FLAT | A.DITHER_LOWPASS):
+        assert np.array_equal(np.ctypeslib.as_array(pc.tpdf_generators, (ch,)), np.ctypeslib.as_array(mc.tpdf_generators, (ch,)))
+
+
+def test_decimate_multithreaded_alone_changes_nothing_on_one_device(monkeypatch):
+    monkeypatch.delenv("ARTAMD_SHARDS", raising=False)
+    d = A.Decimator(8, 16, 2, 1.0, 48000, A.DITHER_HIGHPASS | A.DECIMATE_MULTITHREADED)
+    assert d.shards() == 0
+
+
+@pytest.mark.parametrize("ch,nsec,cutoff", [(32, 2, 44100 * 0.45 / 96000), (7, 1, 0.01), (8, 4, 0.2)], ids=["32ch_2sec_config_c", "7ch_1sec_slow", "8ch_4sec"])
+def test_multi_device_biquad_bank_equals_ordinary_bank(eight_shards, ch, nsec, cutoff):
+    """biquadBankCreateMulti on 8 shards against an ordinary bank: the same samples bit for bit (long runs: the time-parallel form
+    inside every shard; short runs: the serial kernels), and the same filter state read back, across calls"""
+    import ctypes as C
+    L = A.lib()
+    co = A.BiquadCoefficients(); L.biquad_lowpass(C.byref(co), cutoff)
+    secs = (A.Biquad * (ch * nsec))()
+    for i in range(ch * nsec):
+        L.biquad_init(C.byref(secs [i]), C.byref(co), 1.0 + 0.01 * (i % 3))
+    plain, multi = A.BiquadBank(secs, ch, nsec), A.BiquadBank(secs, ch, nsec, multi=True)
+    assert plain.shards() == 0 and multi.shards() == min(8, ch)
+    for frames in (150000, 500, 70000):
+        x = torch.from_numpy(_stream(ch, frames, seed_skip=frames % 97)).cuda()
+        a, b = x.clone(), x.clone()
+        plain.apply_device(a, frames); multi.apply_device(b, frames)
+        torch.cuda.synchronize()
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), frames
+    sa, sb = plain.read(), multi.read()
+    assert bytes(sa) == bytes(sb)
+    multi.repairs(); plain.repairs()                          # (how many chunks needed a repair depends on the chunking: diagnostics only)

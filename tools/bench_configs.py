@@ -1,5 +1,9 @@
-"""Device-resident throughput of the BASELINE.json configs other than the headline (which bench.py covers).
-Prints one JSON line per config.  Usage: python tools/bench_configs.py [--steps N]"""
+"""Device-resident throughput of the BASELINE.json configs other than the headline (which bench.py covers), every stage with the
+reference's own CPU path timed beside it in the same run (tools/cpu_ref.py: the real reference from oracle/_ref, its own
+threading — workers.c:249-371 through RESAMPLE_MULTITHREADED / DECIMATE_MULTITHREADED, decimator.c:119-136 — threads and host
+cores stated) and the roofline fraction of the stage's dominant kernel (HIP events around the FIR launches; executed matrix
+operations over that instruction's dense peak, or algorithmic bytes over the HBM peak for the streaming stages).
+Prints one JSON line per config.  Usage: python tools/bench_configs.py [--steps N] [--no-cpu]"""
 import argparse, ctypes as C, json, math, os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
@@ -9,7 +13,39 @@ import audio_resampler_amd as A
 from audio_resampler_amd.synth import noise
 
 ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=10); ap.add_argument("--block", type=int, default=1 << 20)
+ap.add_argument("--no-cpu", action="store_true"); ap.add_argument("--cpu-budget", type=float, default=3.0)
 args = ap.parse_args()
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import cpu_ref
+PEAK_F32, PEAK_I8, PEAK_HBM = 157.3, 5033.0, 8000.0
+
+
+def fir_roofline(rs, out_samples, taps, src, dst, interp_used):
+    """executed operations of the FIR kernel that ran (HIP events around its launches) over the peak that bounds it"""
+    ms, launches = rs.read_timing()
+    if not launches or ms <= 0:
+        return None
+    rate = out_samples / (ms * 1e-3)
+    kernel = rs.last_kernel()
+    fixed_state, pairs = rs.fixed_point()
+    g = math.gcd(src, dst); P, Q = dst // g, src // g
+    kpad = ((taps + int(31.0 * Q / P) + 2 + 3 + 31) // 32) * 32
+    if kernel == 2 and fixed_state == 1:
+        ops, peak, name, unit = 2 * kpad * pairs, PEAK_I8, "fir_i8 (fixed point, int8 matrix cores)", "TOP/s"
+    elif kernel == 2:
+        ops, peak, name, unit = 2 * kpad, PEAK_F32, "fir_mfma (f32 matrix cores)", "TFLOP/s"
+    else:
+        ops, peak, name, unit = (4 * taps + 3) if interp_used else 2 * taps, PEAK_F32, "fir_general (vector, algorithmic flop)", "TFLOP/s"
+    ach = rate * ops / 1e12
+    bytes_per = 4.0 * src / dst + 4.0
+    return {"kernel": name, "bound": "mfma" if kernel == 2 else "valu", "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
+            "avg_kernel_ms": round(ms / launches, 4), "hbm_frac_algorithmic": round(rate * bytes_per / 1e9 / PEAK_HBM, 4)}
+
+
+def hbm_roofline(samples_per_s, bytes_per_sample, kernel):
+    gbs = samples_per_s * bytes_per_sample / 1e9
+    return {"kernel": kernel, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM, "unit": "GB/s", "frac": round(gbs / PEAK_HBM, 5),
+            "note": "algorithmic bytes / wall time of the whole stage (all its launches)"}
 stream = torch.cuda.current_stream().cuda_stream
 
 
@@ -41,9 +77,15 @@ def resample_only(name, ch, taps, filters, src, dst, flags, fixed, block, ratio_
         assert u == block
         return g * ch
     n, dt = timed(step, args.steps)
+    rs.set_timing(True); m = 0
+    for _ in range(max(3, args.steps // 2)): m += step()
+    roof = fir_roofline(rs, m, taps, src, dst, bool(rs.L.resampleInterpolationUsed(rs.p)))
+    rs.set_timing(False)
+    cpu = None if args.no_cpu else cpu_ref.resample(ch, taps, filters, src, dst, flags, fixed=fixed, budget=args.cpu_budget, ratio_fn=ratio_fn)
     print(json.dumps({"config": name, "Msamples_per_s": round(n / dt / 1e6, 1), "ms_per_step": round(dt / args.steps * 1e3, 3),
                       "kernel": rs.last_kernel(), "block_frames": block, "channels": ch, "filters": rs.L.resampleGetNumFilters(rs.p),
-                      "interp": bool(rs.L.resampleInterpolationUsed(rs.p))}), flush=True)
+                      "interp": bool(rs.L.resampleInterpolationUsed(rs.p)), "roofline": roof, "cpu_reference": cpu,
+                      "gpu_over_cpu": round(n / dt / 1e6 / cpu["Msamples_per_s"], 1) if cpu else None}), flush=True)
 
 
 BH, IN, LP = A.BLACKMAN_HARRIS, A.SUBSAMPLE_INTERPOLATE, A.INCLUDE_LOWPASS
@@ -87,12 +129,32 @@ def dither_only():
     dec0.process_device(d_out, cap - 16, d_pcm)
     return (cap - 16) * ch
 n, dt = timed(dither_only, args.steps)
+cpu = None if args.no_cpu else cpu_ref.decimate(ch, 16, 2, dst, A.DITHER_HIGHPASS, block=65536, budget=args.cpu_budget, threaded=True)
 print(json.dumps({"config": "C' 16-bit decimation, HP-TPDF dither, no noise shaping (no recurrence => fully parallel)", "Msamples_per_s": round(n / dt / 1e6, 1),
-                  "ms_per_step": round(dt / args.steps * 1e3, 3)}), flush=True)
+                  "ms_per_step": round(dt / args.steps * 1e3, 3), "roofline": hbm_roofline(n / dt, 6.0, "decimate_parallel_kernel"),
+                  "cpu_reference": cpu, "gpu_over_cpu": round(n / dt / 1e6 / cpu["Msamples_per_s"], 1) if cpu else None}), flush=True)
 for which in ("resample", "biquad", "decimate", "all"):
     n, dt = timed(stage(which), max(2, args.steps // 3))
-    print(json.dumps({"config": f"C  8ch 96k->44.1k -4 fixed (147x988 no-lerp, LP) + 2x biquad + 16-bit ATH decimate: stage={which}",
-                      "Msamples_per_s": round(n / dt / 1e6, 1), "ms_per_step": round(dt / max(2, args.steps // 3) * 1e3, 3), "block_frames": block}), flush=True)
+    roof = cpu = cpu2 = None
+    if which == "resample":
+        rs.set_timing(True); m = 0
+        for _ in range(3): m += stage(which)()
+        roof = fir_roofline(rs, m, taps, src, dst, False); rs.set_timing(False)
+        cpu = None if args.no_cpu else cpu_ref.resample(ch, taps, taps, src, dst, BH | IN | LP, fixed=True, budget=args.cpu_budget)
+    elif which == "biquad":
+        roof = hbm_roofline(n / dt, 8.0, "biquad_spec_kernel (+ check, commit, copy aside)")
+        cpu = None if args.no_cpu else cpu_ref.biquad_cascade(ch, 2, dst * 0.45 / src, budget=args.cpu_budget)
+    elif which == "decimate":
+        roof = hbm_roofline(n / dt, 6.0, "decimate_pipe_kernel (serial error feedback per channel)")
+        cpu = None if args.no_cpu else cpu_ref.decimate(ch, 16, 2, dst, A.DITHER_HIGHPASS | A.SHAPING_ATH_CURVE, budget=args.cpu_budget)
+        cpu2 = None if args.no_cpu else cpu_ref.decimate(ch, 16, 2, dst, A.DITHER_HIGHPASS | A.SHAPING_ATH_CURVE, block=65536, budget=args.cpu_budget, threaded=True)
+    else:
+        cpu = None if args.no_cpu else cpu_ref.config_c_pipeline(ch, taps, src, dst, budget=args.cpu_budget)
+    line = {"config": f"C  8ch 96k->44.1k -4 fixed (147x988 no-lerp, LP) + 2x biquad + 16-bit ATH decimate: stage={which}",
+            "Msamples_per_s": round(n / dt / 1e6, 1), "ms_per_step": round(dt / max(2, args.steps // 3) * 1e3, 3), "block_frames": block,
+            "roofline": roof, "cpu_reference": cpu, "gpu_over_cpu": round(n / dt / 1e6 / cpu["Msamples_per_s"], 1) if cpu else None}
+    if cpu2: line["cpu_reference_threaded"] = cpu2
+    print(json.dumps(line), flush=True)
 
 
 # ---- C pipelined: the three stages of successive blocks overlap on three HIP streams (block k+1 in the biquads
