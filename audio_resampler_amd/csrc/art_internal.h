@@ -51,6 +51,9 @@ typedef struct {
     int roll_appended;                   /*   (frames appended by this call) into roll_dst; arthip_fir then returns k | ART_FIR_ROLLED */                      /* 0: interleaved; else planar */
     int in_frames;                       /* frames valid at `in` (reads beyond return 0) */
     int C, T, F, H;
+    int stream_C;                        /* channels of the whole stream when this context is a shard of a multi-device context (0: = C): the
+                                          * kernel choice is made for the stream, so that a shard and an ordinary context of the same stream
+                                          * run the same kernels and produce the same bits */
     int interpolate, lowpass;            /* SUBSAMPLE_INTERPOLATE / INCLUDE_LOWPASS in effect */
     int mode;                            /* ART_MODE_* */
     double ratio;

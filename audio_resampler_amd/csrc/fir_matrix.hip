@@ -562,18 +562,20 @@ bool artfir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int
 {
     if (a->n_end <= a->n_begin || (a->mode & 3) == ART_MODE_STRICT) return false;
     const unsigned int total = a->n_end - a->n_begin;
+    // (a shard of a multi-device context decides as its whole stream would on one device: same kernels, same bits either way)
+    const int C = a->stream_C > a->C ? a->stream_C : a->C;
     bool enough;
-    if (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32) {
+    if (C == 1 || C == 2 || C == 4 || C == 8 || C == 16 || C == 32) {
         // (up to 256 taps the general kernel works four frames per wave: its per-frame cost roughly halves; with long filters
         // a mid-sized call is cut into 16-frame tiles that each stage ~T frames: 1.5x per frame below ~40k outputs — measured)
-        const double k_ns = ((0.2 + 0.04 * a->C) + 0.00007 * a->C * a->T) * (general_group (a->T) == 16 ? 0.47 : 0.85) *
+        const double k_ns = ((0.2 + 0.04 * C) + 0.00007 * C * a->T) * (general_group (a->T) == 16 ? 0.47 : 0.85) *
                             ((a->T >= 512 && total < 40000u) ? 1.5 : 1.0);
         const double chunks = (a->T + 63) / 32;
-        const double floor_ns = 13500.0 + 550.0 * chunks + (a->C <= 2 ? 2000.0 : 0.0);
+        const double floor_ns = 13500.0 + 550.0 * chunks + (C <= 2 ? 2000.0 : 0.0);
         enough = total * k_ns >= floor_ns - 5000.0;
     }
     else
-        enough = (double) total * a->C * a->T >= 1.2e8;
+        enough = (double) total * C * a->T >= 1.2e8;
     return a->mode == ART_MODE_FAST && a->period_out > 0 && a->fix_list && a->scratch && a->in_pitch == 0 && a->out_pitch == 0 &&
                          segs->lin_floor == INT_MIN && kernel_pref != ART_KERNEL_GENERAL &&
                          (enough || kernel_pref >= ART_KERNEL_MFMA) && total >= (unsigned int) a->period_out;
@@ -614,7 +616,7 @@ size_t artfir_planes_bytes (const ArtFirArgs *a, unsigned int outputs, int kerne
     // and its extra launch ~4 us: long filters and big calls win (8 ch x 988 taps: from ~90k frames per call, +27 % at 1M;
     // 4 and 32 channels alike), 380-tap and shorter filters lose at every size (13 chunks per tile: the f32 kernel is not
     // matrix-bound there).  kernel_pref 7 takes the fixed-point kernel wherever it can run.
-    if (kernel_pref != 7 && (a->T < 512 || (double) outputs * a->C * a->T < 8.5e8)) return 0;
+    if (kernel_pref != 7 && (a->T < 512 || (double) outputs * (a->stream_C > a->C ? a->stream_C : a->C) * a->T < 8.5e8)) return 0;
     static const bool off = [] { const char *e = getenv ("ARTAMD_NO_FIXED"); return e && *e && *e != '0'; } ();
     if (off) return 0;
     MfmaGeom g;

@@ -57,6 +57,7 @@ struct artamd_resampler {
     ArtamdSegment *segs; int seg_cap;
     int floor_active;                       /* ring index 0 is a hard history floor (after a flush-time rewind) */
     int kernel_pref, last_kernel;
+    int stream_channels;                     /* a shard: channels of the whole stream (kernel choice); 0 otherwise */
     /* cached rational structure of the current ratio */
     double period_ratio; int period_out, period_in;
     /* optional HIP-event timing of FIR launches */
@@ -511,6 +512,7 @@ static Resample *init_sharded (int numChannels, int numTaps, int numFilters, dou
         hip->ev_shard [s] = arthip_order_event_create ();
         hip->nshards = s + 1;
         ok = hip->shards [s] && hip->ev_shard [s];
+        if (ok) hip->shards [s]->hip->stream_channels = numChannels;
     }
     if (prev >= 0) arthip_set_device (prev);
 
@@ -1145,6 +1147,7 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
         a.in_frames = is_flush ? (flush_in ? T / 2 : 0) : (int) res.input_used;
         a.out = d_out; a.out_pitch = out_pitch;
         a.C = C; a.T = T; a.F = cxt->numFilters; a.H = H;
+        a.stream_C = hip->stream_channels;
         a.interpolate = (cxt->flags & SUBSAMPLE_INTERPOLATE) != 0;
         a.lowpass = (cxt->flags & INCLUDE_LOWPASS) != 0;
         /* the double-precision build has one arithmetic: EXTEND_CONVOLUTION_MATH only matters for 4-byte samples
@@ -1270,6 +1273,7 @@ static int batch_plan (Resample *cxt, const art_s *d_in, int nIn, art_s *d_out, 
     a->in = d_in; a->in_pitch = 0; a->in_frames = (int) res->input_used;
     a->out = d_out; a->out_pitch = 0;
     a->C = C; a->T = T; a->F = cxt->numFilters; a->H = H;
+    a->stream_C = hip->stream_channels;
     a->interpolate = (cxt->flags & SUBSAMPLE_INTERPOLATE) != 0;
     a->lowpass = (cxt->flags & INCLUDE_LOWPASS) != 0;
     a->mode = (!ART_WIDE && (cxt->flags & EXTEND_CONVOLUTION_MATH)) ? ART_MODE_PRECISE : ART_MODE_FAST;

@@ -180,8 +180,7 @@ def test_sharded_context_device_pointer_calls(eight_shards):
     x = _stream(ch, frames)
     plain, sharded = _pair(ch, BH | INTERP)
     for r in (plain, sharded):
-        r.advance(T / 2)
-        r.set_kernel(6)       # (the f32 matrix kernels: left to itself the 32-channel call is big enough for the fixed-point kernel, its 4-channel shards are not)
+        r.advance(T / 2)      # (kernel choice left to the library: a shard decides as its whole stream would — here the fixed-point kernel on both sides)
     cap = int(frames * R) + 2000
     d_in = torch.from_numpy(x).cuda()
     outs = []
@@ -254,6 +253,29 @@ def test_sharded_context_runs_its_shards_in_fixed_point_with_the_same_bits(eight
     assert outs [0] [0] == outs [1] [0] and outs [0] [2] == outs [1] [2]
     assert np.array_equal(outs [0] [1].view(np.uint32), outs [1] [1].view(np.uint32))
     assert np.array_equal(outs [0] [3].view(np.uint32), outs [1] [3].view(np.uint32))
+
+
+def test_sharded_and_ordinary_context_choose_the_same_kernel_at_every_call_size(eight_shards):
+    """kernel choice left to the library: a 4-channel shard decides as its 32-channel stream would on one device (general kernel
+    for small calls, f32 matrix kernel for middling ones, fixed point for big ones), so the two contexts agree bit for bit at
+    every size — the default mode, no kernel pinned"""
+    ch = 32
+    sizes = [300, 2500, 9000, 30000, 61000]
+    x = _stream(ch, sum(sizes))
+    plain, sharded = _pair(ch, BH | INTERP)
+    kinds = []
+    pos = 0
+    for r in (plain, sharded):
+        r.advance(T / 2)
+    for n in sizes:
+        cap = int(n * R) + 2000
+        a = plain.process(x [pos:pos + n], cap, R); ka = (plain.last_kernel(), plain.fixed_point() [0])
+        b = sharded.process(x [pos:pos + n], cap, R); kb = (sharded.last_kernel(), sharded.fixed_point() [0])
+        pos += n
+        assert a [:2] == b [:2] and ka == kb, (n, ka, kb)
+        assert np.array_equal(np.array(a [2]).view(np.uint32), np.array(b [2]).view(np.uint32)), (n, ka)
+        kinds.append(ka)
+    assert (1, 0) in kinds and (2, 0) in kinds and (2, 1) in kinds, kinds      # every kind of kernel was exercised
 
 
 # ---- the other two stages spread the same way: DECIMATE_MULTITHREADED (reference decimator.c:92-93, 119-136) and a multi-device biquad bank ----
