@@ -104,6 +104,12 @@ def _bind(width):
         "decimateFree": (None, [DP]),
         # art_hip.h
         "artamdDeviceCount": (C.c_int, []),
+        "artamdDeviceAlloc": (ptr, [C.c_size_t]),
+        "artamdDeviceFree": (None, [ptr]),
+        "artamdUpload": (C.c_int, [ptr, ptr, C.c_size_t, ptr]),
+        "artamdDownload": (C.c_int, [ptr, ptr, C.c_size_t, ptr]),
+        "artamdDeviceZero": (C.c_int, [ptr, C.c_size_t, ptr]),
+        "artamdStreamSynchronize": (C.c_int, [ptr]),
         "artamdVersion": (C.c_char_p, []),
         "artamdSetDevices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
         "resampleHipGetDevice": (C.c_int, [RP]),
@@ -137,6 +143,8 @@ def _bind(width):
         "decimateProcessInterleavedLEDevice": (None, [DP, ptr, C.c_int, ptr]),
         "decimateHipClipped": (C.c_long, [DP]),
         "decimateHipShardCount": (C.c_int, [DP]),
+        "artamdErrorCount": (C.c_int, []),
+        "artamdLastError": (C.c_char_p, []),
         "floatIntegersLEDevice": (None, [ptr, C.c_double, C.c_int, C.c_int, C.c_int, ptr, C.c_int, ptr]),
         # stretch.h
         "stretchInit": (ptr, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -41,6 +41,14 @@ int arthip_device_count (void)
 }
 
 int artamdDeviceCount (void) { return arthip_device_count (); }
+// device memory for callers of the device-pointer entry points that bring no runtime of their own (tools/art_gpu.py: no
+// torch import, a fraction of a second less start-up per file) — thin names over the runtime; asynchronous on `stream`
+void *artamdDeviceAlloc (size_t bytes) { return arthip_malloc (bytes); }
+void artamdDeviceFree (void *p) { arthip_free (p); }
+int artamdUpload (void *d_dst, const void *h_src, size_t bytes, void *stream) { return arthip_h2d (d_dst, h_src, bytes, stream); }
+int artamdDownload (void *h_dst, const void *d_src, size_t bytes, void *stream) { return arthip_d2h (h_dst, d_src, bytes, stream); }
+int artamdDeviceZero (void *d_dst, size_t bytes, void *stream) { return arthip_zero (d_dst, bytes, stream); }
+int artamdStreamSynchronize (void *stream) { return arthip_sync (stream); }
 int arthip_current_device (void) { int d = 0; return hipGetDevice (&d) == hipSuccess ? d : -1; }
 
 void *arthip_malloc (size_t bytes)

@@ -20,6 +20,22 @@
  * Biquad design
  * ---------------------------------------------------------------------------------------- */
 
+/* The void entry points of the reference (biquad_apply_*, floatIntegersLE) cannot report a failure, and there is no CPU path to
+ * fall back to: a failure is printed, counted (artamdErrorCount / artamdLastError: tools check them before they trust the audio
+ * they write) and, with ARTAMD_ABORT_ON_ERROR=1, fatal on the spot. */
+static int pcm_errors;
+static char pcm_last_error [256];
+static void pcm_fail (const char *what)
+{
+    snprintf (pcm_last_error, sizeof (pcm_last_error), "%s: %s", what, arthip_last_error ());
+    fprintf (stderr, "artamd: %s\n", pcm_last_error);
+    __atomic_add_fetch (&pcm_errors, 1, __ATOMIC_RELAXED);
+    const char *e = getenv ("ARTAMD_ABORT_ON_ERROR");
+    if (e && *e && *e != '0') abort ();
+}
+int artamdErrorCount (void) { return __atomic_load_n (&pcm_errors, __ATOMIC_RELAXED); }
+const char *artamdLastError (void) { return pcm_errors ? pcm_last_error : NULL; }
+
 static void butterworth (double freq, double *K_out, double *norm_out, double *b1, double *b2)
 {
     const double Q = sqrt (0.5), K = tan (M_PI * freq);
@@ -171,8 +187,8 @@ static void biquad_run_host (Biquad *f, art_s *buffer, int n, int stride, int sa
 
     pthread_mutex_lock (&scratch_lock);
     if (arthip_device_count () < 1 || scratch_reserve ((size_t) n)) {
-        /* no CPU evaluation path exists: say so and leave the caller's samples and filter state untouched */
-        fprintf (stderr, "artamd: biquad needs a HIP device and scratch memory (no CPU path): %s\n", arthip_last_error ());
+        /* no CPU evaluation path exists: say so (counted: artamdErrorCount) and leave the caller's samples and filter state untouched */
+        pcm_fail ("biquad needs a HIP device and scratch memory (no CPU path)");
         pthread_mutex_unlock (&scratch_lock);
         return;
     }
@@ -211,7 +227,7 @@ static void biquad_run_host (Biquad *f, art_s *buffer, int n, int stride, int sa
     else
         rc = arthip_biquad_chain (host_scratch.d_state, 1, 1, host_scratch.d_in, n, sample_form ? -1 : 1, NULL);
 
-    if (rc) fprintf (stderr, "artamd: biquad launch failed: %s\n", arthip_last_error ());
+    if (rc) pcm_fail ("biquad launch failed (samples left unfiltered)");
     else {
         if (by_kernel)
             arthip_copy2_by_kernel (h, d_result, sizeof (art_s) * (size_t) n, host_scratch.h_state, host_scratch.d_state, sizeof (Biquad), NULL);
@@ -224,6 +240,7 @@ static void biquad_run_host (Biquad *f, art_s *buffer, int n, int stride, int sa
             else for (int i = 0; i < n; ++i) buffer [(size_t) i * stride] = h [i];      /* only this channel's samples are written */
             *f = *host_scratch.h_state;
         }
+        else pcm_fail ("biquad kernel failed (samples left unfiltered)");
     }
     pthread_mutex_unlock (&scratch_lock);
 }
@@ -961,8 +978,9 @@ void floatIntegersLE (unsigned char *input, double inputGain, int inputBits, int
         ingest_scratch.d_out = arthip_malloc (ingest_scratch.out_cap); ingest_scratch.h_out = arthip_host_alloc (ingest_scratch.out_cap);
     }
     if (arthip_device_count () < 1 || !ingest_scratch.d_in || !ingest_scratch.d_out || !ingest_scratch.h_in || !ingest_scratch.h_out) {
-        /* no CPU evaluation path exists: say so and leave the caller's buffer untouched */
-        fprintf (stderr, "artamd: floatIntegersLE needs a HIP device and scratch memory (no CPU path): %s\n", arthip_last_error ());
+        /* no CPU evaluation path exists: say so (counted: artamdErrorCount) and hand back silence rather than uninitialised memory */
+        pcm_fail ("floatIntegersLE needs a HIP device and scratch memory (no CPU path; output zeroed)");
+        memset (output, 0, out_bytes);
         ingest_scratch.in_cap = ingest_scratch.out_cap = 0;
         pthread_mutex_unlock (&ingest_lock);
         return;
@@ -976,6 +994,7 @@ void floatIntegersLE (unsigned char *input, double inputGain, int inputBits, int
     floatIntegersLEDevice (ingest_scratch.d_in, inputGain, inputBits, inputBytes, inputStride, ingest_scratch.d_out, numSamples, NULL);
     if (small) arthip_copy_by_kernel (ingest_scratch.h_out, ingest_scratch.d_out, out_bytes, NULL);
     else arthip_d2h (output, ingest_scratch.d_out, out_bytes, NULL);
-    if (!arthip_sync (NULL) && small) memcpy (output, ingest_scratch.h_out, out_bytes);
+    if (arthip_sync (NULL)) { pcm_fail ("floatIntegersLE kernel failed (output zeroed)"); memset (output, 0, out_bytes); }
+    else if (small) memcpy (output, ingest_scratch.h_out, out_bytes);
     pthread_mutex_unlock (&ingest_lock);
 }

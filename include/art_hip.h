@@ -25,6 +25,15 @@ extern "C" {
 
 /* ---- runtime ---- */
 int artamdDeviceCount (void);                       /* 0 when no usable gfx950 device / HIP runtime */
+/* device memory and transfers for callers of the device-pointer entry points that bring no GPU runtime of their own (a tool in C,
+ * or tools/art_gpu.py without torch): thin names over the HIP runtime; the transfers are asynchronous on `hipStream` (NULL: the
+ * null stream) and return 0 on success */
+void *artamdDeviceAlloc (size_t bytes);
+void artamdDeviceFree (void *d_ptr);
+int artamdUpload (void *d_dst, const void *h_src, size_t bytes, void *hipStream);
+int artamdDownload (void *h_dst, const void *d_src, size_t bytes, void *hipStream);
+int artamdDeviceZero (void *d_dst, size_t bytes, void *hipStream);
+int artamdStreamSynchronize (void *hipStream);
 const char *artamdVersion (void);
 
 /* Devices that RESAMPLE_MULTITHREADED contexts created from now on spread their channels over (contiguous, balanced
@@ -125,6 +134,12 @@ void biquadBankFree (BiquadBank *bank);
  * (pcm_kernels.hip, biquad_spec_kernel).  These report how many chunks had to be recomputed so far (normally 0). */
 unsigned int biquadBankRepairs (BiquadBank *bank);   /* synchronises */
 unsigned int artamdBiquadRepairs (void);             /* the host-pointer calls (biquad_apply_buffer) of this process */
+
+/* The reference's void entry points (biquad_apply_buffer / _sample, floatIntegersLE) cannot return an error and this library has no
+ * CPU path: a failure there (no device, allocation, launch) is printed to stderr, counted, and leaves silence (floatIntegersLE) or the
+ * unfiltered samples (biquad) behind.  A tool checks the count before it trusts what it writes; ARTAMD_ABORT_ON_ERROR=1 aborts instead. */
+int artamdErrorCount (void);
+const char *artamdLastError (void);                  /* NULL while the count is zero */
 
 /* ---- decimator, device pointers ---- */
 void decimateHipSetStream (Decimate *cxt, void *hipStream);

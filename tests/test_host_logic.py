@@ -45,6 +45,17 @@ def test_no_gpu_means_loud_failure_not_fallback(capfd):
     assert not L.decimateInit(2, 16, 2, 1.0, 48000, 0)
     err = capfd.readouterr().err
     assert "no CPU path" in err
+    # the reference's void entry points cannot return an error: counted, and silence rather than uninitialised memory comes back
+    before = L.artamdErrorCount()
+    raw, out = np.arange(16, dtype=np.uint8), np.full(8, 7.0, np.float32)
+    L.floatIntegersLE(raw.ctypes.data_as(C.POINTER(C.c_ubyte)), 1.0, 16, 2, 1, out.ctypes.data_as(C.POINTER(C.c_float)), 8)
+    assert L.artamdErrorCount() == before + 1 and not out.any() and b"no CPU path" in L.artamdLastError()
+    co, f = A.BiquadCoefficients(), A.Biquad()
+    L.biquad_lowpass(C.byref(co), 0.1); L.biquad_init(C.byref(f), C.byref(co), 1.0)
+    x = np.ones(8, np.float32)
+    L.biquad_apply_buffer(C.byref(f), x.ctypes.data_as(C.POINTER(C.c_float)), 8, 1)
+    assert L.artamdErrorCount() == before + 2 and np.all(x == 1.0)           # samples and filter state untouched
+    capfd.readouterr()
 
 
 @pytest.mark.parametrize("name", G.NAMES)

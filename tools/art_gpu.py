@@ -101,7 +101,9 @@ def parse_time_spec(text):
 
 
 def main(argv):
-    import torch
+    # (no torch: the library's own device-memory entry points — a second less start-up per file than importing a framework)
+    os.environ.setdefault("ARTAMD_NO_TORCH", "1")
+    import numpy as np
     import audio_resampler_amd as A
     L = A.lib()
 
@@ -160,7 +162,7 @@ def main(argv):
     outbits = outbits or inbits
     out_bytes = (outbits + 7) // 8
     ratio = rate_out / rate_in
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = None                                            # the null stream
 
     # ---- a target duration, absolute or relative, becomes a tempo ratio (art.c:740-765)
     if duration is not None:
@@ -218,31 +220,37 @@ def main(argv):
 
     cap = int(math.floor((stretch_cap + taps // 2) * ratio + 100.0))
     target = int(math.floor(frames_in * stretch_ratio * ratio + 0.5))
-    d_raw = torch.empty(BLOCK * ch * in_bytes, dtype=torch.uint8, device="cuda")
-    d_in = torch.empty(BLOCK, ch, dtype=torch.float32, device="cuda")
-    d_st = torch.empty(stretch_cap, ch, dtype=torch.float32, device="cuda") if st else None
-    d_out = torch.empty(cap, ch, dtype=torch.float32, device="cuda")
-    d_pcm = torch.empty(cap * ch * out_bytes, dtype=torch.uint8, device="cuda")
-    import numpy as np
+    def dev(nbytes):
+        p = L.artamdDeviceAlloc(max(int(nbytes), 16))
+        if not p:
+            raise SystemExit("device allocation failed")
+        return p
+    d_raw, d_in = dev(BLOCK * ch * in_bytes), dev(BLOCK * ch * 4)
+    d_st = dev(stretch_cap * ch * 4) if st else None
+    d_out, d_pcm = dev(cap * ch * 4), dev(cap * ch * out_bytes)
     raw = np.frombuffer(payload, dtype=np.uint8)
+    host_out = np.empty(cap * ch * max(out_bytes, 4), np.uint8)
 
     out_chunks, produced, pos = [], 0, 0
     while produced < target:
         n = min(BLOCK, frames_in - pos)
         if n > 0:
             nbytes = n * ch * in_bytes
-            d_raw[:nbytes].copy_(torch.from_numpy(raw[pos * ch * in_bytes:pos * ch * in_bytes + nbytes].copy()), non_blocking=True)
-            if inbits > 24:                     # 32-bit float input
-                d_in[:n].copy_(d_raw[:nbytes].view(torch.float32).view(n, ch))
+            piece = raw[pos * ch * in_bytes:pos * ch * in_bytes + nbytes]
+            if inbits > 24:                     # 32-bit float input: samples as they are (x gain, art.c:949-957)
+                fl = piece.view(np.float32)
                 if gain != 1.0:
-                    d_in[:n].mul_(np.float32(gain).item())
+                    fl = fl * np.float32(gain)
+                fl = np.ascontiguousarray(fl)
+                L.artamdUpload(d_in, fl.ctypes.data, nbytes, stream)
+                L.artamdStreamSynchronize(stream)       # (`fl` may be a temporary)
             else:
-                L.floatIntegersLEDevice(d_raw.data_ptr(), gain, inbits, in_bytes, 1, d_in.data_ptr(), n * ch, stream)
+                L.artamdUpload(d_raw, piece.ctypes.data, nbytes, stream)
+                L.floatIntegersLEDevice(d_raw, gain, inbits, in_bytes, 1, d_in, n * ch, stream)
             pos += n
         src = d_in
         if st:                                  # stretch (or drain the stretcher once the file is exhausted)
-            n = L.stretchProcessDevice(st, d_in.data_ptr(), n, d_st.data_ptr(), stretch_ratio) if n > 0 else \
-                L.stretchFlushDevice(st, d_st.data_ptr())
+            n = L.stretchProcessDevice(st, d_in, n, d_st, stretch_ratio) if n > 0 else L.stretchFlushDevice(st, d_st)
             src = d_st
         # ART filters `inbuffer` here although, when stretching, the resampler reads the stretcher's own buffer (art.c:1009-1016
         # against :1023): with a stretch the pre-filter has no effect on the output.  Reproduced: the file is the reference's.
@@ -261,15 +269,18 @@ def main(argv):
             # the stretcher can come up short of the rounded target: pad with silence (art.c:1036-1047)
             made = min(target - produced, cap)
             buf = d_out
-            d_out[:made].zero_()
+            L.artamdDeviceZero(d_out, made * ch * 4, stream)
         if post is not None and made:
             post.apply_device(buf, made)
         made = min(made, target - produced)
         if dec is not None:
             dec.process_device(buf, made, d_pcm)
-            out_chunks.append(d_pcm[:made * ch * out_bytes].cpu().numpy().tobytes())
+            nout, d_src = made * ch * out_bytes, d_pcm
         else:
-            out_chunks.append(buf[:made].contiguous().cpu().numpy().tobytes())
+            nout, d_src = made * ch * 4, buf
+        L.artamdDownload(host_out.ctypes.data, d_src, nout, stream)
+        L.artamdStreamSynchronize(stream)
+        out_chunks.append(host_out[:nout].tobytes())
         produced += made
 
     if st:
@@ -283,6 +294,11 @@ def main(argv):
     if not quiet:
         clipped = dec.clipped() if dec is not None else 0
         print(f"{produced} frames x {ch} ch written to {dst}" + (f"; {clipped} samples clipped" if clipped else ""), file=sys.stderr)
+    for p in (d_raw, d_in, d_st, d_out, d_pcm):
+        if p:
+            L.artamdDeviceFree(p)
+    if L.artamdErrorCount():                                  # (the reference's void entry points cannot report: counted instead)
+        raise SystemExit(f"error: {L.artamdLastError().decode()} — {dst} is not to be trusted")
 
 
 if __name__ == "__main__":

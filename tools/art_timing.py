@@ -6,10 +6,11 @@ import numpy as np
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 R = os.path.join(ROOT, "oracle", "_ref")
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+long_secs = float(sys.argv[2]) if len(sys.argv) > 2 else 600.0
 tmp = tempfile.mkdtemp()
 
 
-def make(rate, ch):
+def make(rate, ch, secs=secs):
     path = os.path.join(tmp, f"in_{rate}_{ch}.wav")
     n = int(rate * secs)
     rng = np.random.default_rng(1)
@@ -21,8 +22,9 @@ def make(rate, ch):
     return path
 
 
-for opts, rate, ch in (("-4 -r48000", 44100, 2), ("-3 -r44100 -p", 96000, 2), ("-2 --tempo=1.25", 44100, 2)):
-    src = make(rate, ch)
+for opts, rate, ch, dur in (("-4 -r48000", 44100, 2, secs), ("-3 -r44100 -p", 96000, 2, secs), ("-2 --tempo=1.25", 44100, 2, secs),
+                            ("-4 -r48000", 44100, 8, long_secs), ("-4 -r44100 -p -o16", 96000, 8, long_secs)):
+    src = make(rate, ch, dur)
     row = []
     for name, cmd in (("reference art", [os.path.join(R, "art_strict")]), ("art.c on libartamd", [os.path.join(R, "art_amd")]),
                       ("tools/art_gpu.py", [sys.executable, os.path.join(ROOT, "tools", "art_gpu.py")])):
@@ -31,4 +33,4 @@ for opts, rate, ch in (("-4 -r48000", 44100, 2), ("-3 -r44100 -p", 96000, 2), ("
         p = subprocess.run(cmd + opts.split() + ["-q", "-y", src, out], capture_output=True, text=True)
         dt = time.perf_counter() - t0
         row.append(f"{name}: {dt:6.2f} s" + ("" if p.returncode == 0 else " (FAILED)"))
-    print(f"{secs:.0f} s of {ch}-ch {rate} Hz audio, {opts:18s} | " + " | ".join(row), flush=True)
+    print(f"{dur:.0f} s of {ch}-ch {rate} Hz audio, {opts:18s} | " + " | ".join(row), flush=True)
