@@ -157,6 +157,22 @@ for which in ("resample", "biquad", "decimate", "all"):
     print(json.dumps(line), flush=True)
 
 
+# ---- the shaped decimator is a serial recurrence per channel (one lane each): it scales with channels, not with the chip
+for chn in (64, 512):
+    decn = A.Decimator(chn, 16, 2, 1.0, dst, A.DITHER_HIGHPASS | A.SHAPING_ATH_CURVE); decn.set_stream(stream)
+    nf = 1 << 18
+    xn, _ = noise(nf * chn); d_xn = torch.from_numpy(xn.reshape(nf, chn)).cuda(); d_pn = torch.empty(nf * chn * 2, dtype=torch.uint8, device="cuda")
+    def many():
+        decn.process_device(d_xn, nf, d_pn)
+        return nf * chn
+    n, dt = timed(many, max(2, args.steps // 3))
+    cpu = None if args.no_cpu else cpu_ref.decimate(chn, 16, 2, dst, A.DITHER_HIGHPASS | A.SHAPING_ATH_CURVE, block=65536, budget=args.cpu_budget, threaded=True)
+    print(json.dumps({"config": f"C'' 16-bit ATH-shaped decimation of {chn} channels (one serial lane per channel)", "Msamples_per_s": round(n / dt / 1e6, 1),
+                      "ms_per_step": round(dt / max(2, args.steps // 3) * 1e3, 3), "block_frames": nf, "channels": chn,
+                      "roofline": hbm_roofline(n / dt, 6.0, "decimate_pipe_kernel / decimate_lds_kernel"), "cpu_reference": cpu,
+                      "gpu_over_cpu": round(n / dt / 1e6 / cpu["Msamples_per_s"], 1) if cpu else None}), flush=True)
+    del decn, d_xn, d_pn
+
 # ---- C pipelined: the three stages of successive blocks overlap on three HIP streams (block k+1 in the biquads
 # while block k is resampled and block k-1 decimated); buffers are double-buffered and ordered with events.
 sA, sB, sC = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerate the measurement evidence of a round on the GPU box (via gpurun): bench line, rocprofv3 kernel statistics and PMC
 # passes (separate runs; --pmc never together with --stats) for the headline kernel and for every other kernel the library ships.
-# usage: bash tools/refresh_evidence.sh [tag]      -> gpurun_out/<tag>/...   then: python tools/roofline_report.py gpurun_out/<tag> profiles r2
+# usage: bash tools/refresh_evidence.sh [tag]      -> gpurun_out/<tag>/...   then: python tools/roofline_report.py gpurun_out/<tag> profiles r3
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-evidence}
@@ -39,8 +39,13 @@ for c in fixed_D4 fixed_D32 general_E general_P general_A matrix_B matrix_D4 mat
   allpasses $c python $R/tools/profile_case.py $c 4
 done
 python $R/tools/bench_configs.py --steps 30 > $OUT/configs.jsonl 2> $OUT/configs.err
+# what the counters report for a known byte count, per access width (the fp64 kernel's 8-byte loads)
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE WRITE_SIZE --output-format csv -d $OUT/pmc -o calib -- $R/tools/micro/fetch_calib > $OUT/fetch_calib.log 2>&1
+# the same bench line with the traffic measured in THIS lease (roofline_report.py writes the json from the passes above)
+python $R/tools/roofline_report.py $OUT $OUT/report r3 > $OUT/report.log 2>&1
+python $R/bench.py --pmc-json $OUT/report/r3_traffic.json > $OUT/bench_pmc.json 2> $OUT/bench_pmc.err
 python $R/tools/bench_wide.py --block 1048576 --steps 20 > $OUT/wide.jsonl 2>/dev/null
 bash $R/tools/bench_fixed_point.sh > $OUT/fixed_point_shapes.txt 2>&1
 ARTAMD_HOST_TRACE=1 python $R/tools/bench_host_api.py > $OUT/host_api.txt 2>&1
-python $R/tools/art_timing.py 60 > $OUT/art_timing.txt 2>&1
+python $R/tools/art_timing.py 60 600 > $OUT/art_timing.txt 2>&1
 ls $OUT $OUT/prof $OUT/pmc | head -80

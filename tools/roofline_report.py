@@ -52,7 +52,7 @@ for f in ("bench100.json", "bench.json"):
 # ---- headline
 st = stats("headline")
 fixed = str(bench.get("dtype", "")).startswith("i8")
-frag = "fir_i8_stream" if fixed else "fir_mfma"
+frag = "fir_i8_" if fixed else "fir_mfma"
 kname, (calls, avg_ns, pct) = find(st, frag)
 c = counters("headline", frag)
 spl = bench["roofline"]["algorithmic_bytes_per_launch"] / bench["roofline"]["bytes_per_sample"]
@@ -76,7 +76,8 @@ if c.get("SQ_VALU_MFMA_BUSY_CYCLES") and c.get("GRBM_GUI_ACTIVE"):
     tj["mfma_pipe_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (c["GRBM_GUI_ACTIVE"] / 8), 3)
 json.dump(tj, open(os.path.join(dst, f"{rnd}_traffic.json"), "w"), indent=1)
 summary.append(("headline", kname, c))
-for frag2, what in (("mfma_prepare", "its prepare launch"), ("i8_stage", "its staging pass: digit planes of the rows and of history ++ input"), ("fir_mfma_stream", "its f32 stand-by, dismissed on the device")):
+for frag2, what in (("mfma_prepare", "its prepare launch"), ("i8_stage_kernel<true, true>", "its peak pass: per-slice peaks of history ++ input + the rows' digit planes"),
+                    ("i8_stage_kernel<true, false>", "its quantise pass: block exponents, digit planes of history ++ input"), ("fir_mfma_stream", "the f32 kernel of the same run (bench.py's value_f32 leg)")):
     pk, v = find(st, frag2)
     if pk and pk != kname: rows.append((f"  ({what})", pk, v[0], v[1], "-", "-", "-", None, None))
 # the f32 streaming kernel on the same workload (bench.py --kernel 6)
