@@ -17,6 +17,7 @@
 #include "resampler.h"
 #include "biquad.h"
 #include "decimator.h"
+#include <stddef.h>
 #include "stretch.h"
 
 #ifdef __cplusplus
