@@ -48,6 +48,7 @@ while time.time() < t_end:
     # (every session at its own level, every channel a little apart: the tolerance below is relative to the session's level, as
     # float arithmetic's — and the fixed-point kernel's block floating point's — is)
     level = float(10.0 ** rng.uniform(-5.0, 1.5)) if rng.integers(0, 2) else 1.0
+    unit = 2.0 ** np.ceil(np.log2(level))                 # the power of two at or above the level: what "full scale" is for this session
     x = ((rng.random((sum(calls) + 8, ch)) - 0.5) * (level * (0.5 + 0.5 * rng.random(ch)))).astype(dt)
     pos, bad, used_kernels = 0, None, set()
     for k, n in enumerate(calls):
@@ -61,13 +62,13 @@ while time.time() < t_end:
             d = np.abs(y - yo); tol = 2.0 ** -47 * np.maximum(1.0, np.abs(yo))
             if not np.all(d <= tol): bad = ("value64", k, float(d.max())); break
         else:
-            ok, worst, rms = tolerance_ok(y.astype(np.float64) / level, yo.astype(np.float64) / level)
+            ok, worst, rms = tolerance_ok(y.astype(np.float64) / unit, yo.astype(np.float64) / unit)
             if not ok: bad = ("value", k, worst, level, int(np.argmax(np.abs(y.astype(np.float64) - yo)) // ch), g); break
         pos += u
     if bad is None:
         u, g, y = h.process(None, 2 * T, ratio, flush=True); uo, go, yo = o.process(None, 2 * T, ratio, flush=True)
         if g != go: bad = ("flush counts", g, go)
-        elif g and not wide and not tolerance_ok(np.array(y, np.float64) / level, np.array(yo, np.float64) / level)[0]: bad = ("flush value",)
+        elif g and not wide and not tolerance_ok(np.array(y, np.float64) / unit, np.array(yo, np.float64) / unit)[0]: bad = ("flush value",)
     desc = f"wide={int(wide)} ch={ch} T={T} F={F} {src}->{dst} interp={int(interp)} fixed={int(fixed)} calls={calls} kernels={sorted(used_kernels)}"
     kinds[(wide, tuple(sorted(used_kernels)))] = kinds.get((wide, tuple(sorted(used_kernels))), 0) + 1
     if bad: n_bad += 1; print("FAIL", desc, bad, flush=True)

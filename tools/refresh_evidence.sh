@@ -40,7 +40,8 @@ for c in fixed_D4 fixed_D32 general_E general_P general_A matrix_B matrix_D4 mat
 done
 python $R/tools/bench_configs.py --steps 30 > $OUT/configs.jsonl 2> $OUT/configs.err
 # what the counters report for a known byte count, per access width (the fp64 kernel's 8-byte loads)
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE WRITE_SIZE --output-format csv -d $OUT/pmc -o calib -- $R/tools/micro/fetch_calib > $OUT/fetch_calib.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc -o calib_fetch -- $R/tools/micro/fetch_calib > $OUT/fetch_calib.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc -o calib_write -- $R/tools/micro/fetch_calib >> $OUT/fetch_calib.log 2>&1
 # the same bench line with the traffic measured in THIS lease (roofline_report.py writes the json from the passes above)
 python $R/tools/roofline_report.py $OUT $OUT/report r3 > $OUT/report.log 2>&1
 python $R/bench.py --pmc-json $OUT/report/r3_traffic.json > $OUT/bench_pmc.json 2> $OUT/bench_pmc.err
