@@ -5,7 +5,7 @@
 // rounded once to 32-bit BLOCK floating point: the launch's periods are cut into exponent blocks (~10k input frames: a fraction
 // of a second; the length depends on the ratio and the filter only, never on the channel count, so a channel's bits do not
 // depend on which other channels share its context), and inside a block every channel has its own binary exponent, taken
-// from the channel's peak |x| over the frames the block's outputs read, so that the peak lands in [2^29, 2^31 - 2^23) — exact
+// from the channel's peak |x| over the frames the block's outputs read, so that the peak lands in [2^29, 2^31 - 2^24) — exact
 // for every float sample within 2^-6 of that peak, (peak) x 2^-31 absolute below it: the error model is RELATIVE to the
 // channel's level around the output, as float arithmetic's is, not tied to full scale.  Both are written as four signed
 // base-256 digits each (d0 most significant: value = sum_i d_i 256^(3-i)).  The dot product of two such numbers is
@@ -51,7 +51,7 @@ constexpr int I8_COLS = 128;              // columns per workgroup
 constexpr int I8_MAX_PPW = 64;
 constexpr int I8_PADF = 64;               // zero frames in front of linear frame 0 in the digit planes
 constexpr float I8_SCALE = 1073741824.0f; // 2^30: the filter rows' fixed point
-constexpr float I8_LIMIT = 1.98f;         // |row value| the digits can hold: (2^31 - 2^23) / 2^30, rounded down
+constexpr float I8_LIMIT = 1.98f;         // |row value| the digits can hold: 0x7f7f7f7f / 2^30 = 1.98437..., rounded down
 
 struct I8Geom {
     int g;                                // period stride inside a tile
@@ -77,12 +77,14 @@ struct I8Geom {
     int *shifts;                          // [ebs][C]: the block's samples of channel c are quantised as rint (x * 2^shift)
 };
 
-// binary exponent for a channel whose peak magnitude has these float bits: peak * 2^shift in [2^29, 2^31 - 2^23) — as large as the
-// digits hold (the top digit of (q + 0x80808080) must not overflow).  Zero and denormal peaks take the smallest normal's exponent.
+// binary exponent for a channel whose peak magnitude has these float bits: peak * 2^shift in [2^29, 2^31 - 2^24) — as large as the
+// digits hold: four signed digits reach 0x7f7f7f7f = (2^31 - 2^23) - 0x8081 and no further (q + 0x80808080 must not carry out of
+// the dword), so a peak whose six leading mantissa bits are all ones (>= 2^31 - 2^24 at the larger exponent) takes one bit less.
+// Zero and denormal peaks take the smallest normal's exponent.
 __device__ __forceinline__ int shift_of_peak (unsigned int bits)
 {
     const int e = max ((int)(bits >> 23), 1);
-    return 157 - e - ((bits & 0x7f0000u) == 0x7f0000u ? 1 : 0);
+    return 157 - e - ((bits & 0x7e0000u) == 0x7e0000u ? 1 : 0);
 }
 
 constexpr int I8_STAGE_THREADS = 256;     // workgroup of the two staging passes
@@ -191,7 +193,7 @@ __device__ __forceinline__ void stage_slice (const ArtFirArgs &a, const MfmaGeom
     }
     __syncthreads ();
     const unsigned int pk = s_peak [tid & (q.cgrp - 1)];
-    // the channel's exponent in this block: |x| <= peak, so |x * 2^shift| < 2^31 - 2^23 and the scaling itself is exact (v_ldexp_f32)
+    // the channel's exponent in this block: |x| <= peak, so |x * 2^shift| < 2^31 - 2^24 <= 0x7f7f7f7f and the scaling itself is exact (v_ldexp_f32)
     const int shift = shift_of_peak (pk);
     if (tid < q.cgrp && slice == 0) {
         q.shifts [eb * a.C + c] = shift;

@@ -182,6 +182,37 @@ def test_fixed_point_floor_is_relative_to_the_channels_peak_in_the_exponent_bloc
     assert _rms(errs [1]) <= 1.25 * _rms(refs [1])
 
 
+EDGE_MANTISSAS = [0x7dffff, 0x7e0000, 0x7efefe, 0x7efeff, 0x7eff80, 0x7effff, 0x7f0000, 0x7fffff]
+
+
+@pytest.mark.parametrize("sign", [1.0, -1.0], ids=["positive", "negative"])
+def test_peaks_at_the_top_of_the_digit_range_do_not_carry_out_of_the_top_digit(sign):
+    """four signed base-256 digits end at 0x7f7f7f7f, 0x8081 short of 2^31 - 2^23: a channel's peak with mantissa 0x7efeff ... 0x7effff
+    scaled to exponent 30 would carry out of the dword (found by tools/fuzz_long.py --kernel 7 --seed 41, session 1279: one such
+    sample among 6.7 M, an output wrong by half of full scale).  Every channel here has its peak on one of the mantissas around
+    the boundaries, at different binary exponents, positive or negative, one exponent block each"""
+    ch, T, frames = 8, 48, 60000
+    ratio = 32000 / 48000
+    x, _ = noise(frames * ch, state=0xED6E | 1)
+    x = x.reshape(frames, ch).copy()
+    for c, mant in enumerate(EDGE_MANTISSAS):
+        peak = np.array([(126 + c % 3) << 23 | mant], np.uint32).view(np.float32) [0]         # 0.99.. / 1.98.. / 3.9..
+        x [:, c] *= np.float32(peak)                                                            # |noise| <= 0.5: below the peak
+        for f in range(5000 + 37 * c, frames, 9000):                                            # one peak sample per exponent block
+            x [f, c] = np.float32(sign) * peak
+    cap = int(frames * ratio) + 400
+    r = HipResampler(ch, T, T, 0.0, BH | LOWPASS, fixed=(48000.0, 32000.0, 0), kernel=7); r.advance(T / 2)
+    o = OracleResampler(ch, T, T, 0.0, BH | LOWPASS | PRECISE, fixed=(48000.0, 32000.0, 0)); o.advance(T / 2)
+    u, g, y = r.process(x, cap, ratio)
+    assert r.last_kernel() == 2 and r.fixed_point() [0] == 1, (r.last_kernel(), r.fixed_point())
+    uo, go, yo = o.process(x, cap, ratio, threads=8)
+    assert (u, g) == (uo, go)
+    y64, t64 = np.array(y, np.float64), np.array(yo, np.float64)
+    for c in range(ch):
+        err = np.abs(y64 [:, c] - t64 [:, c])
+        assert np.all(err <= _spacing(t64 [:, c]) + 2.0 ** -24 * 4.0), (c, hex(EDGE_MANTISSAS [c]), float(err.max()))
+
+
 BAD = [("above the old range", 2.5, 1), ("below the old range", -1.99, 1), ("huge", -3e30, 1), ("infinity", np.inf, 2), ("NaN", np.nan, 2)]
 
 

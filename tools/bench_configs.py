@@ -129,7 +129,8 @@ def dither_only():
     dec0.process_device(d_out, cap - 16, d_pcm)
     return (cap - 16) * ch
 n, dt = timed(dither_only, args.steps)
-cpu = None if args.no_cpu else cpu_ref.decimate(ch, 16, 2, dst, A.DITHER_HIGHPASS, block=65536, budget=args.cpu_budget, threaded=True)
+# (one thread: the reference's threaded decimator dereferences its noise shapers even when shaping is off — decimator.c:129-130, a NULL pointer here)
+cpu = None if args.no_cpu else cpu_ref.decimate(ch, 16, 2, dst, A.DITHER_HIGHPASS, block=65536, budget=args.cpu_budget, threaded=False)
 print(json.dumps({"config": "C' 16-bit decimation, HP-TPDF dither, no noise shaping (no recurrence => fully parallel)", "Msamples_per_s": round(n / dt / 1e6, 1),
                   "ms_per_step": round(dt / args.steps * 1e3, 3), "roofline": hbm_roofline(n / dt, 6.0, "decimate_parallel_kernel"),
                   "cpu_reference": cpu, "gpu_over_cpu": round(n / dt / 1e6 / cpu["Msamples_per_s"], 1) if cpu else None}), flush=True)

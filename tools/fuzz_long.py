@@ -10,14 +10,16 @@ import audio_resampler_amd as A
 import _oracle
 from _hip import tolerance_ok
 
-ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=240); ap.add_argument("--seed", type=int, default=1); ap.add_argument("--budget", type=float, default=4e8); ap.add_argument("--kernel", type=int, default=2, help="kernel preference of the 4-byte contexts: 2 matrix path (automatic among its kernels), 7 fixed point wherever it can run")
+ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=240); ap.add_argument("--seed", type=int, default=1); ap.add_argument("--budget", type=float, default=4e8); ap.add_argument("--only", type=int, default=-1, help="replay: draw every session's parameters and data but run only session number N"); ap.add_argument("--kernel", type=int, default=2, help="kernel preference of the 4-byte contexts: 2 matrix path (automatic among its kernels), 7 fixed point wherever it can run")
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
 BH, INTERP, LOWPASS, PRECISE = _oracle.BH, _oracle.INTERP, _oracle.LOWPASS, _oracle.PRECISE
 t_end = time.time() + args.seconds
 n_ok = n_bad = 0
 kinds = {}
+session = -1
 while time.time() < t_end:
+    session += 1
     wide = bool(rng.integers(0, 4) == 0)
     ch = int(rng.choice([1, 2, 3, 4, 6, 8, 16, 32, 33]))
     T = int(rng.choice([48, 156, 380, 988, 1024]))
@@ -38,6 +40,12 @@ while time.time() < t_end:
         dt = np.float32
         mk_h = lambda: A.Resampler(ch, T, F, 0.0, flags | (LOWPASS if fixed else 0), (float(src), float(dst), 0) if fixed else None)
         mk_o = lambda: _oracle.OracleResampler(ch, T, F, 0.0, flags | (LOWPASS if fixed else 0) | PRECISE, fixed=(float(src), float(dst), 0) if fixed else None)
+    if args.only >= 0 and session != args.only:
+        if not wide or True:
+            level = float(10.0 ** rng.uniform(-5.0, 1.5)) if rng.integers(0, 2) else 1.0
+            rng.random((sum(calls) + 8, ch)); rng.random(ch)       # (the draws the session would have made)
+        if session > args.only: break
+        continue
     try:
         h, o = mk_h(), mk_o()
     except Exception as e:
@@ -69,7 +77,7 @@ while time.time() < t_end:
         u, g, y = h.process(None, 2 * T, ratio, flush=True); uo, go, yo = o.process(None, 2 * T, ratio, flush=True)
         if g != go: bad = ("flush counts", g, go)
         elif g and not wide and not tolerance_ok(np.array(y, np.float64) / unit, np.array(yo, np.float64) / unit)[0]: bad = ("flush value",)
-    desc = f"wide={int(wide)} ch={ch} T={T} F={F} {src}->{dst} interp={int(interp)} fixed={int(fixed)} calls={calls} kernels={sorted(used_kernels)}"
+    desc = f"#{session} wide={int(wide)} ch={ch} T={T} F={F} {src}->{dst} interp={int(interp)} fixed={int(fixed)} calls={calls} kernels={sorted(used_kernels)}"
     kinds[(wide, tuple(sorted(used_kernels)))] = kinds.get((wide, tuple(sorted(used_kernels))), 0) + 1
     if bad: n_bad += 1; print("FAIL", desc, bad, flush=True)
     else: n_ok += 1
