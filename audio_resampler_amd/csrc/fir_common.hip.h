@@ -141,6 +141,31 @@ __attribute__ ((unused)) __device__ __forceinline__ double fused (double a, doub
 // coefficient loads in flight and share the reduction.  The price is latency on calls too small to fill the chip — a
 // group walks more tap pairs than a wave did: 12 -> 14 us for 1,024 frames at 8 ch x 988 taps — which is why 16 lanes stop
 // at 256 taps (at 380 they gain no more than 32 and cost a 10 ms block 2 us).
+// The matrix-core kernels' tiles hold `rows` consecutive slots of ONE period.  A short period (48k -> 32k: 2 outputs per 3 inputs;
+// 44.1k -> 88.2k: 2 per 1) would leave a tile all but empty, and one that is a little more than a whole number of tiles leaves its
+// last tile mostly empty — but any multiple of a period is a period: such ratios are taken several periods at a time (32 per 48,
+// 32 per 16).  Returns the multiple: 1 while the padding stays within 15 %, else the one that fills whole tiles, or — where that takes more
+// than 16 tiles — the smallest that brings the padding within 4 % (the best below 16 tiles).  A function of the ratio alone: every context of a stream, sharded or not, chooses the same.
+static inline int artfir_period_multiple (int P, int rows)
+{
+    const int tiles = (P + rows - 1) / rows;
+    if (tiles * rows * 100 <= P * 115) return 1;
+    static const bool off = [] { const char *e = getenv ("ARTAMD_PERIOD_MULTIPLE"); return e && *e == '0'; } ();     // (A/B runs)
+    if (off) return 1;
+    {   // (a multiple that fills whole tiles, if a small one does)
+        int a = P, b = rows;
+        while (b) { const int t = a % b; a = b; b = t; }
+        if ((rows / a) * P <= 16 * rows) return rows / a;
+    }
+    int best = 1;
+    double best_waste = (double) tiles * rows / P;
+    for (int mu = 2; mu * P <= 16 * rows; ++mu) {
+        const double w = (double)(((mu * P + rows - 1) / rows) * rows) / (mu * P);
+        if (w < best_waste - 1e-9) { best = mu; best_waste = w; if (w <= 1.04) break; }
+    }
+    return best;
+}
+
 __host__ __device__ constexpr int general_group (int taps) { return taps <= 256 ? 16 : 32; }
 
 } // namespace

@@ -586,7 +586,10 @@ bool artfir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int
 static int matrix_geometry (const ArtFirArgs *a, MfmaGeom &g)
 {
     const unsigned int total = a->n_end - a->n_begin;
-    g.P = a->period_out; g.Q = a->period_in;
+    {   // (short or badly fitting periods: several at a time, fir_common.hip.h)
+        const int mu = artfir_period_multiple (a->period_out, 32);
+        g.P = mu * a->period_out; g.Q = mu * a->period_in;
+    }
     // compile-time channel count where the whole stream is one column group and the buffers allow vector loads
     const bool small = (size_t) a->in_frames * a->C * 4 < 0xffff0000ull && ((uintptr_t) a->in % 16) == 0 && ((uintptr_t) a->hist % 16) == 0;
     const int cgt = (small && (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32)) ? a->C : 0;

@@ -315,7 +315,10 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
         const bool ok = artfir_takes_matrix_path (a, segs, kernel_pref);
         if (ok) {
             WideGeom g;
-            g.P = a->period_out; g.Q = a->period_in;
+            {   // (short or badly fitting periods: several at a time, fir_common.hip.h)
+                const int mu = artfir_period_multiple (a->period_out, MW_ROWS);
+                g.P = mu * a->period_out; g.Q = mu * a->period_in;
+            }
             g.slot_tiles = (g.P + MW_ROWS - 1) / MW_ROWS;
             g.nrows = a->interpolate ? 64 : 32;
             const int shift_max = (int)((MW_ROWS - 1.0) * g.Q / g.P) + 2;
