@@ -54,12 +54,16 @@ constexpr float I8_SCALE = 1073741824.0f; // 2^30: the filter rows' fixed point
 constexpr float I8_LIMIT = 1.98f;         // |row value| the digits can hold: 0x7f7f7f7f / 2^30 = 1.98437..., rounded down
 
 struct I8Geom {
+    int tr;                               // rows (slots) per tile: 32, or 64 (fir_i8_wide_kernel: two 32-row register tiles on one K origin)
+    int tiles;                            // ceil (P / tr)
+    int ktot;                             // K columns of a tile: T + the span of its rows' window starts + alignment, a multiple of I8_KC
     int g;                                // period stride inside a tile
     int gq4;                              // g * Q / 4: blocks between consecutive columns' periods
     int super_groups;                     // groups of g * ppw consecutive periods
     int sg_per_xcd;
     unsigned char *a_planes;
     unsigned long long *a_masks;          // [variant][row]: bit c set = chunk c of the row has a non-zero most significant digit
+    unsigned long long *tile_masks;       // [variant][32-row half]: the OR over the half's rows (quantise launch; read by fir_i8_wide_kernel)
     const unsigned char *x_planes;        // (written through x_planes_w by the staging pass)
     unsigned int *x_planes_w;
     // exponent blocks: block e = periods [e * eb_periods, (e + 1) * eb_periods) of the launch; its planes hold 4-frame blocks
@@ -230,26 +234,20 @@ void i8_stage_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g, I8Geom q)
 {
     const int tid = threadIdx.x;
     // (PEAK launch: the row workgroups come first in the grid — latency chains, they finish under the X workgroups' traffic)
-    const unsigned int a_wgs = PEAK ? (unsigned int)(g.slot_tiles * q.g) * 32u : 0u;
-    if (blockIdx.x < a_wgs) {
-        // ---- A role ----
-        const int ab = (int) blockIdx.x;
-        const int variant = ab >> 5, row = ab & 31;
-        const int st = variant / q.g, jr = variant - st * q.g;
+    const unsigned int t_wgs = PEAK ? (unsigned int) g.slot_tiles * 32u : 0u;
+    const unsigned int a_wgs = PEAK ? t_wgs + (unsigned int)(q.tiles * q.g * q.tr) : 0u;
+    if (blockIdx.x < t_wgs) {
+        // ---- table role: what mfma_prepare_kernel leaves for the f32 streaming kernels (that kernel is not launched at all then):
+        // one workgroup per row of the 32-row slot tiles — the effective rows in float, the canonical positions, the tiles' origins
+        const int st = (int) blockIdx.x >> 5, row = (int) blockIdx.x & 31;
         const int rows_valid = min (32, g.P - st * 32);
         const Pos p0 = locate<INTERP> (a, segs, a.n_begin + st * 32);
         const Pos p = locate<INTERP> (a, segs, a.n_begin + st * 32 + min (row, rows_valid - 1));
         const float *h0 = a.bank + (size_t) p.fi * a.T;
-        // K column 0 of this tile family sits r frames before the first slot's window (the start of its 4-frame block)
-        const int r = max (p0.ip - a.T / 2 + 1 + jr * g.Q + I8_PADF, 0) & 3;
-        const int shift = p.ip - p0.ip + r;
-        bool bad = false;
-        __shared__ unsigned long long s_mask;
         __shared__ unsigned int s_pass;
-        if (tid == 0) { s_mask = 0ull; s_pass = 0u; }
-        __syncthreads ();
-        // what mfma_prepare_kernel leaves for the streaming kernels is written here: that kernel is not launched at all then
-        if (jr == 0 && row == 0) {
+        if (row == 0) {
+            if (tid == 0) s_pass = 0u;
+            __syncthreads ();
             if (tid == 0) {
                 g.tile_w0 [3 * st] = p0.ip - a.T / 2 + 1;
                 if (st == 0) a.fix_count [0] = 0;
@@ -260,28 +258,48 @@ void i8_stage_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g, I8Geom q)
                 const Pos pq = locate<INTERP> (a, segs, a.n_begin + st * 32 + tid);
                 if ((pq.fi % a.F) == 0) atomicOr (&s_pass, 1u << tid);
             }
+            __syncthreads ();
+            if (tid == 0) { g.tile_w0 [3 * st + 1] = (int) s_pass; g.tile_w0 [3 * st + 2] = 0; }
         }
-        if (jr == 0) {
-            // ... including the effective rows in float and the canonical positions (what the f32 streaming kernel stages)
-            if (tid == 0) { g.canon_ip [st * 32 + row] = p.ip; g.canon_fi [st * 32 + row] = p.fi; g.canon_frac [st * 32 + row] = p.frac; }
-            float *dst = g.eff + (size_t)(st * 32 + row) * g.ktot;
-            for (int k = tid; k < g.ktot; k += 256) {
-                const int tap = k - (p.ip - p0.ip);
-                float cf = 0.0f;
-                if (tap >= 0 && tap < a.T) {
-                    if (INTERP) {
-                        const double left = (double) h0 [tap] * (1.0 - p.frac);
-                        const double right = (double) h0 [tap + a.T] * p.frac;
-                        cf = (float)(left + right);
-                    }
-                    else cf = h0 [tap];
+        if (tid == 0) { g.canon_ip [st * 32 + row] = p.ip; g.canon_fi [st * 32 + row] = p.fi; g.canon_frac [st * 32 + row] = p.frac; }
+        float *dst = g.eff + (size_t)(st * 32 + row) * g.ktot;
+        for (int k = tid; k < g.ktot; k += 256) {
+            const int tap = k - (p.ip - p0.ip);
+            float cf = 0.0f;
+            if (tap >= 0 && tap < a.T) {
+                if (INTERP) {
+                    const double left = (double) h0 [tap] * (1.0 - p.frac);
+                    const double right = (double) h0 [tap + a.T] * p.frac;
+                    cf = (float)(left + right);
                 }
-                dst [k] = cf;
+                else cf = h0 [tap];
             }
+            dst [k] = cf;
         }
+        return;
+    }
+    if (blockIdx.x < a_wgs) {
+        // ---- planes role: one workgroup per (tile, residue) variant and row -> the row's digit planes (same arithmetic as
+        // mfma_prepare_kernel up to the rounding: the fp64 blend goes straight to fixed point, not through float)
+        const int ab = (int)(blockIdx.x - t_wgs);
+        const int variant = ab / q.tr, row = ab - variant * q.tr;
+        const int st = variant / q.g, jr = variant - st * q.g;
+        const int rows_valid = min (q.tr, g.P - st * q.tr);
+        const Pos p0 = locate<INTERP> (a, segs, a.n_begin + st * q.tr);
+        const Pos p = locate<INTERP> (a, segs, a.n_begin + st * q.tr + min (row, rows_valid - 1));
+        const float *h0 = a.bank + (size_t) p.fi * a.T;
+        // K column 0 of this tile family sits r frames before the first slot's window (the start of its 4-frame block)
+        const int r = max (p0.ip - a.T / 2 + 1 + jr * g.Q + I8_PADF, 0) & 3;
+        const int shift = p.ip - p0.ip + r;
+        bool bad = false;
+        __shared__ unsigned long long s_mask;
+        if (tid == 0) s_mask = 0ull;
+        __syncthreads ();
         unsigned long long mine = 0ull;
-        unsigned char *base = q.a_planes + (size_t) variant * (g.ktot / I8_KC) * 4096 + row * 16;
-        for (int k4 = tid * 4; k4 < g.ktot; k4 += 1024) {
+        // [variant][chunk][plane][16-tap half][row][16 taps]: the tr * 128 bytes a workgroup stages per chunk are contiguous
+        const int chunk_bytes = q.tr * 128, plane_bytes = q.tr * 32, half_bytes = q.tr * 16;
+        unsigned char *base = q.a_planes + (size_t) variant * (q.ktot / I8_KC) * chunk_bytes + row * 16;
+        for (int k4 = tid * 4; k4 < q.ktot; k4 += 1024) {
             unsigned int s [4], pl [4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -300,21 +318,28 @@ void i8_stage_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g, I8Geom q)
             }
             to_planes (s, pl);
 #pragma unroll
-            for (int pn = 0; pn < 4; ++pn) *reinterpret_cast<unsigned int *> (base + (size_t)(k4 >> 5) * 4096 + pn * 1024 + ((k4 >> 4) & 1) * 512 + (k4 & 15)) = pl [pn];
+            for (int pn = 0; pn < 4; ++pn) *reinterpret_cast<unsigned int *> (base + (size_t)(k4 >> 5) * chunk_bytes + pn * plane_bytes + ((k4 >> 4) & 1) * half_bytes + (k4 & 15)) = pl [pn];
             if (pl [0]) mine |= 1ull << (k4 >> 5);
         }
         if (mine) atomicOr (&s_mask, mine);
         __syncthreads ();
-        if (tid == 0) {
-            q.a_masks [variant * 32 + row] = s_mask;
-            if (jr == 0 && row == 0) { g.tile_w0 [3 * st + 1] = (int) s_pass; g.tile_w0 [3 * st + 2] = 0; }
-        }
+        if (tid == 0) q.a_masks [variant * q.tr + row] = s_mask;
         if (bad) *q.flag = q.epoch;
         return;
     }
     // ---- X role ----
     const int groups = a.C / q.cgrp;
     const int xid = (int)(blockIdx.x - a_wgs);
+    if (!PEAK && xid >= q.ebs * groups * q.slices) {
+        // (behind the X workgroups of the quantise launch: the rows' masks of the launch before it, per 32-row register tile)
+        const int e = (xid - q.ebs * groups * q.slices) * I8_STAGE_THREADS + tid, halves = q.tr / 32;
+        if (e < q.tiles * q.g * halves) {
+            unsigned long long m = 0ull;
+            for (int r = 0; r < 32; ++r) m |= q.a_masks [(e / halves) * q.tr + (e % halves) * 32 + r];
+            q.tile_masks [e] = m;
+        }
+        return;
+    }
     const int slice = xid % q.slices, xb = xid / q.slices, eb = xb / groups, cgi = xb - eb * groups;
     const int gb0 = q.b0 + eb * q.eb_step;                      // the region's first block
     // (slices that start inside the history ++ head span — the first few — read two arrays and leave the stand-by its head)
@@ -386,13 +411,13 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
     }
 
     const int xcd = blockIdx.x & 7, rank = blockIdx.x >> 3;
-    const int tiles_per_xcd = q.sg_per_xcd * q.g * g.slot_tiles;
-    const int nchunks = g.ktot / I8_KC;
+    const int tiles_per_xcd = q.sg_per_xcd * q.g * q.tiles;
+    const int nchunks = q.ktot / I8_KC;
 
     // tile `within` of this XCD's list -> (slot tile, first period); false if the tile holds no output of the launch
     auto tile_at = [&] (int within, int &st, int &j0) -> bool {
-        st = within % g.slot_tiles;
-        const int t2 = within / g.slot_tiles, jr = t2 % q.g, sg = xcd * q.sg_per_xcd + t2 / q.g;
+        st = within % q.tiles;
+        const int t2 = within / q.tiles, jr = t2 % q.g, sg = xcd * q.sg_per_xcd + t2 / q.g;
         if (sg >= q.super_groups) return false;
         j0 = sg * q.g * PPW + jr;
         return a.n_begin + (unsigned int) j0 * g.P + (unsigned int)(st * 32) < a.n_end;
@@ -649,13 +674,13 @@ void fir_i8_dma_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
     }
 
     const int xcd = blockIdx.x & 7, rank = blockIdx.x >> 3;
-    const int tiles_per_xcd = q.sg_per_xcd * q.g * g.slot_tiles;
-    const int nchunks = g.ktot / I8_KC;
+    const int tiles_per_xcd = q.sg_per_xcd * q.g * q.tiles;
+    const int nchunks = q.ktot / I8_KC;
 
     // tile `within` of this XCD's list -> (slot tile, first period); false if the tile holds no output of the launch
     auto tile_at = [&] (int within, int &st, int &j0) -> bool {
-        st = within % g.slot_tiles;
-        const int t2 = within / g.slot_tiles, jr = t2 % q.g, sg = xcd * q.sg_per_xcd + t2 / q.g;
+        st = within % q.tiles;
+        const int t2 = within / q.tiles, jr = t2 % q.g, sg = xcd * q.sg_per_xcd + t2 / q.g;
         if (sg >= q.super_groups) return false;
         j0 = sg * q.g * PPW + jr;
         return a.n_begin + (unsigned int) j0 * g.P + (unsigned int)(st * 32) < a.n_end;
@@ -819,13 +844,283 @@ void fir_i8_dma_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Tiles of 64 slots.  The LDS pipe is what bounds the kernel above (profiles/r3_ablation_i8_dma.txt): a 32 x 32 register tile reads
+// 8 KB of operands per 9.5 products, and every workgroup tile of 32 slots stages its own 16 KB of X digits per chunk.  Here a
+// matrix wave holds TWO 32-row tiles on one K origin — 64 consecutive slots x 32 columns, 2 x 5 x 16 accumulators — so a B read
+// feeds two product chains (12 KB per 19 products) and a workgroup's X digits serve 64 slots (24 KB staged per 76 products instead
+// of 40).  256 registers per wave leave room for two waves per SIMD: a workgroup is FOUR waves, two workgroups per CU, and there
+// are no staging waves — with LDS-DMA staging is a handful of issue slots, so every wave issues its share of the next-but-one
+// chunk (6 buffer_load ... lds: two 1 KB pieces of the rows, one of each X plane) right after the chunk's barrier and counts its
+// own landings.  One barrier per chunk: at it every wave has its part of chunk c in the LDS and has finished reading chunk c - 1,
+// whose buffer the DMA issued behind the barrier overwrites.  The tile's 32 stores per lane sit on the same VM counter as the
+// DMAs, in issue order: for the two chunks after an epilogue the counted wait allows for them.
+// Periods are taken several at a time where that fills 64-row tiles (fir_common.hip.h: 160 outputs per period -> 320).
+// A launch the digits cannot hold is produced by fir_i8_standby_kernel, launched behind this one (this kernel's workgroups of
+// four waves cannot run the f32 streaming kernel's eight-wave tile loop).
+// ---------------------------------------------------------------------------------------------------
+template <int CG, bool PASS>
+__global__ __launch_bounds__ (MF_THREADS) __attribute__ ((amdgpu_waves_per_eu (2, 2)))
+void fir_i8_wide_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
+{
+    static_assert (CG >= 4 && I8_COLS % CG == 0, "16-byte vectors of 4 channels");
+    constexpr int THREADS = MF_THREADS;
+    constexpr int PPW = I8_COLS / CG;
+    constexpr int NBUF = 3, A_BUF = 8192, B_BUF = 16384, A_ALL = NBUF * A_BUF;
+    // (ONE __shared__ object: with a second one the compiler waits vmcnt(0) before the first LDS read behind a DMA)
+    __shared__ __attribute__ ((aligned (16))) unsigned char smem_ [NBUF * (A_BUF + B_BUF)];
+    unsigned char *const As_ = smem_, *const Bs_ = smem_ + A_ALL;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane (tid >> 6);       // (uniform, and known to be: LDS-DMA destinations are scalars)
+
+    const unsigned int stream_blocks = 8u * (unsigned int) wgs_per_xcd;
+    if (blockIdx.x >= stream_blocks) {                        // extra workgroups: the history roll (as in fir_mfma_kernel)
+        if (a.roll_dst) {
+            const int e = (int)(blockIdx.x - stream_blocks) * THREADS + tid;
+            if (e < a.H * a.C) {
+                const int f = e / a.C, c = e - f * a.C, lin = a.roll_appended + f;
+                float v = 0.0f;
+                if (lin < a.H) v = a.hist [(size_t) lin * a.C + c];
+                else if (a.in && lin - a.H < a.in_frames) v = a.in [(size_t)(lin - a.H) * a.C + c];
+                a.roll_dst [e] = v;
+            }
+        }
+        return;
+    }
+    if (*q.flag == q.epoch) return;                           // (samples the digits cannot hold: fir_i8_standby_kernel's launch)
+
+    const int xcd = blockIdx.x & 7, rank = blockIdx.x >> 3;
+    const int tiles_per_xcd = q.sg_per_xcd * q.g * q.tiles;
+    const int nchunks = q.ktot / I8_KC;
+
+    // tile `within` of this XCD's list -> (tile of 64 slots, first period); false if the tile holds no output of the launch
+    auto tile_at = [&] (int within, int &st, int &j0) -> bool {
+        st = within % q.tiles;
+        const int t2 = within / q.tiles, jr = t2 % q.g, sg = xcd * q.sg_per_xcd + t2 / q.g;
+        if (sg >= q.super_groups) return false;
+        j0 = sg * q.g * PPW + jr;
+        return a.n_begin + (unsigned int) j0 * g.P + (unsigned int)(st * 64) < a.n_end;
+    };
+    int my_tiles = 0;
+    { int st, j0; for (int w = rank; w < tiles_per_xcd; w += wgs_per_xcd) my_tiles += tile_at (w, st, j0) ? 1 : 0; }
+    if (my_tiles == 0) return;
+    const int total = my_tiles * nchunks;                     // chunks of this workgroup's stream
+
+    // ---- this wave's share of the staging: rows, pieces 2 wave and 2 wave + 1 of the chunk's 8 KB (one address, the second piece
+    // 1 KB on in memory and in the LDS alike: the instruction's own offset); X, 4-tap blocks 2 wave and 2 wave + 1 of every plane
+    // (64 lanes = 2 blocks x 32 column quads = 1 KB, lane-linear in the LDS).  The stream's tile has one resource for its rows and
+    // one for its X planes; a chunk is an offset added to the lanes' addresses.
+    constexpr int VPF = CG / 4;                               // 16-byte vectors per 4-frame block of the stream
+    constexpr unsigned int A_STEP = 8192u, B_STEP = (I8_KC / 4) * CG * 4u;
+    const int kb = 2 * wave + (lane >> 5), colquad = lane & 31, m = colquad / VPF, cv = colquad - m * VPF;
+    const unsigned int boff = (unsigned int)((m * q.gq4 + kb) * CG + cv * 4) * 4u;           // (the tile's first block sits in the resource base)
+    const unsigned int a_off = (unsigned int)(wave * 2048 + lane * 16);
+    // a column whose period lies d exponent blocks behind the tile's first column stages from that block's own planes: d regions
+    // further on, where the same 4-frame block sits d * eb_step blocks earlier
+    const unsigned int x_total = 4u * q.eb_plane_bytes;
+    const unsigned int eb_hop = x_total - (unsigned int) q.eb_step * (unsigned int)(CG * 4);
+    const int plane_step = __builtin_amdgcn_readfirstlane ((int) q.eb_plane_bytes);
+    // (the tile table through the scalar cache: a vector load here would sit on the VM counter among the DMAs)
+    const __attribute__ ((address_space (4))) int *tile_w0 = (const __attribute__ ((address_space (4))) int *) g.tile_w0;
+
+    int f_within = rank - wgs_per_xcd, f_chunk = 0;
+    __amdgpu_buffer_rsrc_t f_ra = make_rsrc (nullptr, 0u), f_rb = f_ra;
+    unsigned int f_va = 0u, f_vb = 0u;                        // the lanes' offsets of the stream's next chunk
+    auto open_tile = [&] () {                                 // next tile of this workgroup's list that holds outputs (there is one)
+        int st = 0, j0 = 0;
+        for (f_within += wgs_per_xcd; f_within < tiles_per_xcd; f_within += wgs_per_xcd)
+            if (tile_at (f_within, st, j0)) break;
+        const int la = max (tile_w0 [3 * (2 * st)] + j0 * g.Q + I8_PADF, 0);     // (the origin of the pair's first 32-row slot tile)
+        const int eb = j0 / q.eb_periods;
+        unsigned int skip = (unsigned int) max ((la >> 2) - q.b0 - eb * q.eb_step, 0) * (unsigned int)(CG * 4);
+        if (skip > q.eb_plane_bytes) skip = q.eb_plane_bytes;
+        const size_t from = (size_t) eb * x_total + skip;
+        f_rb = make_rsrc (q.x_planes + from, (unsigned int) min (q.x_bytes - from, (size_t) 0xfffffff0u));
+        const unsigned int fa_bytes = (unsigned int) nchunks * A_STEP;
+        f_ra = make_rsrc (q.a_planes + (size_t)(st * q.g + j0 % q.g) * fa_bytes, fa_bytes);
+        f_va = a_off;
+        f_vb = boff + (unsigned int)((j0 + m * q.g) / q.eb_periods - eb) * eb_hop;
+        f_chunk = 0;
+    };
+    // the stream's next chunk -> LDS buffer `buf`: 6 DMA instructions of this wave
+    auto issue = [&] (int buf) {
+        const lds_ptr_t la_ = (lds_ptr_t)(As_ + buf * A_BUF + wave * 2048);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds (f_ra, la_, 16, (int) f_va, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds (f_ra, la_, 16, (int) f_va, 0, 1024, 0);
+#pragma unroll
+        for (int pn = 0; pn < 4; ++pn)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds (f_rb, (lds_ptr_t)(Bs_ + buf * B_BUF + pn * 4096 + wave * 1024), 16, (int) f_vb, pn * plane_step, 0, 0);
+        f_va += A_STEP; f_vb += B_STEP;
+    };
+
+    {   // the two workgroups of a CU share each SIMD's matrix pipe: left alone their waves fall into step (both multiply, then both
+        // wait for the LDS and the barrier); different issue priorities make them alternate instead
+        const unsigned int hw_id = __builtin_amdgcn_s_getreg ((4 - 1) << 11 | 16 << 6 | 4);      // HW_ID.TG_ID: bits 19:16
+        if (hw_id & 1u) __builtin_amdgcn_s_setprio (3); else __builtin_amdgcn_s_setprio (0);
+    }
+    const int col = wave * 32 + (lane & 31);
+    const int jl = col / CG, c = col - jl * CG;
+    // A image of a chunk [plane][16-tap half][row 0..63][16 taps]; B image [plane][4-tap block][column][4 taps]
+    const unsigned char *Ab0 = As_ + (lane >> 5) * 1024 + (lane & 31) * 16;
+    const unsigned char *Bb0 = Bs_ + (lane >> 5) * 2048 + col * 4;
+    // output offset of this lane inside a tile: (period jl * g, slot 4 * (lane >> 5), channel c); the row's own 0..3 / +8 / +16 / +24
+    // (+ 32 for the second register tile) slots are immediates of the store
+    const unsigned int out_off = (unsigned int)((jl * q.g * g.P + 4 * (lane >> 5)) * CG + c) * 4u;
+
+    // ---- the stream: chunk s is staged into LDS buffer s % 3 two iterations before it is multiplied
+    open_tile ();
+    int issued = 0;                                           // chunks handed to the DMA so far
+    auto issue_next = [&] (int buf) {
+        if (issued < total) {
+            if (f_chunk == nchunks) open_tile ();
+            issue (buf);
+            ++f_chunk; ++issued;
+        }
+    };
+    issue_next (0);
+    issue_next (1);
+    int fill = 2, qb = 0;                                     // LDS buffers of the chunk two ahead and of the current chunk
+    int since_stores = 2;                                     // chunks since a tile's stores were issued (2: none in flight)
+    int done = 0;                                             // chunks multiplied so far
+
+    for (int within = rank; within < tiles_per_xcd; within += wgs_per_xcd) {
+        int st, j0;
+        if (!tile_at (within, st, j0)) continue;
+        // rows carry 30 fraction bits, this lane's channel 2^shift in its period's exponent block; the class sums are combined at
+        // weight 256^(4 - s) in units of 2^16: the result is scaled by 2^(-14 - shift).  (The load is issued by hand behind the
+        // first chunk's barrier, older than the DMAs issued after it: it has landed by the second chunk's counted wait, and the
+        // compiler, which does not see it, drains nothing for it)
+        const int *shift_at = q.shifts + ((j0 + jl * q.g) / q.eb_periods) * CG + c;
+        int shift_v = 0;
+        i32x16 acc [2] [5];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int s = 0; s < 5; ++s)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc [h] [s] [r] = 0;
+        // chunks in which some row of a register tile has a non-zero most significant digit (the few around the rows' centres:
+        // taps fall off as 1 / distance): everywhere else the four products with that digit plane are exactly zero and not issued
+        // (through the scalar cache, like the tile table: an ordinary vector load would make the compiler drain the VM counter —
+        // DMAs and all — before its first use)
+        unsigned long long top [2];
+        {
+            const __attribute__ ((address_space (4))) unsigned long long *tm = (const __attribute__ ((address_space (4))) unsigned long long *) q.tile_masks + (st * q.g + j0 % q.g) * 2;
+            top [0] = tm [0]; top [1] = tm [1];
+        }
+
+        for (int ch = 0; ch < nchunks; ++ch, ++done) {
+            // this wave's part of the current chunk has landed once nothing older than the next chunk's 6 DMAs (and a just finished
+            // tile's 32 stores) is outstanding
+            if (done + 1 >= issued) asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (since_stores < 2) asm volatile ("s_waitcnt vmcnt(38)" ::: "memory");
+            else asm volatile ("s_waitcnt vmcnt(6)" ::: "memory");
+            __builtin_amdgcn_s_barrier ();                    // every wave's part has; and every wave has read the chunk before
+            asm volatile ("" ::: "memory");
+            if (ch == 0) asm volatile ("global_load_dword %0, %1, off" : "=v" (shift_v) : "v" (shift_at) : "memory");
+            issue_next (fill);                                // the chunk two ahead -> the buffer the chunk before this one has left
+            fill = fill == NBUF - 1 ? 0 : fill + 1;
+            since_stores = since_stores < 2 ? since_stores + 1 : 2;
+
+            const unsigned char *Ab = Ab0 + qb * A_BUF, *Bb = Bb0 + qb * B_BUF;
+            qb = qb == NBUF - 1 ? 0 : qb + 1;
+            i32x4 av [2] [4], bv [4];
+#pragma unroll
+            for (int pn = 0; pn < 4; ++pn) {
+                av [0] [pn] = *reinterpret_cast<const i32x4 *> (Ab + pn * 2048);
+                av [1] [pn] = *reinterpret_cast<const i32x4 *> (Ab + pn * 2048 + 512);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bv [pn] [i] = *reinterpret_cast<const int *> (Bb + pn * 4096 + i * 512);
+            }
+            __builtin_amdgcn_sched_group_barrier (0x100, 16, 0);
+            asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int i = 1; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (i + j <= 4) acc [h] [i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8 (av [h] [i], bv [j], acc [h] [i + j], 0, 0, 0);
+                if ((top [h] >> ch) & 1ull) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc [h] [j] = __builtin_amdgcn_mfma_i32_32x32x32_i8 (av [h] [0], bv [j], acc [h] [j], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- the tile's outputs: C/D layout of 32x32: row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31
+        const unsigned int n_tile = a.n_begin + (unsigned int) j0 * g.P + (unsigned int)(st * 64);
+        const int rows_valid = min (64, g.P - st * 64);
+        const size_t left = (size_t)(a.n_end - n_tile) * CG * 4;
+        const __amdgpu_buffer_rsrc_t rs_out = make_rsrc (a.out + (size_t) n_tile * CG, left > 0xffffff00ull ? 0xffffff00u : (unsigned int) left);
+        const int out_exp = -14 - shift_v;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const unsigned int pass_rows = PASS && 2 * st + h < g.slot_tiles ? (unsigned int) tile_w0 [3 * (2 * st + h) + 1] : 0u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i_const = h * 32 + (r & 3) + 8 * (r >> 2);      // compile-time part of the slot
+                double v = (double) acc [h] [0] [r];
+#pragma unroll
+                for (int s = 1; s < 5; ++s) v = v * 256.0 + (double) acc [h] [s] [r];
+                float y = (float) __builtin_ldexp (v, out_exp);
+                const int i = i_const + 4 * (lane >> 5);
+                if constexpr (PASS) {
+                    if ((pass_rows >> (i & 31)) & 1u)
+                        y = load_frame (a, INT_MIN, g.canon_ip [st * 64 + i] + g.canon_fi [st * 64 + i] / a.F + (j0 + jl * q.g) * g.Q, c);
+                }
+                // (always 32 store instructions per tile — the counted waits rely on it: a slot past the period goes out of the
+                // resource's range, as frames at or past n_end do, and is dropped)
+                const unsigned int off = i < rows_valid ? out_off + (unsigned int)(i_const * CG) * 4u : 0xfffffff0u;
+                __builtin_amdgcn_raw_buffer_store_b32 (__float_as_uint (y), rs_out, (int) off, 0, 0);
+            }
+        }
+        since_stores = 0;
+    }
+    asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// The stand-by of fir_i8_wide_kernel, launched behind it: a launch whose samples the digits cannot hold (flag raised by the staging
+// pass) is produced in f32 by the streaming kernel's own tile loop, from the tables the staging pass has left for it — the bits
+// of fir_mfma_stream_kernel.  Every other launch: the workgroups read the flag and leave.
+template <int CG, bool PASS>
+__global__ __launch_bounds__ (2 * MF_THREADS)
+void fir_i8_standby_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
+{
+    if (*q.flag != q.epoch) return;
+    __shared__ __attribute__ ((aligned (16))) float As_ [2] [32 * MF_LD];
+    __shared__ __attribute__ ((aligned (16))) float Bs_ [2] [MF_COLS * MF_LD];
+    stand_by_tiles<CG, PASS> (a, g, wgs_per_xcd, As_, Bs_);
+}
+
 } // namespace
+
+// 64-slot tiles (fir_i8_wide_kernel) for streams whose 4-frame blocks are whole 16-byte vectors: ARTAMD_I8_WIDE=1.  Off by default:
+// the kernel is correct (the same bits as the 32-slot kernels: exact integer sums) and moves 40 % fewer bytes into the LDS per
+// product, but measures the same 97 us on the headline launch (profiles/r3_wide_tiles_experiment.txt) and costs a launch more.
+bool artfir_i8_wide_enabled ()
+{
+    static const bool on = [] { const char *e = getenv ("ARTAMD_I8_WIDE"); const char *d = getenv ("ARTAMD_I8_DMA"); return e && *e == '1' && !(d && *d == '0'); } ();
+    return on;
+}
+static bool i8_wide_tiles (int cgt) { return artfir_i8_wide_enabled () && cgt >= 4; }
 
 // The planes buffer of a launch: [header: flag (art_internal.h)][row masks][exponents][A digit planes][X digit planes per exponent block];
 // returns its size, 0 if the launch is not for this path
 static size_t i8_layout (const ArtFirArgs *a, const MfmaGeom &g, int cgt, I8Geom &q, char *base, unsigned int outputs = 0)
 {
     if (!cgt || g.tile_rows != 32 || (g.ktot % I8_KC)) return 0;
+    q.tr = i8_wide_tiles (cgt) ? 64 : 32;
+    for (;;) {  // (as matrix_geometry's ktot, for tiles of tr rows; + 3: a tile's K columns start on a 4-frame block, up to 3 frames early)
+        const int shift_max = (int)((q.tr - 1.0) * g.Q / g.P) + 2;
+        q.ktot = ((a->T + shift_max + 3 + I8_KC - 1) / I8_KC) * I8_KC;
+        // (the 64-slot kernel's counted waits want three chunks per tile; and one mask bit per chunk)
+        if (q.tr == 64 && (q.ktot / I8_KC < 3 || q.ktot / I8_KC > 64)) { q.tr = 32; continue; }
+        break;
+    }
+    q.tiles = (g.P + q.tr - 1) / q.tr;
     const int ppw = I8_COLS / cgt > I8_MAX_PPW ? I8_MAX_PPW : I8_COLS / cgt;
     q.g = (g.Q % 4 == 0) ? 1 : (g.Q % 2 == 0) ? 2 : 4;
     q.gq4 = q.g * g.Q / 4;
@@ -833,7 +1128,7 @@ static size_t i8_layout (const ArtFirArgs *a, const MfmaGeom &g, int cgt, I8Geom
     const unsigned int total = outputs ? outputs + (unsigned int) g.P : a->n_end - a->n_begin, periods = (total + g.P - 1) / g.P;
     q.super_groups = (int)((periods + (unsigned int)(q.g * ppw) - 1) / (unsigned int)(q.g * ppw));
     q.sg_per_xcd = (q.super_groups + 7) / 8;
-    if (g.ktot / I8_KC > 64) return 0;                                  // (one mask bit per chunk)
+    if (q.ktot / I8_KC > 64) return 0;                                  // (one mask bit per chunk)
     // Exponent blocks: eb_periods periods each — a multiple of g (block starts stay on 4-frame blocks) chosen from the ratio alone
     // so that a block spans ~9,400 input frames (one 8-channel tile's periods at 44.1k -> 48k), whatever the channel count.  A
     // block's planes hold every frame its periods read: their input span, + the span of one period's slot tiles (< Q + 2 frames),
@@ -845,7 +1140,7 @@ static size_t i8_layout (const ArtFirArgs *a, const MfmaGeom &g, int cgt, I8Geom
         q.eb_periods = 16 * q.g * (k > 1 ? k : 1);
     }
     q.eb_step = q.eb_periods * g.Q / 4;                                 // (g * Q is a multiple of 4)
-    const int over_blocks = (g.Q + 2 + g.ktot + 3 + 3) / 4 + 2;
+    const int over_blocks = (g.Q + 2 + q.ktot + 3 + 3) / 4 + 2;
     q.eb_blocks = q.eb_step + over_blocks;
     q.ebs = (int)((periods + (unsigned int) q.eb_periods - 1) / (unsigned int) q.eb_periods);
     // Staging workgroups: a block's region is cut into slices of consecutive 4-frame blocks, 32-byte runs per frame (8 channels
@@ -860,12 +1155,13 @@ static size_t i8_layout (const ArtFirArgs *a, const MfmaGeom &g, int cgt, I8Geom
     q.eb_plane_bytes = (unsigned int) q.eb_blocks * (unsigned int) a->C * 4u;
     q.x_bytes = (size_t) q.ebs * 4 * q.eb_plane_bytes;
     q.b0 = 0;
-    const size_t a_bytes = (size_t) g.slot_tiles * q.g * (g.ktot / I8_KC) * 4096;
-    const size_t masks = (size_t) g.slot_tiles * q.g * 32 * 8, shifts = (size_t) q.ebs * a->C * 4;
+    const size_t a_bytes = (size_t) q.tiles * q.g * (q.ktot / I8_KC) * (size_t)(q.tr * 128);
+    const size_t masks = (size_t) q.tiles * q.g * q.tr * 8 + (size_t) q.tiles * q.g * (q.tr / 32) * 8, shifts = (size_t) q.ebs * a->C * 4;
     const size_t teams = (size_t) q.ebs * q.slices * a->C * 4;
     const size_t head = (ART_I8_HEAD_BYTES + masks + teams + shifts + 255) & ~(size_t) 255;
     q.flag = (int *) base; q.epoch = 0;
     q.a_masks = (unsigned long long *)(base + ART_I8_HEAD_BYTES);
+    q.tile_masks = q.a_masks + (size_t) q.tiles * q.g * q.tr;
     q.peaks = (unsigned int *)(base + ART_I8_HEAD_BYTES + masks);
     q.shifts = (int *)(base + ART_I8_HEAD_BYTES + masks + teams);
     q.a_planes = (unsigned char *) base + head;
@@ -889,7 +1185,7 @@ int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGe
     int ep = ++launches;
     if (ep <= 0) { launches = 1; ep = 1; }                             // (the flag word is zero when the buffer is allocated)
     q.epoch = ep;
-    if (a->fixed_out) { a->fixed_out [0] = ep; a->fixed_out [1] = g.slot_tiles * q.g * 32; a->fixed_out [2] = g.ktot / I8_KC; }
+    if (a->fixed_out) { a->fixed_out [0] = ep; a->fixed_out [1] = q.tiles * q.g * q.tr; a->fixed_out [2] = q.ktot / I8_KC; }
 
     {   // block of the launch's first window start: the reference's position arithmetic for output n_begin (as locate ())
         int e = 0;
@@ -901,7 +1197,7 @@ int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGe
         q.b0 = (la > 0 ? la : 0) >> 2;
     }
     const unsigned int x_wgs = (unsigned int)(q.ebs * (a->C / q.cgrp) * q.slices);
-    const dim3 pgrid (x_wgs + (unsigned int)(g.slot_tiles * q.g) * 32u), xgrid (x_wgs);
+    const dim3 pgrid (x_wgs + (unsigned int) g.slot_tiles * 32u + (unsigned int)(q.tiles * q.g * q.tr)), xgrid (x_wgs + (unsigned int)((q.tiles * q.g * (q.tr / 32) + I8_STAGE_THREADS - 1) / I8_STAGE_THREADS));
     if (a->interpolate) {
         hipLaunchKernelGGL ((i8_stage_kernel<true, true>), pgrid, dim3 (I8_STAGE_THREADS), 0, st, *a, *segs, g, q);
         hipLaunchKernelGGL ((i8_stage_kernel<true, false>), xgrid, dim3 (I8_STAGE_THREADS), 0, st, *a, *segs, g, q);
@@ -912,8 +1208,8 @@ int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGe
     }
     if (a->ev_start) arthip_event_record (a->ev_start, (void *) st);
 
-    const int tiles_per_xcd = q.sg_per_xcd * q.g * g.slot_tiles;
-    // As many workgroups as the XCD holds (32 CUs x 2: 60 KB of LDS, 128 registers each) less two slots for the history-roll
+    const int tiles_per_xcd = q.sg_per_xcd * q.g * q.tiles;
+    // As many workgroups as the XCD holds (32 CUs x 2: 60 / 72 KB of LDS, 128 / 256 registers each) less two slots for the history-roll
     // workgroups of the same grid, each striding the XCD's tile list; the last, partly filled round then runs with one
     // workgroup per CU and its tiles finish sooner.  (Equal shares — 56 workgroups x 5 tiles for the headline's 280 — kept 8
     // slots idle for the whole launch: 0.1078 ms, 64 workgroups 0.1039, 62 0.1029; 4 and 32 channels, 256k..1M frames,
@@ -921,8 +1217,24 @@ int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGe
     const int resident = 62;
     int wgs_per_xcd = tiles_per_xcd < resident ? tiles_per_xcd : resident;
     { static const int k_env = [] { const char *e = getenv ("ARTAMD_I8_WGS"); return e && *e ? atoi (e) : 0; } (); if (k_env > 0 && k_env < tiles_per_xcd) wgs_per_xcd = k_env; }
-    const dim3 sgrid ((unsigned int)(8 * wgs_per_xcd) + roll_blocks);
     const bool pass = !a->interpolate && !a->lowpass;
+    if (q.tr == 64) {
+        // 64-slot tiles: four-wave workgroups (the roll's extra workgroups counted for 256 threads), and the stand-by as a launch of
+        // its own behind the kernel — one workgroup per CU, which reads the flag and leaves
+        const unsigned int roll256 = a->roll_dst ? (unsigned int)((a->H * a->C + MF_THREADS - 1) / MF_THREADS) : 0u;
+        const dim3 wgrid ((unsigned int)(8 * wgs_per_xcd) + roll256);
+        const int sb_tiles = g.groups_per_xcd * g.slot_tiles, sb_wgs = sb_tiles < 32 ? sb_tiles : 32;
+        const dim3 sbgrid ((unsigned int)(8 * sb_wgs));
+#define I8_WIDE(CGT) do { if (pass) { hipLaunchKernelGGL ((fir_i8_wide_kernel<CGT, true>), wgrid, dim3 (MF_THREADS), 0, st, *a, g, q, wgs_per_xcd); \
+                                      hipLaunchKernelGGL ((fir_i8_standby_kernel<CGT, true>), sbgrid, dim3 (2 * MF_THREADS), 0, st, *a, g, q, sb_wgs); } \
+                          else { hipLaunchKernelGGL ((fir_i8_wide_kernel<CGT, false>), wgrid, dim3 (MF_THREADS), 0, st, *a, g, q, wgs_per_xcd); \
+                                 hipLaunchKernelGGL ((fir_i8_standby_kernel<CGT, false>), sbgrid, dim3 (2 * MF_THREADS), 0, st, *a, g, q, sb_wgs); } } while (0)
+        switch (cgt) { case 32: I8_WIDE (32); break; case 16: I8_WIDE (16); break; case 8: I8_WIDE (8); break; default: I8_WIDE (4); }
+#undef I8_WIDE
+        if (a->ev_stop) arthip_event_record (a->ev_stop, (void *) st);
+        return 1;
+    }
+    const dim3 sgrid ((unsigned int)(8 * wgs_per_xcd) + roll_blocks);
 #define I8_GO(CGT) do { if (pass) hipLaunchKernelGGL ((fir_i8_stream_kernel<CGT, true>), sgrid, dim3 (2 * MF_THREADS), 0, st, *a, g, q, wgs_per_xcd); \
                         else hipLaunchKernelGGL ((fir_i8_stream_kernel<CGT, false>), sgrid, dim3 (2 * MF_THREADS), 0, st, *a, g, q, wgs_per_xcd); } while (0)
 #define I8_DMA(CGT) do { if (pass) hipLaunchKernelGGL ((fir_i8_dma_kernel<CGT, true>), sgrid, dim3 (2 * MF_THREADS), 0, st, *a, g, q, wgs_per_xcd); \
