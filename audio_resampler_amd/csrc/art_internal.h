@@ -58,6 +58,9 @@ typedef struct {
     int mode;                            /* ART_MODE_* */
     double ratio;
     unsigned int n_begin, n_end;         /* call-relative output frames to produce */
+    int segs_truncated;                  /* the launch reaches beyond the segments of its table (a call of more than ART_MAX_SEGS ring epochs
+                                          * handed over whole, arthip_fir_spans_segments): only a kernel that follows the lattice from the
+                                          * launch's first period may run it — arthip_fir returns -2, nothing enqueued, otherwise */
     /* periodic-phase structure for the MFMA kernel (0 = none): out frame n+period_out sits exactly
      * period_in input frames after out frame n */
     int period_out, period_in;
@@ -125,6 +128,10 @@ size_t arthip_fir_planes_bytes (const ArtFirArgs *a, unsigned int outputs, int k
 size_t arthip_fir_batch_item_bytes (void);
 int arthip_fir_batch_max_segments (void);                /* ring-epoch segments a batched call may have */
 int arthip_fir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref);   /* what arthip_fir would do */
+/* May a call of more segments than a table holds be ONE launch (n_begin .. n_end = the whole call, segs = its first ART_MAX_SEGS
+ * segments)?  Yes where the launch runs on a streaming matrix-core kernel: those take their positions from the lattice of the
+ * launch's first period, not from the table (short filters: a ring epoch is a few hundred frames, a 1M-frame call eight tables) */
+int arthip_fir_spans_segments (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref);
 int arthip_fir_batch (const ArtFirArgs *a, const ArtSegTable *segs, int n, void *d_table, void *stream);
 /* new_hist[H][C] = last H frames of (hist ++ in[0..appended)); in may be NULL => zeros appended */
 int arthip_roll_history (art_s *new_hist, const art_s *hist, const art_s *in, long in_pitch, int appended, int H, int C, void *stream);

@@ -5,6 +5,8 @@ extern "C" {
 
 int arthip_fir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref) { return artfir_takes_matrix_path (a, segs, kernel_pref) ? 1 : 0; }
 
+int arthip_fir_spans_segments (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref) { return artfir_matrix_spans_segments (a, segs, kernel_pref) ? 1 : 0; }
+
 size_t arthip_fir_planes_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref) { return artfir_planes_bytes (a, outputs, kernel_pref); }
 
 int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, void *stream)
@@ -12,6 +14,8 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
     hipStream_t st = (hipStream_t) stream;
 
     if (a->n_end <= a->n_begin) return ART_KERNEL_GENERAL;
+
+    if (a->segs_truncated && ((a->mode & 3) == ART_MODE_STRICT || !artfir_matrix_spans_segments (a, segs, kernel_pref))) return -2;
 
     if ((a->mode & 3) == ART_MODE_STRICT) {
         artfir_strict (*a, *segs, (a->mode & 4) != 0, st);
@@ -23,6 +27,7 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
     // the general kernel (fir_matrix.hip / fir_matrix64.hip)
     const int matrix = artfir_matrix (a, segs, kernel_pref, stream);
     if (matrix) return matrix;
+    if (a->segs_truncated) return -2;                        // (nothing enqueued: the matrix path declines before its first launch)
 
     if (a->ev_start) arthip_event_record (a->ev_start, stream);
     if (artfir_general (*a, *segs, st)) {

@@ -612,6 +612,14 @@ static int matrix_geometry (const ArtFirArgs *a, MfmaGeom &g)
     return cgt;
 }
 
+// see arthip_fir_spans_segments (art_internal.h): the launch would run on a streaming kernel (the conditions of `regular` below)
+bool artfir_matrix_spans_segments (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref)
+{
+    if (kernel_pref == 5 || !artfir_takes_matrix_path (a, segs, kernel_pref)) return false;
+    MfmaGeom g;
+    return matrix_geometry (a, g) != 0 && (size_t) a->n_end * a->C * 4 < 0xffff0000ull && mfma_launch_is_regular (a, segs);
+}
+
 // bytes of digit planes the fixed-point kernel wants for a call of this shape (the host sizes a->planes with it before the launch)
 size_t artfir_planes_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref)
 {
@@ -673,6 +681,7 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
         dim3 grid ((unsigned int)(8 * g.groups_per_xcd * g.slot_tiles) + roll_blocks, (unsigned int)((a->C + g.cg - 1) / g.cg));
 
         const bool regular = ws && !wide && kernel_pref != 5 && (size_t) a->n_end * a->C * 4 < 0xffff0000ull && mfma_launch_is_regular (a, segs);
+        if (a->segs_truncated && !regular) return 0;          // (the tile kernel replays positions from the table: not beyond it)
         // Fixed point on the integer matrix cores (fir_matrix_i8.hip) where the launch has its digit planes: staging pass + main
         // kernel, which carries the f32 tile loop as its own stand-by (a sample the digits cannot hold is only found on the
         // device) and takes the history roll along.  kernel_pref 6 pins the f32 kernel.

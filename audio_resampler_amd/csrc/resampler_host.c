@@ -1190,12 +1190,27 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
             a.fixed_out = hip->last_fixed;
         }
 
+        /* A call of more ring epochs than a table holds (short filters: an epoch is a few hundred frames) is cut into launches of
+         * ART_MAX_SEGS segments — unless it runs on a streaming matrix-core kernel, which follows the lattice from its first period
+         * and needs the table for that period only: then the whole call is ONE launch with the first table (asked first; a launch
+         * that declines after all enqueues nothing and the cut launches follow) */
+        int whole = 0;
+        if (matrix_sized && nseg > ART_MAX_SEGS) {
+            ArtSegTable tab;
+            tab.count = ART_MAX_SEGS; tab.lin_floor = lin_floor;
+            for (int s = 0; s < ART_MAX_SEGS; ++s) {
+                tab.first [s] = hip->segs [s].first_output; tab.lin_base [s] = hip->segs [s].lin_base; tab.base [s] = hip->segs [s].base_offset;
+            }
+            a.n_begin = hip->segs [0].first_output; a.n_end = res.output_generated;
+            whole = arthip_fir_spans_segments (&a, &tab, hip->kernel_pref);
+        }
         for (int s0 = 0; s0 < nseg; s0 += ART_MAX_SEGS) {
-            const int s1 = s0 + ART_MAX_SEGS < nseg ? s0 + ART_MAX_SEGS : nseg;
+            const int s_tab = s0 + ART_MAX_SEGS < nseg ? s0 + ART_MAX_SEGS : nseg;     /* segments in this launch's table ... */
+            const int s1 = whole ? nseg : s_tab;                                       /* ... and those it produces */
             ArtSegTable tab;
 
-            tab.count = s1 - s0; tab.lin_floor = lin_floor;
-            for (int s = s0; s < s1; ++s) {
+            tab.count = s_tab - s0; tab.lin_floor = lin_floor;
+            for (int s = s0; s < s_tab; ++s) {
                 tab.first [s - s0] = hip->segs [s].first_output;
                 tab.lin_base [s - s0] = hip->segs [s].lin_base;
                 tab.base [s - s0] = hip->segs [s].base_offset;
@@ -1210,11 +1225,15 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
                 /* the last FIR launch of the call may take the history roll along (one launch less on the stream) */
                 a.roll_dst = (s1 == nseg && appended > 0) ? hip->d_hist [hip->cur ^ 1] : NULL;
                 a.roll_appended = appended;
+                a.segs_truncated = whole;
                 int k = arthip_fir (&a, &tab, hip->kernel_pref, hip->stream);
+                a.segs_truncated = 0;
+                if (k == -2 && whole) { whole = 0; s0 = -ART_MAX_SEGS; continue; }      /* (declined: nothing enqueued — again, cut) */
                 if (k >= 0 && (k & ART_FIR_ROLLED)) { rolled = 1; k &= ~ART_FIR_ROLLED; }
                 if (k < 0) { fprintf (stderr, "artamd: FIR launch failed: %s\n", arthip_last_error ()); res.input_used = res.output_generated = 0; return res; }
                 hip->last_kernel = k;
             }
+            if (whole) break;
         }
     }
 

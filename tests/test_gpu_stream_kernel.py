@@ -25,7 +25,7 @@ CASES = [
     (8, 988, 988, 96000, 44100, True, BH | INTERP | LOWPASS, (140000, 140000)),       # config C's resampler: 147 x 988 nearest filter
     (2, 380, 320, 44100, 48000, False, BH, (120000, 120000)),                         # nearest filter, no low-pass: pass-through samples (F = 2P)
     (2, 380, 32, 44100, 48000, False, BH, (120000, 120000)),                          # nearest filter, F < P: five pass-through slots per period, two of them in one tile
-    (2, 64, 160, 48000, 44100, False, BH, (250000,)),                                 # short filter, 3 chunks, P = 147
+    (2, 64, 160, 48000, 44100, False, BH, (150000, 100000)),                          # short filter, 3 chunks, P = 147 (calls of fewer ring epochs than a launch's table holds: both kernels cut the same launches)
     (8, 988, 988, 44100, 48000, False, BH | INTERP, (2000, 3000, 500, 9000)),         # small calls: fewer tiles than workgroups
 ]
 
@@ -118,3 +118,28 @@ def test_irregular_launches_take_the_replaying_kernel_and_match_the_oracle():
         outs.append(y)
     d = np.abs(outs[0].astype(np.float64) - outs[1].astype(np.float64))
     assert np.all(d <= 2.0 * 2.0 ** -23 * np.maximum(1.0, np.abs(outs[1]))), d.max()
+
+
+@pytest.mark.parametrize("shape", [(1, 48, 48, BH | INTERP, 44100, 48000), (2, 48, 160, BH, 44100, 48000), (8, 156, 156, BH | INTERP, 48000, 32000), (4, 48, 48, BH | INTERP, 44100, 88200)],
+                         ids=["mono_t48", "stereo_t48_nearest_passthrough", "c8_t156_48to32", "c4_t48_2x"])
+def test_a_call_of_more_ring_epochs_than_a_table_holds_is_one_launch_with_the_same_bits(shape):
+    """short filters: a ring epoch is a few hundred input frames, a 1M-frame call many hundred segments, a launch's table 192 — a call
+    that runs on a streaming matrix-core kernel is handed over whole (the kernels follow the lattice from the launch's first
+    period); kernel preference 5, the one-tile-per-workgroup kernel, which replays positions from the table, keeps the cut
+    launches (each anchors its tiles at its own first output: other K origins, other float roundings — not the same bits): all
+    three against the oracle"""
+    ch, T, F, flags, src, dst = shape
+    frames = 700000
+    ratio = dst / src
+    x, _ = noise(frames * ch, state=0x5E65 | 1)
+    x = x.reshape(frames, ch)
+    outs = {}
+    for kernel in (6, 5, 7):
+        r = HipResampler(ch, T, F, 0.0, flags, kernel=kernel); r.advance(T / 2)
+        u, g, y = r.process(x, int(frames * ratio) + 4000, ratio)
+        assert u == frames and r.last_kernel() == 2
+        outs[kernel] = np.array(y).copy()
+    o = OracleResampler(ch, T, F, 0.0, flags | PRECISE); o.advance(T / 2)
+    uo, go, yo = o.process(x, int(frames * ratio) + 4000, ratio, threads=8)
+    for kernel in (6, 5, 7):
+        assert outs[kernel].shape == np.array(yo).shape and tolerance_ok(outs[kernel], np.array(yo))[0], kernel
