@@ -189,14 +189,17 @@ static int plan_call (ArtamdPosition *p, int nIn, int cap, double ratio, Resampl
         double limit = (double)(top - half);
         unsigned int lo = made, hi = ucap;
 
-        /* two bisection steps placed around the arithmetic estimate (any probe inside [lo, hi) is a valid step of the same
-         * monotone search, so the answer is unchanged): a 1M-frame call has 70-180 ring epochs, 21 steps each otherwise */
+        /* two bisection steps placed AT the arithmetic estimate (any probe inside [lo, hi) is a valid step of the same
+         * monotone search, so the answer is unchanged): the answer is the estimate rounded up unless the roundings of the
+         * reference's own expression disagree with it by one, so the two probes e, e + 1 normally close the interval — two
+         * divisions per ring epoch instead of 21 (a 1M-frame call has 70-180 epochs with long filters, 1,456 at 48 taps, where
+         * the planner, not the GPU, set the pace of a call) */
         {
             const double est = (limit - base) * ratio;
             if (est > 2.0 && est < 4.0e9) {
                 const unsigned int e = (unsigned int) est;
                 for (int probe = 0; probe < 2; ++probe) {
-                    const unsigned int mid = probe ? e + 2 : e - 2;
+                    const unsigned int mid = probe ? e + 1 : e;
                     if (mid >= lo && mid < hi) { if (base + (double) mid / ratio < limit) lo = mid + 1; else hi = mid; }
                 }
             }
