@@ -22,6 +22,7 @@ extern "C" {
  * [0] stand-down flag word.  The rows' mask words follow the header. */
 #define ART_I8_HEAD_BYTES 256
 
+#define ART_SPLIT_HEAD_BYTES 65536   /* arrival counters of the K-split kernel: 4 per tile, up to 4096 tiles */
 #define ART_MAX_SEGS 192         /* ring-epoch segments per kernel launch (passed by value: 16 B each, kernel arguments stay below 4 KB) */
 
 /* numeric modes of the FIR */
@@ -72,6 +73,9 @@ typedef struct {
     void *scratch; size_t scratch_bytes;
     /* device memory for the fixed-point matrix kernel's digit planes of one launch (arthip_fir_planes_bytes; NULL: f32 kernels) */
     void *planes; size_t planes_bytes;
+    /* device memory for the K-split streaming kernel of launches with few tiles (arthip_fir_split_bytes; NULL: unsplit): the first
+     * ART_SPLIT_HEAD_BYTES are arrival counters, zero whenever no launch is in flight (zeroed by the owner when allocated) */
+    void *split; size_t split_bytes;
     /* host, optional, 3 ints filled when the fixed-point kernel is enqueued: the launch's flag value (the first word of
      * `planes` equals it afterwards iff the kernel stood down), mask words behind the header (at planes + ART_I8_HEAD_BYTES),
      * chunks per tile */
@@ -123,6 +127,8 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
 /* bytes a->planes must hold for the fixed-point matrix kernel to run a call of this shape (C, T, H, in_frames, period) making
  * `outputs` frames; 0: the call is not for it (shape, size, kernel preference) */
 size_t arthip_fir_planes_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref);
+/* bytes a->split must hold for a call of this shape making `outputs` frames to run on the K-split kernel; 0: the call is not for it */
+size_t arthip_fir_split_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref);
 /* n independent general-kernel calls (default / precise mode) in one launch per kernel variant; d_table = device scratch of
  * n * arthip_fir_batch_item_bytes () bytes (reused call after call: stream order protects it); asynchronous like arthip_fir */
 size_t arthip_fir_batch_item_bytes (void);

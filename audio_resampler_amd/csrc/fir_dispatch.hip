@@ -7,6 +7,8 @@ int arthip_fir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, 
 
 int arthip_fir_spans_segments (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref) { return artfir_matrix_spans_segments (a, segs, kernel_pref) ? 1 : 0; }
 
+size_t arthip_fir_split_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref) { return artfir_split_bytes (a, outputs, kernel_pref); }
+
 size_t arthip_fir_planes_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref) { return artfir_planes_bytes (a, outputs, kernel_pref); }
 
 int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, void *stream)

@@ -526,6 +526,235 @@ void fir_mfma_stream_kernel (ArtFirArgs a, MfmaGeom g, int wgs_per_xcd)
     // (the tile loop, shared as text with the fixed-point kernel's stand-by)
 #include "fir_matrix_stream_body.inc"
 }
+
+// ---------------------------------------------------------------------------------------------------
+// The streaming kernel for launches of FEW tiles (calls of some ten thousand frames: fewer tiles than the chip has CUs).  One
+// workgroup per tile walks the whole K range at the pace ONE CU draws rows and samples through a cold L2 (~20 us for 32 chunks
+// whatever the call's size: profiles/r3_small_launch_experiment.txt).  Here a tile's K range is cut into KS parts, each a work item
+// of its own (the same staging, the same walk over its chunks, the same flush schedule inside them): KS times the workgroups,
+// each fetching a KS-th.  A part leaves its 32 x 128 fp64 partial sums in device memory; the part that finishes LAST — per matrix
+// wave: a wave's 32 columns are its own, so the four waves of a workgroup never wait for each other — adds the KS partials in
+// the order of the parts and writes the outputs: the result does not depend on which part came last.  All parts of a tile are
+// neighbours in one XCD's work list (one L2); partials and counters still go through agent-scope accesses (write-through
+// stores, L1-bypassing loads), so nothing rests on where a workgroup runs.
+// Not the bits of the unsplit kernel in general (the same flushed values, added in another association: a float in ~2^29 may
+// round the other way): the library's own choice only (kernel preference 0 / 2; 8 forces it), decided from the stream's size, never
+// with preference 5 / 6, whose bit-for-bit agreement the tests pin.
+// ---------------------------------------------------------------------------------------------------
+template <bool INTERP, int CG, bool PASS>
+__global__ __launch_bounds__ (2 * MF_THREADS) __attribute__ ((amdgpu_waves_per_eu (6)))
+void fir_mfma_split_kernel (ArtFirArgs a, MfmaGeom g, int wgs_per_xcd, int KS, double *partials, unsigned int *arrivals)
+{
+    constexpr int THREADS = 2 * MF_THREADS;
+    constexpr int PPW = MF_COLS / CG > MF_MAX_PPW ? MF_MAX_PPW : MF_COLS / CG;
+    constexpr int NCOLS = PPW * CG;
+    __shared__ __attribute__ ((aligned (16))) float As_ [2] [32 * MF_LD];
+    __shared__ __attribute__ ((aligned (16))) float Bs_ [2] [MF_COLS * MF_LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool loader = wave >= 4;
+    const int pt = tid & (MF_THREADS - 1);
+
+    const unsigned int stream_blocks = 8u * (unsigned int) wgs_per_xcd;
+    if (blockIdx.x >= stream_blocks) {                        // extra workgroups: the history roll (as in fir_mfma_kernel)
+        if (a.roll_dst) {
+            const int e = (int)(blockIdx.x - stream_blocks) * THREADS + tid;
+            if (e < a.H * a.C) {
+                const int f = e / a.C, c = e - f * a.C, lin = a.roll_appended + f;
+                float v = 0.0f;
+                if (lin < a.H) v = a.hist [(size_t) lin * a.C + c];
+                else if (a.in && lin - a.H < a.in_frames) v = a.in [(size_t)(lin - a.H) * a.C + c];
+                a.roll_dst [e] = v;
+            }
+        }
+        return;
+    }
+
+    const int xcd = blockIdx.x & 7, rank = blockIdx.x >> 3;
+    const int tiles_per_xcd = g.groups_per_xcd * g.slot_tiles;
+    const int items_per_xcd = tiles_per_xcd * KS;
+    const int nchunks = g.ktot / MF_KC;
+
+    // work item `within` of this XCD's list -> (slot tile, period group, part); false past the last valid tile (validity is monotone)
+    auto item_at = [&] (int within, int &st, int &jg, int &ks) -> bool {
+        if (within >= items_per_xcd) return false;
+        const int tile = within / KS;
+        ks = within - tile * KS;
+        st = tile % g.slot_tiles; jg = xcd * g.groups_per_xcd + tile / g.slot_tiles;
+        if (jg >= g.period_groups) return false;
+        return a.n_begin + (unsigned int)(jg * PPW) * g.P + (unsigned int)(st * 32) < a.n_end;
+    };
+    auto chunks_of = [&] (int ks, int &c0, int &c1) { c0 = ks * nchunks / KS; c1 = (ks + 1) * nchunks / KS; };
+
+    if (NCOLS < MF_COLS)                                      // unused columns stay zero for the whole kernel
+        for (int e = tid; e < (MF_COLS - NCOLS) * MF_LD; e += THREADS)
+            for (int b = 0; b < 2; ++b) Bs_ [b] [NCOLS * MF_LD + e] = 0.0f;
+
+    // chunks this workgroup will consume in total (both roles count the same way)
+    int total = 0;
+    { int st, jg, ks, c0, c1; for (int w = rank; item_at (w, st, jg, ks); w += wgs_per_xcd) { chunks_of (ks, c0, c1); total += c1 - c0; } }
+    if (total == 0) return;
+
+    if (loader) {
+        constexpr int VEC = CG >= 4 ? 4 : (CG == 2 ? 2 : 1);
+        constexpr int VPF = CG / VEC, VPP = MF_KC * VPF, NB = (PPW * VPP) / MF_THREADS;
+        constexpr unsigned int A_STEP = MF_KC * 4u, B_STEP = MF_KC * CG * 4u;
+        const int a_row = pt >> 3, a_kseg = (pt & 7) * 4;
+        const unsigned int a_off0 = (unsigned int)(a_row * g.ktot + a_kseg) * 4u;
+        const int adst = a_row * MF_LD + a_kseg;
+        unsigned int boff [NB]; int bdst [NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int v = pt + u * MF_THREADS;
+            const int jl = v / VPP, rem = v % VPP, kk = rem / VPF, cv = rem % VPF;
+            boff [u] = (unsigned int)((jl * g.Q + kk) * CG + cv * VEC) * 4u;       // (the tile's window origin sits in the resource base)
+            bdst [u] = (jl * CG + cv * VEC) * MF_LD + kk;
+        }
+        float ra0 [4], rb0 [NB * VEC];
+
+        // the fetch stream: item being fetched, its bases, the chunk to fetch next and the item's last (all uniform)
+        int f_within = rank, f_chunk = 0, f_end = 0;
+        bool f_live = false;
+        const char *fa_base = nullptr, *fb_base = nullptr;
+        unsigned int fa_bytes = 0, fb_bytes = 0;
+        auto open_item = [&] () {
+            int st, jg, ks;
+            f_live = item_at (f_within, st, jg, ks);
+            if (!f_live) return;
+            chunks_of (ks, f_chunk, f_end);
+            const int w0 = g.tile_w0 [3 * st] + jg * PPW * g.Q;
+            const bool touches_hist = w0 < a.H;              // (first period group of a call: staged from the gathered head)
+            const int origin = touches_hist ? -MF_HEAD_PAD : a.H;
+            const char *base = touches_hist ? reinterpret_cast<const char *> (g.head) : reinterpret_cast<const char *> (a.in);
+            const size_t total_b = touches_hist ? (size_t) g.head_frames * a.C * 4 : (size_t) a.in_frames * a.C * 4;
+            size_t skip = (size_t) max (w0 - origin, 0) * CG * 4;
+            if (skip > total_b) skip = total_b;
+            fb_base = base + skip; fb_bytes = (unsigned int)(total_b - skip);
+            fa_base = reinterpret_cast<const char *> (g.eff + (size_t) st * 32 * g.ktot);
+            fa_bytes = (unsigned int)((size_t) 32 * g.ktot * 4);
+        };
+        auto fetch_next = [&] () {
+            if (f_live) {
+                const unsigned int sa = min ((unsigned int) f_chunk * A_STEP, fa_bytes), sb = min ((unsigned int) f_chunk * B_STEP, fb_bytes);
+                const __amdgpu_buffer_rsrc_t ra_ = make_rsrc (fa_base + sa, fa_bytes - sa), rb_ = make_rsrc (fb_base + sb, fb_bytes - sb);
+                VecLoad<4>::load (ra0, ra_, a_off0);
+#pragma unroll
+                for (int u = 0; u < NB; ++u) VecLoad<VEC>::load (&rb0 [u * VEC], rb_, boff [u]);
+                if (++f_chunk == f_end) { f_within += wgs_per_xcd; open_item (); }
+            }
+        };
+        auto commit = [&] (auto buf_tag) {
+            constexpr int BUF = decltype (buf_tag)::value;
+            f32x4 v; v [0] = ra0 [0]; v [1] = ra0 [1]; v [2] = ra0 [2]; v [3] = ra0 [3];
+            *reinterpret_cast<f32x4 *> (&As_ [BUF] [adst]) = v;
+#pragma unroll
+            for (int u = 0; u < NB; ++u)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) Bs_ [BUF] [bdst [u] + e * MF_LD] = rb0 [u * VEC + e];
+        };
+
+        open_item ();
+        fetch_next (); commit (std::integral_constant<int, 0> {}); fetch_next ();
+        __syncthreads ();
+        for (int q = 0; q < total; q += 2) {
+            commit (std::integral_constant<int, 1> {}); fetch_next ();       // (past the end: registers are stale, the LDS is not read)
+            __syncthreads ();
+            if (q + 1 < total) {
+                commit (std::integral_constant<int, 0> {}); fetch_next ();
+                __syncthreads ();
+            }
+        }
+        return;
+    }
+
+    // ---- matrix waves ----
+    const int arow = (lane & 31) * MF_LD + 4 * (lane >> 5);
+    const int col = wave * 32 + (lane & 31);
+    const bool col_live = col < NCOLS;
+    const int jl = col / CG, c = col - jl * CG;
+    const int brow = col * MF_LD + 4 * (lane >> 5);
+    const unsigned int out_off = (unsigned int)((jl * g.P + 4 * (lane >> 5)) * CG + c) * 4u;
+
+    double sum [16];
+
+    __syncthreads ();                                        // the staging waves have committed chunk 0
+    int consumed = 0;                                        // chunks walked so far: the stream's chunk s sits in LDS buffer s & 1
+    for (int within = rank; ; within += wgs_per_xcd) {
+        int st, jg, ks, c0, c1;
+        if (!item_at (within, st, jg, ks)) break;
+        chunks_of (ks, c0, c1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum [r] = 0.0;
+
+        if ((consumed ^ c0) & 1) mf_k_walk<1> (As_, Bs_, arow, brow, nchunks, g.band_lo, g.band_hi, sum, c0, c1);
+        else mf_k_walk<0> (As_, Bs_, arow, brow, nchunks, g.band_lo, g.band_hi, sum, c0, c1);
+        consumed += c1 - c0;
+
+        // ---- this part's sums -> device memory; the wave that brings the tile's count to KS adds the parts up.  A part's image:
+        // [register pair][thread][2 doubles] — 16 bytes per lane and instruction, a wave's lanes side by side; stores written
+        // through and loads past the L1 (cache policy sc0 sc1: coherent wherever the other parts ran)
+        constexpr int COHERENT = 1 | 16;                     // (aux bits of the raw buffer instructions on gfx940+: sc0, sc1)
+        const int tile_g = xcd * tiles_per_xcd + within / KS;
+        {
+        const size_t part_bytes = (size_t) 16 * MF_THREADS * sizeof (double);
+        {
+            const __amdgpu_buffer_rsrc_t rs_part = make_rsrc (reinterpret_cast<char *> (partials) + (size_t)(tile_g * KS + ks) * part_bytes, (unsigned int) part_bytes);
+#pragma unroll
+            for (int r2 = 0; r2 < 8; ++r2) {
+                u32x4 v;
+                const unsigned long long lo = (unsigned long long) __double_as_longlong (sum [2 * r2]), hi = (unsigned long long) __double_as_longlong (sum [2 * r2 + 1]);
+                v.x = (unsigned int) lo; v.y = (unsigned int)(lo >> 32); v.z = (unsigned int) hi; v.w = (unsigned int)(hi >> 32);
+                __builtin_amdgcn_raw_buffer_store_b128 (v, rs_part, (r2 * MF_THREADS + pt) * 16, 0, COHERENT);
+            }
+        }
+        asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");       // (written through: the count below is only seen behind them)
+        unsigned int before = 0u;
+        if (lane == 0) before = __hip_atomic_fetch_add (arrivals + tile_g * 4 + wave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        before = (unsigned int) __builtin_amdgcn_readfirstlane ((int) before);
+        if (before != (unsigned int)(KS - 1)) continue;
+        if (lane == 0) __hip_atomic_store (arrivals + tile_g * 4 + wave, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // (for the next launch)
+
+        {
+        // every part's sums, in the order of the parts (all loads of a register pair in flight together)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum [r] = 0.0;
+        for (int k0 = 0; k0 < KS; k0 += 2) {                  // (KS is 2, 4 or 8: two parts at a time, 16 loads in flight)
+            u32x4 v [2] [8];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const __amdgpu_buffer_rsrc_t rs_part = make_rsrc (reinterpret_cast<char *> (partials) + (size_t)(tile_g * KS + k0 + kk) * part_bytes, (unsigned int) part_bytes);
+#pragma unroll
+                for (int r2 = 0; r2 < 8; ++r2) v [kk] [r2] = __builtin_amdgcn_raw_buffer_load_b128 (rs_part, (r2 * MF_THREADS + pt) * 16, 0, COHERENT);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int r2 = 0; r2 < 8; ++r2) {
+                    sum [2 * r2] = sum [2 * r2] + __longlong_as_double ((long long)((unsigned long long) v [kk] [r2].x | (unsigned long long) v [kk] [r2].y << 32));
+                    sum [2 * r2 + 1] = sum [2 * r2 + 1] + __longlong_as_double ((long long)((unsigned long long) v [kk] [r2].z | (unsigned long long) v [kk] [r2].w << 32));
+                }
+        }
+        }
+        }
+        const unsigned int n_tile = a.n_begin + (unsigned int)(jg * PPW) * g.P + (unsigned int)(st * 32);
+        const int rows_valid = min (32, g.P - st * 32);
+        const size_t left = (size_t)(a.n_end - n_tile) * CG * 4;
+        const __amdgpu_buffer_rsrc_t rs_out = make_rsrc (a.out + (size_t) n_tile * CG, left > 0xffffff00ull ? 0xffffff00u : (unsigned int) left);
+        const unsigned int pass_rows = PASS ? (unsigned int) g.tile_w0 [3 * st + 1] : 0u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i_const = (r & 3) + 8 * (r >> 2);      // compile-time part of the slot
+            float y = (float) sum [r];
+            const int i = i_const + 4 * (lane >> 5);
+            if constexpr (PASS) {
+                if ((pass_rows >> i) & 1u)
+                    y = load_frame (a, INT_MIN, g.canon_ip [st * 32 + i] + g.canon_fi [st * 32 + i] / a.F + (jg * PPW + jl) * g.Q, c);
+            }
+            if (col_live && i < rows_valid)
+                __builtin_amdgcn_raw_buffer_store_b32 (__float_as_uint (y), rs_out, (int)(out_off + (unsigned int)(i_const * CG) * 4u), 0, 0);
+        }
+    }
+}
 } // namespace
 
 // May fir_mfma_stream_kernel run this launch (it never replays an output's position)?  Every output n of the launch sits at
@@ -612,6 +841,45 @@ static int matrix_geometry (const ArtFirArgs *a, MfmaGeom &g)
     return cgt;
 }
 
+// Parts a tile's K range is cut into for this launch (fir_mfma_split_kernel), 1: not split.  Decided from the STREAM's size (a shard
+// of a multi-device context as its whole stream would: the same parts, the same bits): tiles = slot tiles x period groups of 128
+// columns.  Measured (profiles/r3_split_k_experiment.txt): cutting K does not cut a part's sample fetch (a tile's 16 periods are
+// 147 frames apart: a quarter of the K range still spans 3/4 of the tile's input), so more than two parts lose; two parts win
+// where half the CUs would otherwise idle through a whole K walk (50-110 tiles: the 32,768-frame call of 8 ch x 988 taps,
+// 21.7 -> 16.2 us) and nowhere else.  Kernel preference 8 forces 2 / 4 / 8 parts (tests, experiments: ARTAMD_SPLIT_KS).
+static int matrix_split_parts (const ArtFirArgs *a, const MfmaGeom &g, unsigned int outputs, int kernel_pref)
+{
+    if (kernel_pref == 5 || kernel_pref == 6 || kernel_pref == 7) return 1;
+    static const bool off = [] { const char *e = getenv ("ARTAMD_NO_SPLIT"); return e && *e && *e != '0'; } ();
+    if (off) return 1;
+    const int C = a->stream_C > a->C ? a->stream_C : a->C;
+    const double periods = ceil ((double) outputs / g.P);
+    const double cols = C >= 2 ? 128.0 : 64.0;                                   // (mono: 64 periods per tile, half the columns idle)
+    const double tiles = g.slot_tiles * ceil (periods * C / cols);
+    const int nchunks = g.ktot / MF_KC;
+    int ks = (tiles >= 50 && tiles <= 110 && nchunks >= 16) ? 2 : 1;
+    if (kernel_pref == 8) {                                   // (forced: the library's own parts where it splits, else as many as fill the chip)
+        if (ks == 1) ks = tiles * 8 <= 768 ? 8 : tiles * 4 <= 768 ? 4 : 2;
+        static const int k_env = [] { const char *e = getenv ("ARTAMD_SPLIT_KS"); return e && *e ? atoi (e) : 0; } ();
+        if (k_env > 0) ks = k_env;
+    }
+    while (ks > 1 && nchunks / ks < 4) ks >>= 1;
+    return ks;
+}
+
+size_t artfir_split_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref)
+{
+    if (!a->period_out || a->mode != ART_MODE_FAST) return 0;
+    ArtFirArgs b = *a;
+    b.n_begin = 0; b.n_end = outputs + (unsigned int) a->period_out * 64u;       // (any launch of the call: at most this many outputs)
+    MfmaGeom g;
+    if (!matrix_geometry (&b, g)) return 0;
+    const int ks = matrix_split_parts (a, g, outputs, kernel_pref);
+    const size_t tiles = (size_t) 8 * g.groups_per_xcd * g.slot_tiles;
+    if (ks < 2 || tiles * 16 > ART_SPLIT_HEAD_BYTES) return 0;
+    return ART_SPLIT_HEAD_BYTES + tiles * ks * 16 * MF_THREADS * sizeof (double);
+}
+
 // see arthip_fir_spans_segments (art_internal.h): the launch would run on a streaming kernel (the conditions of `regular` below)
 bool artfir_matrix_spans_segments (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref)
 {
@@ -623,7 +891,7 @@ bool artfir_matrix_spans_segments (const ArtFirArgs *a, const ArtSegTable *segs,
 // bytes of digit planes the fixed-point kernel wants for a call of this shape (the host sizes a->planes with it before the launch)
 size_t artfir_planes_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref)
 {
-    if (!a->period_out || a->mode != ART_MODE_FAST || kernel_pref == 5 || kernel_pref == 6) return 0;
+    if (!a->period_out || a->mode != ART_MODE_FAST || kernel_pref == 5 || kernel_pref == 6 || kernel_pref == 8) return 0;
     // Where it pays (MI355X, tools/bench_shapes.py with and without ARTAMD_NO_FIXED, profiles/r2_fixed_point_shapes.txt): the
     // integer kernel gains in proportion to outputs x channels x taps, its staging pass costs in proportion to the input
     // and its extra launch ~4 us: long filters and big calls win (8 ch x 988 taps: from ~90k frames per call, +27 % at 1M;
@@ -703,6 +971,26 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
             const int resident = 94;
             int wgs_per_xcd = tiles_per_xcd < resident ? tiles_per_xcd : resident;
             { static const int k_env = [] { const char *e = getenv ("ARTAMD_TILES_PER_WG"); return e && *e ? atoi (e) : 0; } (); if (k_env > 0) wgs_per_xcd = (tiles_per_xcd + k_env - 1) / k_env; }
+            // launches of few tiles: a tile's K range as several work items (fir_mfma_split_kernel)
+            const int ks = a->split ? matrix_split_parts (a, g, a->n_end - a->n_begin, kernel_pref) : 1;
+            if (ks > 1 && (size_t) 8 * tiles_per_xcd * 16 <= ART_SPLIT_HEAD_BYTES &&
+                ART_SPLIT_HEAD_BYTES + (size_t) 8 * tiles_per_xcd * ks * 16 * MF_THREADS * sizeof (double) <= a->split_bytes) {
+                const int items = tiles_per_xcd * ks;
+                const int wgs = items < resident ? items : resident;
+                const dim3 kgrid ((unsigned int)(8 * wgs) + roll_blocks);
+                unsigned int *arrivals = (unsigned int *) a->split;
+                double *partials = (double *)((char *) a->split + ART_SPLIT_HEAD_BYTES);
+#define MK_GO_(I, CGT, PS) hipLaunchKernelGGL ((fir_mfma_split_kernel<I, CGT, PS>), kgrid, dim3 (2 * MF_THREADS), 0, st, *a, g, wgs, ks, partials, arrivals)
+#define MK_GO(I, CGT) do { if (!I && !a->lowpass) MK_GO_ (false, CGT, true); else MK_GO_ (I, CGT, false); } while (0)
+                if (a->interpolate) switch (cgt) { case 32: MK_GO (true, 32); break; case 16: MK_GO (true, 16); break; case 8: MK_GO (true, 8); break;
+                                                    case 4: MK_GO (true, 4); break; case 2: MK_GO (true, 2); break; default: MK_GO (true, 1); }
+                else                switch (cgt) { case 32: MK_GO (false, 32); break; case 16: MK_GO (false, 16); break; case 8: MK_GO (false, 8); break;
+                                                    case 4: MK_GO (false, 4); break; case 2: MK_GO (false, 2); break; default: MK_GO (false, 1); }
+#undef MK_GO
+#undef MK_GO_
+                if (a->ev_stop) arthip_event_record (a->ev_stop, stream);
+                return hipGetLastError () == hipSuccess ? (ART_KERNEL_MFMA | (a->roll_dst ? ART_FIR_ROLLED : 0)) : -1;
+            }
             const dim3 sgrid ((unsigned int)(8 * wgs_per_xcd) + roll_blocks);
 #define MS_GO_(I, CGT, PS) hipLaunchKernelGGL ((fir_mfma_stream_kernel<I, CGT, PS>), sgrid, dim3 (2 * MF_THREADS), 0, st, *a, g, wgs_per_xcd)
 #define MS_GO(I, CGT) do { if (!I && !a->lowpass) MS_GO_ (false, CGT, true); else MS_GO_ (I, CGT, false); } while (0)

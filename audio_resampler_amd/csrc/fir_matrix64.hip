@@ -299,6 +299,7 @@ bool artfir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int
 // Launch the fp64 matrix-core path for this call if it applies: ART_KERNEL_MFMA (| ART_FIR_ROLLED), -1 on a launch failure,
 // 0 when the call is for the general kernel.
 size_t artfir_planes_bytes (const ArtFirArgs *, unsigned int, int) { return 0; }
+size_t artfir_split_bytes (const ArtFirArgs *, unsigned int, int) { return 0; }
 bool artfir_matrix_spans_segments (const ArtFirArgs *, const ArtSegTable *, int) { return false; }    // (the fp64 kernel checks every output's position against the table)        // (the fixed-point kernel is a 4-byte-sample path)
 
 int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, void *stream)

@@ -20,9 +20,11 @@ namespace {
 // (Tried, same box, same run: a frame-major X tile in LDS — the staging waves then write whole dwordx4 loads, 5 LDS writes per
 // chunk and thread instead of 9, the matrix waves pick their k's with ds_read2_b32 — 0.1547 vs 0.1541 ms: the staging waves' LDS
 // writes are not what the matrix waves wait for.  Raised wave priority for either role: no change.)
+// c_from, c_to: the chunks to walk ([0, nchunks): the whole tile; fir_mfma_split_kernel hands a tile's K range to several
+// workgroups) — chunk c sits in LDS buffer (c & 1) ^ PAR
 template <int PAR>
 __device__ __forceinline__ void mf_k_walk (const float (*As_) [32 * MF_LD], const float (*Bs_) [MF_COLS * MF_LD], int arow, int brow,
-                                           int nchunks, int band_lo, int band_hi, double (&sum) [16])
+                                           int nchunks, int band_lo, int band_hi, double (&sum) [16], int c_from = 0, int c_to = 0x7fffffff)
 {
     auto b_of = [&] (const float *Bs, int grp) -> f32x4 { return *reinterpret_cast<const f32x4 *> (&Bs [brow + grp * 8]); };
     const int lo_band = band_lo / MF_KC, hi_band = (band_hi + MF_KC - 1) / MF_KC;       // band chunks [lo_band, hi_band)
@@ -100,9 +102,9 @@ __device__ __forceinline__ void mf_k_walk (const float (*As_) [32 * MF_LD], cons
             __syncthreads ();
         }
     };
-    run (0, left_end, 0);
-    centre (left_end, right_from);
-    run (right_from, nchunks, 4);
+    run (max (0, c_from), min (left_end, c_to), 0);
+    centre (max (left_end, c_from), min (right_from, c_to));
+    run (max (right_from, c_from), min (nchunks, c_to), 4);
 }
 
 

@@ -65,6 +65,7 @@ struct artamd_resampler {
     art_s *d_patch; size_t patch_cap;        /* end-point extrapolation: samples computed on the host */
     void *d_scratch; size_t scratch_cap;     /* MFMA path: effective rows + canonical positions of one launch */
     void *d_planes; size_t planes_cap;       /* fixed-point matrix kernel: digit planes of one launch (flag word first) */
+    void *d_split; size_t split_cap;         /* K-split streaming kernel: arrival counters (zero at rest) + partial sums of one launch */
     int last_fixed [3];                      /* its last launch of the last call: flag value (0: none), mask words, chunks per tile */
     unsigned int *d_fix; size_t fix_cap;    /* [0] per-launch, [1] running count of outputs the matrix kernels evaluated off-pattern */
     void *d_batch; size_t batch_cap;         /* argument table of the batched calls led by this context */
@@ -645,7 +646,7 @@ void resampleFree (Resample *cxt)
         arthip_event_destroy (hip->ev_parent);
         free (hip->shards); free (hip->shard_first); free (hip->ev_shard);
         bank_release (hip->bank); arthip_free (hip->d_hist [0]); arthip_free (hip->d_hist [1]);
-        arthip_free (hip->d_in); arthip_free (hip->d_out); arthip_free (hip->d_tmp); arthip_free (hip->d_fix); arthip_free (hip->d_scratch); arthip_free (hip->d_planes); arthip_free (hip->d_patch); arthip_free (hip->d_batch);
+        arthip_free (hip->d_in); arthip_free (hip->d_out); arthip_free (hip->d_tmp); arthip_free (hip->d_fix); arthip_free (hip->d_scratch); arthip_free (hip->d_planes); arthip_free (hip->d_split); arthip_free (hip->d_patch); arthip_free (hip->d_batch);
         arthip_host_free (hip->h_in); arthip_host_free (hip->h_out);
         for (int i = 0; i < hip->ev_cap; ++i) arthip_event_destroy (hip->ev [i]);
         if (hip->own_stream) arthip_stream_destroy (hip->stream);
@@ -1190,6 +1191,14 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
                 if (hip->d_planes) arthip_zero (hip->d_planes, ART_I8_HEAD_BYTES, hip->stream);
             }
             a.planes = want ? hip->d_planes : NULL; a.planes_bytes = hip->d_planes ? hip->planes_cap : 0;
+            /* calls of few tiles: room for the K-split kernel's partial sums (a grown buffer starts with its counters zeroed; the
+             * old one is released behind the launches that used it: stream order) */
+            const size_t split_want = want ? 0 : arthip_fir_split_bytes (&a, res.output_generated, hip->kernel_pref);
+            if (split_want > hip->split_cap) {
+                hip->d_split = grow (hip->d_split, &hip->split_cap, split_want);
+                if (hip->d_split) arthip_zero (hip->d_split, ART_SPLIT_HEAD_BYTES, hip->stream);
+            }
+            a.split = split_want ? hip->d_split : NULL; a.split_bytes = hip->d_split ? hip->split_cap : 0;
             a.fixed_out = hip->last_fixed;
         }
 

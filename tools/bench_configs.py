@@ -98,6 +98,11 @@ resample_only("D/8 4ch -4 (one GPU's shard of D)", 4, 988, 988, 44100, 48000, BH
 resample_only("E  stereo ASRC -3 no-lerp, ratio +-100ppm per block", 2, 380, 380, 44100, 48000, BH, False, 65536,
               ratio_fn=lambda k: 48000 / 44100 * (1 + 100e-6 * math.sin(2 * math.pi * k / 64)))
 resample_only("P  mono -1 48x48 interp", 1, 48, 48, 44100, 48000, BH | IN, False, blk)
+# short periods (2x / 4x / 2:3 conversions: 1-3 outputs per period, taken several periods at a time) and many ring epochs per call
+resample_only("R2 8ch -4 988x988 interp 44.1k->88.2k (2 outputs per period)", 8, 988, 988, 44100, 88200, BH | IN, False, blk // 2)
+resample_only("R3 8ch -4 988x988 interp 48k->32k (2 outputs per 3 inputs)", 8, 988, 988, 48000, 32000, BH | IN, False, blk)
+resample_only("R4 8ch -4 ART form 192k->48k (1 filter, low-pass)", 8, 988, 988, 192000, 48000, BH | IN | LP, True, blk)
+resample_only("S  16ch -2 156x156 interp 44.1k->48k (short filter: 448 ring epochs per call)", 16, 156, 156, 44100, 48000, BH | IN, False, blk // 2)
 
 # ---- C: 8 ch 96k -> 44.1k, preset -4 fixed ratio (147x988 no-lerp, auto low-pass), 2x biquad LP pre-filter, 16-bit decimation
 ch, taps, src, dst = 8, 988, 96000, 44100
