@@ -283,7 +283,7 @@ def main():
                          "unit_note": "integer multiply-adds of v_mfma_i32_32x32x32_i8, 2 ops each (TOP/s), against the dense int8 MFMA peak" if fixed else "f32 MFMA",
                          "frac": round(tflops_exec / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_unit": "bytes/launch (HBM, PMC)", "algorithmic_bytes_per_launch": int(per_launch_samples * BYTES_PER_SAMPLE),
-                         "kernel": "fir_i8_stream_kernel" if fixed else "fir", "avg_kernel_ms": round(avg_ms, 4), "launches": launches,
+                         "kernel": ("fir_i8_dma_kernel" if Cn >= 4 else "fir_i8_stream_kernel") if fixed else "fir_mfma_stream_kernel", "avg_kernel_ms": round(avg_ms, 4), "launches": launches,
                          "avg_prep_ms": round(prep_ms / max(launches, 1), 4),
                          "prep_note": "HIP events: what each launch spends before its dominant kernel (fixed point: peak pass + digit-plane staging pass; f32: row-table pass)",
                          "flop_per_sample_executed": round(executed_per_sample, 1), "bytes_per_sample": round(BYTES_PER_SAMPLE, 3),
