@@ -134,3 +134,34 @@ def test_short_period_ratios_in_the_8_byte_build(ratio):
     assert (u, g) == (uo, go) and h.last_kernel() == 2
     d = np.abs(np.array(y) - np.array(yo))
     assert np.all(d <= 2.0 ** -47 * np.maximum(1.0, np.abs(np.array(yo)))), float(d.max())
+
+
+ODD_RATIOS = [(7, 3), (3, 7), (5, 4), (4, 5), (13, 11), (24, 25), (25, 24), (3, 1), (1, 3), (50, 49), (99, 100), (64, 63), (1, 1)]
+
+
+@pytest.mark.parametrize("kernel", [2, 7])
+@pytest.mark.parametrize("pq", ODD_RATIOS, ids=[f"{p}over{q}" for p, q in ODD_RATIOS])
+def test_arbitrary_small_rational_ratios(pq, kernel):
+    """outputs per period 1 ... 99: every one of them goes through the period rule (exact fill, best fit below 16 tiles, or as it is)
+    — matrix path (library's choice of kernel, and fixed point forced) against the oracle, two calls and the flush"""
+    p, q = pq
+    ch, T = 2, 256
+    blocks = (70001, 52000)
+    r_ = p / q
+    total = sum(blocks)
+    x, _ = noise(total * ch, state=(0xD00D + 977 * p + q) | 1)
+    x = x.reshape(total, ch)
+    h = HipResampler(ch, T, T, 0.0, BH | INTERP, kernel=kernel); h.advance(T / 2)
+    o = OracleResampler(ch, T, T, 0.0, BH | INTERP | PRECISE); o.advance(T / 2)
+    pos = 0
+    for n in blocks:
+        cap = int(n * r_) + 4000
+        u, g, y = h.process(x[pos:pos + n], cap, r_)
+        uo, go, yo = o.process(x[pos:pos + n], cap, r_, threads=8)
+        assert (u, g) == (uo, go)
+        assert h.last_kernel() == 2, h.last_kernel()
+        assert tolerance_ok(np.array(y), np.array(yo))[0], n
+        pos += n
+    u, g, y = h.process(None, 8000, r_, flush=True)
+    uo, go, yo = o.process(None, 8000, r_, flush=True)
+    assert g == go and (g == 0 or tolerance_ok(np.array(y), np.array(yo))[0])
