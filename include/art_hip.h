@@ -142,6 +142,11 @@ unsigned int artamdBiquadRepairs (void);             /* the host-pointer calls (
 int artamdErrorCount (void);
 const char *artamdLastError (void);                  /* NULL while the count is zero */
 
+/* How many periods of an exact rational ratio (outputsPerPeriod = the numerator of the reduced ratio) the matrix-core kernels take at
+ * a time: their tiles hold 32 consecutive outputs of one period, so short periods (2x conversions: 2 outputs) or badly fitting ones
+ * are taken several at a time — 1 while the padding stays within 15 %.  Informational (the choice is the library's own). */
+int artamdPeriodMultiple (int outputsPerPeriod);
+
 /* ---- decimator, device pointers ---- */
 void decimateHipSetStream (Decimate *cxt, void *hipStream);
 /* asynchronous; clipped-sample count accumulates on the device, read with decimateHipClipped() */

@@ -142,3 +142,34 @@ def test_planner_segments_cover_ring_rewinds():
     for a, b in zip(segs, segs[1:]):
         assert b[1] - a[1] == 15 * T and a[2] - b[2] == 15 * T
     assert floor == -2 ** 31
+
+
+@pytest.mark.parametrize("ratio", [48000 / 44100, 44100 / 48000, 2.0, 2.0 / 3.0, 0.25, 1.0, 1.0000003, 3.7], ids=lambda r: f"{r:.7g}")
+def test_planner_equals_oracle_loop_over_hundreds_of_ring_epochs(ratio):
+    """calls of many ring epochs (short filters: 15 T consumed frames each): the planner's two probes at the arithmetic estimate must
+    close the search in every epoch exactly as the oracle's literal loop does — counts, carried position and every segment's start"""
+    T = 48
+    o = OracleResampler(1, T, T, 0.0, BH | INTERP)
+    o.advance(T / 2)
+    c = o.c
+    pos = ArtamdPosition(T, c.filters, c.flags, c.write_pos, 0, c.read_pos, c.fixed_ratio)
+    for n in (250000, 1, 90001):
+        cap = int(n * ratio) + 100
+        u, g, _ = o.process(np.zeros((n, 1), np.float32), cap, ratio)
+        used, made, segs, floor = plan(pos, n, cap, ratio, max_segs=8192)
+        assert (used, made) == (u, g), (n, ratio)
+        st = o.state()
+        assert np.float64(pos.outputOffset).view(np.uint64).item() == st[0] and pos.inputIndex == st[1]
+        assert len(segs) >= n // (15 * T) and all(a[0] <= b[0] for a, b in zip(segs, segs[1:]))
+
+
+def test_period_rule_fills_the_matrix_tiles():
+    """fir_common.hip.h, artfir_period_multiple through the C ABI: 1 while a period pads its 32-row tiles by at most 15 %, else the
+    multiple that fills whole tiles (up to 16 tiles), else the smallest multiple within 4 % of padding"""
+    L = A.lib()
+    assert [L.artamdPeriodMultiple(p) for p in (160, 147, 2, 1, 3, 80, 50, 4, 6, 640, 33)] == [1, 1, 16, 32, 32, 2, 5, 8, 16, 1, 14]
+    for p in range(1, 700):
+        mu = L.artamdPeriodMultiple(p)
+        padded = -(-mu * p // 32) * 32
+        assert mu >= 1 and (mu == 1 or mu * p <= 512)
+        assert padded / (mu * p) <= 1.15 + 1e-12, (p, mu)
