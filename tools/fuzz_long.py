@@ -67,8 +67,9 @@ while time.time() < t_end:
         if (u, g) != (uo, go): bad = ("counts", k, (u, g), (uo, go)); break
         y = np.array(y); yo = np.array(yo)
         if wide:
-            d = np.abs(y - yo); tol = 2.0 ** -47 * np.maximum(1.0, np.abs(yo))
-            if not np.all(d <= tol): bad = ("value64", k, float(d.max())); break
+            # (relative to the session's unit, as for the 4-byte sessions: both results are rounded sums of ~1000 double products)
+            d = np.abs(y - yo) / unit; tol = 2.0 ** -47 * np.maximum(1.0, np.abs(yo) / unit)
+            if not np.all(d <= tol): bad = ("value64", k, float(d.max()), level); break
         else:
             ok, worst, rms = tolerance_ok(y.astype(np.float64) / unit, yo.astype(np.float64) / unit)
             if not ok: bad = ("value", k, worst, level, int(np.argmax(np.abs(y.astype(np.float64) - yo)) // ch), g); break
