@@ -145,6 +145,7 @@ def _bind(width):
         "decimateHipShardCount": (C.c_int, [DP]),
         "artamdErrorCount": (C.c_int, []),
         "artamdPeriodMultiple": (C.c_int, [C.c_int]),
+        "artamdPeriodMultipleRows": (C.c_int, [C.c_int, C.c_int]),
         "artamdLastError": (C.c_char_p, []),
         "floatIntegersLEDevice": (None, [ptr, C.c_double, C.c_int, C.c_int, C.c_int, ptr, C.c_int, ptr]),
         # stretch.h

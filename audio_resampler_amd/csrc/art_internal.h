@@ -20,7 +20,8 @@ extern "C" {
 
 /* header of a context's digit-plane buffer (fixed-point matrix kernel, fir_matrix_i8.hip), zeroed when the buffer is allocated:
  * [0] stand-down flag word.  The rows' mask words follow the header. */
-#define ART_I8_HEAD_BYTES 256
+#define ART_I8_FLAG_BYTES 256    /* the flag word of the fixed-point kernel's buffer (and what shares its cache line) */
+#define ART_I8_HEAD_BYTES 32768  /* the buffer's header, zero when allocated: the flag, then the slab kernel's arrival counters (8 XCDs x 64 tiles x 8 waves) */
 
 #define ART_SPLIT_HEAD_BYTES 65536   /* arrival counters of the K-split kernel: 4 per tile, up to 4096 tiles */
 #define ART_MAX_SEGS 192         /* ring-epoch segments per kernel launch (passed by value: 16 B each, kernel arguments stay below 4 KB) */

@@ -6,6 +6,7 @@ extern "C" {
 int arthip_fir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref) { return artfir_takes_matrix_path (a, segs, kernel_pref) ? 1 : 0; }
 
 int artamdPeriodMultiple (int outputsPerPeriod) { return outputsPerPeriod > 0 ? artfir_period_multiple (outputsPerPeriod, 32) : 0; }
+int artamdPeriodMultipleRows (int outputsPerPeriod, int rows) { return outputsPerPeriod > 0 && rows > 0 ? artfir_period_multiple (outputsPerPeriod, rows) : 0; }
 
 int arthip_fir_spans_segments (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref) { return artfir_matrix_spans_segments (a, segs, kernel_pref) ? 1 : 0; }
 

@@ -816,9 +816,9 @@ static int matrix_geometry (const ArtFirArgs *a, MfmaGeom &g)
 {
     const unsigned int total = a->n_end - a->n_begin;
     {   // (short or badly fitting periods: several at a time, fir_common.hip.h — one rule for every kernel of the path and every
-        // channel count, so that all contexts of a stream have the same rows; with the experimental 64-slot fixed-point kernel
-        // switched on, so as to fill ITS tiles, which is also whole 32-slot tiles for every other kernel)
-        const int mu = artfir_period_multiple (a->period_out, artfir_i8_wide_enabled () ? 64 : 32);
+        // channel count, so that all contexts of a stream have the same rows; so as to fill the 64-slot tiles of the
+        // fixed-point slab kernel, which is also whole 32-slot tiles for every other kernel)
+        const int mu = artfir_period_multiple (a->period_out, artfir_i8_slab_enabled () ? 64 : 32);
         g.P = mu * a->period_out; g.Q = mu * a->period_in;
     }
     // compile-time channel count where the whole stream is one column group and the buffers allow vector loads

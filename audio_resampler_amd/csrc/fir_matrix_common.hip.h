@@ -28,7 +28,7 @@ struct MfmaGeom {
 
 // fir_matrix_i8.hip: the fixed-point kernel of regular launches
 size_t artfir_i8_bytes (const ArtFirArgs *a, const MfmaGeom &g, int cgt, unsigned int outputs);   // device bytes of the digit planes of a call making `outputs` frames (0: not for it)
-bool artfir_i8_wide_enabled ();           // ARTAMD_I8_WIDE=1: 64-slot tiles (periods are then taken so as to fill those)
+bool artfir_i8_slab_enabled ();           // 64-slot tiles of the slab kernel (periods are taken so as to fill those); ARTAMD_I8_SLAB=0: off
 // stage + main kernel of one launch (1), or 0: not for this path (no planes, shape)
 int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGeom &g, int cgt, unsigned int roll_blocks, hipStream_t st);
 

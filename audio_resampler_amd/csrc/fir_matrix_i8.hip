@@ -54,7 +54,8 @@ constexpr float I8_SCALE = 1073741824.0f; // 2^30: the filter rows' fixed point
 constexpr float I8_LIMIT = 1.98f;         // |row value| the digits can hold: 0x7f7f7f7f / 2^30 = 1.98437..., rounded down
 
 struct I8Geom {
-    int tr;                               // rows (slots) per tile: 32, or 64 (fir_i8_wide_kernel: two 32-row register tiles on one K origin)
+    int tr;                               // rows (slots) per tile: 32, or 64 (fir_i8_slab_kernel: two 32-row register tiles on one K origin)
+    int cols;                             // columns per tile: I8_COLS, or SL_COLS (fir_i8_slab_kernel)
     int tiles;                            // ceil (P / tr)
     int ktot;                             // K columns of a tile: T + the span of its rows' window starts + alignment, a multiple of I8_KC
     int g;                                // period stride inside a tile
@@ -63,7 +64,7 @@ struct I8Geom {
     int sg_per_xcd;
     unsigned char *a_planes;
     unsigned long long *a_masks;          // [variant][row]: bit c set = chunk c of the row has a non-zero most significant digit
-    unsigned long long *tile_masks;       // [variant][32-row half]: the OR over the half's rows (quantise launch; read by fir_i8_wide_kernel)
+    unsigned long long *tile_masks;       // [variant][32-row half]: the OR over the half's rows (quantise launch; read by fir_i8_slab_kernel)
     const unsigned char *x_planes;        // (written through x_planes_w by the staging pass)
     unsigned int *x_planes_w;
     // exponent blocks: block e = periods [e * eb_periods, (e + 1) * eb_periods) of the launch; its planes hold 4-frame blocks
@@ -79,6 +80,7 @@ struct I8Geom {
     size_t x_bytes;                       // ebs * 4 * eb_plane_bytes
     int *flag; int epoch;                 // *flag == epoch: this launch cannot run in fixed point (set by the staging pass)
     int *shifts;                          // [ebs][C]: the block's samples of channel c are quantised as rint (x * 2^shift)
+    unsigned char *parts;                 // slabs: parts of tiles cut between workgroups (fir_i8_slab_kernel), behind the planes
 };
 
 // binary exponent for a channel whose peak magnitude has these float bits: peak * 2^shift in [2^29, 2^31 - 2^24) — as large as the
@@ -96,6 +98,15 @@ constexpr int I8_STAGE_K = 4;             // units (4 frames of one channel) per
 
 // digits of a fixed-point value as one dword: byte 3 = d0 ... byte 0 = d3, each signed
 __device__ __forceinline__ unsigned int digits_of (int q) { return ((unsigned int) q + 0x80808080u) ^ 0x80808080u; }
+
+// the class sums of one output as ONE exact integer (|sum_s| < 2^31, class 0 < 2^24: |total| < 2^57), and its single rounding
+__device__ __forceinline__ long long i8_total (int s0, int s1, int s2, int s3, int s4)
+{
+    long long v = (long long) s0;
+    v = (v << 8) + (long long) s1; v = (v << 8) + (long long) s2; v = (v << 8) + (long long) s3; v = (v << 8) + (long long) s4;
+    return v;
+}
+__device__ __forceinline__ float i8_round (long long v, int out_exp) { return (float) __builtin_ldexp ((double) v, out_exp); }
 
 // four consecutive taps' digit dwords -> four plane dwords (plane p, byte q = digit p of tap q)
 __device__ __forceinline__ void to_planes (const unsigned int (&s) [4], unsigned int (&pl) [4])
@@ -605,12 +616,9 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i_const = (r & 3) + 8 * (r >> 2);      // compile-time part of the slot
-            // class sums, weights 256^(4 - s), in fp64 (|total| < 2^58: the four roundings are 2^-53 relative), scaled back by the
-            // rows' and the channel's exponents (a power of two: exact) and rounded ONCE to float
-            double v = (double) acc [0] [r];
-#pragma unroll
-            for (int s = 1; s < 5; ++s) v = v * 256.0 + (double) acc [s] [r];
-            float y = (float) __builtin_ldexp (v, out_exp);
+            // class sums, weights 256^(4 - s), as one exact 64-bit integer, scaled back by the rows' and the channel's exponents (a
+            // power of two: exact) and rounded ONCE to float — the same arithmetic in every fixed-point kernel: the same bits
+            float y = i8_round (i8_total (acc [0] [r], acc [1] [r], acc [2] [r], acc [3] [r], acc [4] [r]), out_exp);
             const int i = i_const + 4 * (lane >> 5);
             if constexpr (PASS) {
                 // nearest-filter mode, the position falls exactly on an input sample: the reference copies it (resampler.c:1141-1142)
@@ -833,10 +841,7 @@ void fir_i8_dma_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i_const = (r & 3) + 8 * (r >> 2);      // compile-time part of the slot
-            double v = (double) acc [0] [r];
-#pragma unroll
-            for (int s = 1; s < 5; ++s) v = v * 256.0 + (double) acc [s] [r];
-            float y = (float) __builtin_ldexp (v, out_exp);
+            float y = i8_round (i8_total (acc [0] [r], acc [1] [r], acc [2] [r], acc [3] [r], acc [4] [r]), out_exp);
             const int i = i_const + 4 * (lane >> 5);
             if constexpr (PASS) {
                 if ((pass_rows >> i) & 1u)
@@ -850,77 +855,114 @@ void fir_i8_dma_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
 
 
 // ---------------------------------------------------------------------------------------------------
-// Tiles of 64 slots.  The LDS pipe is what bounds the kernel above (profiles/r3_ablation_i8_dma.txt): a 32 x 32 register tile reads
-// 8 KB of operands per 9.5 products, and every workgroup tile of 32 slots stages its own 16 KB of X digits per chunk.  Here a
-// matrix wave holds TWO 32-row tiles on one K origin — 64 consecutive slots x 32 columns, 2 x 5 x 16 accumulators — so a B read
-// feeds two product chains (12 KB per 19 products) and a workgroup's X digits serve 64 slots (24 KB staged per 76 products instead
-// of 40).  256 registers per wave leave room for two waves per SIMD: a workgroup is FOUR waves, two workgroups per CU, and there
-// are no staging waves — with LDS-DMA staging is a handful of issue slots, so every wave issues its share of the next-but-one
-// chunk (6 buffer_load ... lds: two 1 KB pieces of the rows, one of each X plane) right after the chunk's barrier and counts its
-// own landings.  One barrier per chunk: at it every wave has its part of chunk c in the LDS and has finished reading chunk c - 1,
-// whose buffer the DMA issued behind the barrier overwrites.  The tile's 32 stores per lane sit on the same VM counter as the
-// DMAs, in issue order: for the two chunks after an epilogue the counted wait allows for them.
-// Periods are taken several at a time where that fills 64-row tiles (fir_common.hip.h: 160 outputs per period -> 320).
-// A launch the digits cannot hold is produced by fir_i8_standby_kernel, launched behind this one (this kernel's workgroups of
-// four waves cannot run the f32 streaming kernel's eight-wave tile loop).
+// Slabs: tiles of 64 slots x 256 columns, one eight-wave workgroup per CU.  What bounds the 32-slot kernel above is the bytes a tile
+// pulls through the L2 and the LDS-DMA path per product — 20 KB per chunk for 38 products per workgroup, two workgroups per CU
+// each staging tiles of their own: 2.0 GB of L2 requests per headline launch, ~60 % of what the eight L2s deliver, and every wait
+// of the kernel is behind that queue.  Here ALL eight waves multiply, each holding two 32-row register tiles on one K origin (64
+// slots x 32 columns, 2 x 5 x 16 accumulators, 256 registers: two waves per SIMD, which cover each other's operand reads), and a
+// workgroup stages 40 KB per 32 taps for 152 products: half the bytes per product (0.26 KB against 0.53), half the DMA pieces.
+// K is walked 64 taps per barrier: two LDS buffers of two 32-tap images each (2 x 80 KB: all of the CU's LDS); behind the barrier
+// of chunk c every wave issues its 10 DMA pieces of chunk c + 1 (one piece of the rows and one of each X plane per 32-tap image)
+// and then multiplies chunk c.  One barrier per chunk: at it every wave's pieces of the chunk have landed (counted per wave,
+// s_waitcnt vmcnt) and every wave has read the chunk before, whose buffer the DMA issued behind the barrier overwrites.
+//   LDS image of 32 taps: rows  [plane][16-tap half][row 0..63][16 taps]           (8 KB, the order the staging pass leaves in memory)
+//                         X     [plane][column half][4-tap block][column 0..127][4 taps]   (32 KB; a DMA piece = 2 blocks x 128 columns)
+// Tiles cut to the launch ("two-tile stream-K").  An XCD's list of L tiles is walked by its W workgroups: whole tiles, strided,
+// for all but the last full round; the remaining S = W + (L mod W) tiles are a run of S x chunks K-chunks cut into W equal
+// pieces, so a workgroup takes the tail of one tile and the head of the next.  The sums are integers: a part leaves its class
+// sums combined to one exact 64-bit integer per output in device memory (16-byte stores written through), and the WAVE that brings
+// the tile's per-wave arrival count to the number of parts adds the others' to its own (coherent loads) and writes the outputs —
+// no workgroup waits for another, any order of arrival gives the same bits, and they are the bits of the uncut tile.
+// The history roll is done by the stream's own workgroups (no extra workgroups: there is one slot per CU).
 // ---------------------------------------------------------------------------------------------------
+constexpr int SL_COLS = 256, SL_THREADS = 512;
+constexpr int SL_A_IMG = 8192, SL_B_IMG = 32768, SL_IMG = SL_A_IMG + SL_B_IMG, SL_BUF = 2 * SL_IMG;
+constexpr int SL_WGS = 32;                // workgroups per XCD: one per CU
+constexpr int SL_MAX_SK = 64;             // stream-K tiles per XCD (< 2 W), arrival counters per XCD
+constexpr size_t SL_PART_BYTES = (size_t) 8 * 16 * 64 * 16;      // one part of one tile: [wave][register pair][lane][2 x int64] = 128 KB
+
+struct I8Slab {
+    int wgs_per_xcd;                      // W
+    int live [8];                         // tiles of each XCD's list that hold outputs (they are a prefix of the list)
+    unsigned char *parts;                 // [xcd][rank][2] parts of SL_PART_BYTES
+    unsigned int *arrivals;               // [xcd][SL_MAX_SK][8 waves], zero between launches
+#ifdef I8_SLAB_TRACE
+    long long *trace;                     // (debug build: per workgroup and wave, cycles spent in each phase of the chunk loop)
+#endif
+};
+
+
 template <int CG, bool PASS>
-__global__ __launch_bounds__ (MF_THREADS) __attribute__ ((amdgpu_waves_per_eu (2, 2)))
-void fir_i8_wide_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
+__global__ __launch_bounds__ (SL_THREADS) __attribute__ ((amdgpu_waves_per_eu (2, 2)))
+void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
 {
-    static_assert (CG >= 4 && I8_COLS % CG == 0, "16-byte vectors of 4 channels");
-    constexpr int THREADS = MF_THREADS;
-    constexpr int PPW = I8_COLS / CG;
-    constexpr int NBUF = 3, A_BUF = 8192, B_BUF = 16384, A_ALL = NBUF * A_BUF;
+    static_assert (CG >= 4 && SL_COLS % CG == 0 && SL_COLS / CG <= I8_MAX_PPW, "16-byte vectors of 4 channels");
+    constexpr int THREADS = SL_THREADS;
+    constexpr int PPW = SL_COLS / CG;
     // (ONE __shared__ object: with a second one the compiler waits vmcnt(0) before the first LDS read behind a DMA)
-    __shared__ __attribute__ ((aligned (16))) unsigned char smem_ [NBUF * (A_BUF + B_BUF)];
-    unsigned char *const As_ = smem_, *const Bs_ = smem_ + A_ALL;
+    __shared__ __attribute__ ((aligned (16))) unsigned char smem_ [2 * SL_BUF];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane (tid >> 6);       // (uniform, and known to be: LDS-DMA destinations are scalars)
 
-    const unsigned int stream_blocks = 8u * (unsigned int) wgs_per_xcd;
-    if (blockIdx.x >= stream_blocks) {                        // extra workgroups: the history roll (as in fir_mfma_kernel)
-        if (a.roll_dst) {
-            const int e = (int)(blockIdx.x - stream_blocks) * THREADS + tid;
-            if (e < a.H * a.C) {
-                const int f = e / a.C, c = e - f * a.C, lin = a.roll_appended + f;
-                float v = 0.0f;
-                if (lin < a.H) v = a.hist [(size_t) lin * a.C + c];
-                else if (a.in && lin - a.H < a.in_frames) v = a.in [(size_t)(lin - a.H) * a.C + c];
-                a.roll_dst [e] = v;
-            }
+    // the history roll: every workgroup its share
+    if (a.roll_dst) {
+        for (int e = (int) blockIdx.x * THREADS + tid; e < a.H * a.C; e += (int) gridDim.x * THREADS) {
+            const int f = e / a.C, c = e - f * a.C, lin = a.roll_appended + f;
+            float v = 0.0f;
+            if (lin < a.H) v = a.hist [(size_t) lin * a.C + c];
+            else if (a.in && lin - a.H < a.in_frames) v = a.in [(size_t)(lin - a.H) * a.C + c];
+            a.roll_dst [e] = v;
         }
+    }
+    const int W = sl.wgs_per_xcd;
+    // (stand-by: as fir_i8_stream_kernel — the f32 streaming kernel's tile loop on this kernel's workgroups and LDS)
+    if (*q.flag == q.epoch) {
+        constexpr int MF_PPW = MF_COLS / CG > MF_MAX_PPW ? MF_MAX_PPW : MF_COLS / CG;
+        (void) MF_PPW;
+        stand_by_tiles<CG, PASS> (a, g, W, *reinterpret_cast<float (*) [2] [32 * MF_LD]> (&smem_ [0]), *reinterpret_cast<float (*) [2] [MF_COLS * MF_LD]> (&smem_ [SL_BUF]));
         return;
     }
-    if (*q.flag == q.epoch) return;                           // (samples the digits cannot hold: fir_i8_standby_kernel's launch)
 
     const int xcd = blockIdx.x & 7, rank = blockIdx.x >> 3;
-    const int tiles_per_xcd = q.sg_per_xcd * q.g * q.tiles;
-    const int nchunks = q.ktot / I8_KC;
-
-    // tile `within` of this XCD's list -> (tile of 64 slots, first period); false if the tile holds no output of the launch
-    auto tile_at = [&] (int within, int &st, int &j0) -> bool {
+    const int nsub = q.ktot / I8_KC, nch = (nsub + 1) >> 1;    // 32-tap images per tile; 64-tap chunks (the last may hold one image)
+    const int L = sl.live [xcd];
+    if (L <= 0) return;
+    // ---- this workgroup's work: D whole tiles (rank, rank + W, ...), then chunks [lo, hi) of the run of S tiles behind them
+    int D, S;
+    {
+        const int R = L / W, rem = L - R * W;
+        D = rem ? (R > 0 ? R - 1 : 0) : R;
+        S = L - D * W;
+    }
+    const int Ct = S * nch, Weff = S ? (W < Ct ? W : Ct) : 1;
+    const int lo = S && rank < Weff ? (rank * Ct) / Weff : 0, hi = S && rank < Weff ? ((rank + 1) * Ct) / Weff : 0;
+    const int t_first = lo / nch, t_last = hi > lo ? (hi - 1) / nch : t_first - 1;
+    const int nseg = D + (t_last - t_first + 1);
+    if (nseg == 0) return;
+    // segment k -> tile of the XCD's list and its chunks [c0, c1)
+    auto segment = [&] (int k, int &within, int &c0, int &c1) {
+        if (k < D) { within = rank + k * W; c0 = 0; c1 = nch; }
+        else {
+            const int t = t_first + (k - D);
+            within = D * W + t;
+            c0 = lo - t * nch; if (c0 < 0) c0 = 0;
+            c1 = hi - t * nch; if (c1 > nch) c1 = nch;
+        }
+    };
+    auto tile_of = [&] (int within, int &st, int &j0) {
         st = within % q.tiles;
         const int t2 = within / q.tiles, jr = t2 % q.g, sg = xcd * q.sg_per_xcd + t2 / q.g;
-        if (sg >= q.super_groups) return false;
         j0 = sg * q.g * PPW + jr;
-        return a.n_begin + (unsigned int) j0 * g.P + (unsigned int)(st * 64) < a.n_end;
     };
-    int my_tiles = 0;
-    { int st, j0; for (int w = rank; w < tiles_per_xcd; w += wgs_per_xcd) my_tiles += tile_at (w, st, j0) ? 1 : 0; }
-    if (my_tiles == 0) return;
-    const int total = my_tiles * nchunks;                     // chunks of this workgroup's stream
 
-    // ---- this wave's share of the staging: rows, pieces 2 wave and 2 wave + 1 of the chunk's 8 KB (one address, the second piece
-    // 1 KB on in memory and in the LDS alike: the instruction's own offset); X, 4-tap blocks 2 wave and 2 wave + 1 of every plane
-    // (64 lanes = 2 blocks x 32 column quads = 1 KB, lane-linear in the LDS).  The stream's tile has one resource for its rows and
-    // one for its X planes; a chunk is an offset added to the lanes' addresses.
+    // ---- this wave's share of the staging, per 32-tap image: piece `wave` of the rows' 8 KB; of every X plane, 4-tap blocks
+    // 2 (wave & 3) and + 1 of column half wave >> 2 (64 lanes = 2 blocks x 32 column quads = 1 KB, lane-linear in the LDS)
     constexpr int VPF = CG / 4;                               // 16-byte vectors per 4-frame block of the stream
     constexpr unsigned int A_STEP = 8192u, B_STEP = (I8_KC / 4) * CG * 4u;
-    const int kb = 2 * wave + (lane >> 5), colquad = lane & 31, m = colquad / VPF, cv = colquad - m * VPF;
+    const int kb = 2 * (wave & 3) + (lane >> 5), colquad = (wave >> 2) * 32 + (lane & 31), m = colquad / VPF, cv = colquad - m * VPF;
     const unsigned int boff = (unsigned int)((m * q.gq4 + kb) * CG + cv * 4) * 4u;           // (the tile's first block sits in the resource base)
-    const unsigned int a_off = (unsigned int)(wave * 2048 + lane * 16);
+    const unsigned int a_off = (unsigned int)(wave * 1024 + lane * 16);
     // a column whose period lies d exponent blocks behind the tile's first column stages from that block's own planes: d regions
     // further on, where the same 4-frame block sits d * eb_step blocks earlier
     const unsigned int x_total = 4u * q.eb_plane_bytes;
@@ -929,75 +971,94 @@ void fir_i8_wide_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
     // (the tile table through the scalar cache: a vector load here would sit on the VM counter among the DMAs)
     const __attribute__ ((address_space (4))) int *tile_w0 = (const __attribute__ ((address_space (4))) int *) g.tile_w0;
 
-    int f_within = rank - wgs_per_xcd, f_chunk = 0;
+    int f_seg = -1, f_ch = 0, f_c1 = 0;
     __amdgpu_buffer_rsrc_t f_ra = make_rsrc (nullptr, 0u), f_rb = f_ra;
     unsigned int f_va = 0u, f_vb = 0u;                        // the lanes' offsets of the stream's next chunk
-    auto open_tile = [&] () {                                 // next tile of this workgroup's list that holds outputs (there is one)
-        int st = 0, j0 = 0;
-        for (f_within += wgs_per_xcd; f_within < tiles_per_xcd; f_within += wgs_per_xcd)
-            if (tile_at (f_within, st, j0)) break;
+    auto open_segment = [&] () {                              // the next segment of this workgroup's list (there is one)
+        int within, st, j0, c0;
+        ++f_seg;
+        segment (f_seg, within, c0, f_c1);
+        tile_of (within, st, j0);
         const int la = max (tile_w0 [3 * (2 * st)] + j0 * g.Q + I8_PADF, 0);     // (the origin of the pair's first 32-row slot tile)
         const int eb = j0 / q.eb_periods;
         unsigned int skip = (unsigned int) max ((la >> 2) - q.b0 - eb * q.eb_step, 0) * (unsigned int)(CG * 4);
         if (skip > q.eb_plane_bytes) skip = q.eb_plane_bytes;
         const size_t from = (size_t) eb * x_total + skip;
         f_rb = make_rsrc (q.x_planes + from, (unsigned int) min (q.x_bytes - from, (size_t) 0xfffffff0u));
-        const unsigned int fa_bytes = (unsigned int) nchunks * A_STEP;
+        const unsigned int fa_bytes = (unsigned int) nsub * A_STEP;
         f_ra = make_rsrc (q.a_planes + (size_t)(st * q.g + j0 % q.g) * fa_bytes, fa_bytes);
-        f_va = a_off;
-        f_vb = boff + (unsigned int)((j0 + m * q.g) / q.eb_periods - eb) * eb_hop;
-        f_chunk = 0;
+        f_ch = c0;
+        f_va = a_off + (unsigned int)(2 * c0) * A_STEP;
+        f_vb = boff + (unsigned int)((j0 + m * q.g) / q.eb_periods - eb) * eb_hop + (unsigned int)(2 * c0) * B_STEP;
     };
-    // the stream's next chunk -> LDS buffer `buf`: 6 DMA instructions of this wave
-    auto issue = [&] (int buf) {
-        const lds_ptr_t la_ = (lds_ptr_t)(As_ + buf * A_BUF + wave * 2048);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds (f_ra, la_, 16, (int) f_va, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds (f_ra, la_, 16, (int) f_va, 0, 1024, 0);
-#pragma unroll
-        for (int pn = 0; pn < 4; ++pn)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds (f_rb, (lds_ptr_t)(Bs_ + buf * B_BUF + pn * 4096 + wave * 1024), 16, (int) f_vb, pn * plane_step, 0, 0);
-        f_va += A_STEP; f_vb += B_STEP;
+    // The stream's next chunk -> LDS buffer `buf`: 10 DMA pieces of this wave, piece 5 im + 0 = the rows' of 32-tap image im, 5 im + 1 + pn
+    // = X plane pn's (an image past the tile's K range: out of the rows' resource, zeros; it is not multiplied).  The pieces are
+    // issued one by one BETWEEN the products of the current chunk's first image: a piece costs the issuing wave tens of cycles, and
+    // all eight waves issuing theirs together right behind the barrier left the matrix pipes idle for a third of every chunk.
+    // next_chunk () moves the stream on (scalar work, behind the barrier) and says where the pieces go; past the end of the stream
+    // the resources are empty and the pieces fetch nothing.
+    int total = D * nch + (hi - lo), issued = 0;              // chunks of this workgroup's stream; handed to the DMA so far
+    unsigned int d_va = 0u, d_vb = 0u;                        // the lanes' offsets of the chunk being issued
+    auto next_chunk = [&] () {
+        if (issued < total) {
+            if (f_seg < 0 || f_ch == f_c1) open_segment ();
+            d_va = f_va; d_vb = f_vb;
+            f_va += 2 * A_STEP; f_vb += 2 * B_STEP;
+            ++f_ch; ++issued;
+        }
+        else { f_ra = make_rsrc (nullptr, 0u); f_rb = f_ra; }
+    };
+    auto piece = [&] (int buf, int idx) {
+        const int im = idx / 5, pc = idx % 5;
+        unsigned char *img = smem_ + buf * SL_BUF + im * SL_IMG;
+        if (pc == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds (f_ra, (lds_ptr_t)(img + wave * 1024), 16, (int)(d_va + (unsigned int) im * A_STEP), 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds (f_rb, (lds_ptr_t)(img + SL_A_IMG + (pc - 1) * 8192 + wave * 1024), 16, (int)(d_vb + (unsigned int) im * B_STEP), (pc - 1) * plane_step, 0, 0);
     };
 
-    {   // the two workgroups of a CU share each SIMD's matrix pipe: left alone their waves fall into step (both multiply, then both
-        // wait for the LDS and the barrier); different issue priorities make them alternate instead
-        const unsigned int hw_id = __builtin_amdgcn_s_getreg ((4 - 1) << 11 | 16 << 6 | 4);      // HW_ID.TG_ID: bits 19:16
-        if (hw_id & 1u) __builtin_amdgcn_s_setprio (3); else __builtin_amdgcn_s_setprio (0);
+    {   // the two waves of a SIMD share its matrix pipe: left alone they fall into step (both read, then both multiply);
+        // different issue priorities make them alternate instead
+#ifndef I8_SLAB_PRIO
+#define I8_SLAB_PRIO 1
+#endif
+        if (I8_SLAB_PRIO == 1) { if (wave & 4) __builtin_amdgcn_s_setprio (2); else __builtin_amdgcn_s_setprio (0); }
     }
     const int col = wave * 32 + (lane & 31);
     const int jl = col / CG, c = col - jl * CG;
-    // A image of a chunk [plane][16-tap half][row 0..63][16 taps]; B image [plane][4-tap block][column][4 taps]
-    const unsigned char *Ab0 = As_ + (lane >> 5) * 1024 + (lane & 31) * 16;
-    const unsigned char *Bb0 = Bs_ + (lane >> 5) * 2048 + col * 4;
+    // rows' image [plane][16-tap half][row 0..63][16 taps]; X image [plane][column half][4-tap block][column 0..127][4 taps]
+    const unsigned char *Ab0 = smem_ + (lane >> 5) * 1024 + (lane & 31) * 16;
+    const unsigned char *Bb0 = smem_ + SL_A_IMG + (wave >> 2) * 4096 + (lane >> 5) * 2048 + (col & 127) * 4;
     // output offset of this lane inside a tile: (period jl * g, slot 4 * (lane >> 5), channel c); the row's own 0..3 / +8 / +16 / +24
     // (+ 32 for the second register tile) slots are immediates of the store
     const unsigned int out_off = (unsigned int)((jl * q.g * g.P + 4 * (lane >> 5)) * CG + c) * 4u;
 
-    // ---- the stream: chunk s is staged into LDS buffer s % 3 two iterations before it is multiplied
-    open_tile ();
-    int issued = 0;                                           // chunks handed to the DMA so far
-    auto issue_next = [&] (int buf) {
-        if (issued < total) {
-            if (f_chunk == nchunks) open_tile ();
-            issue (buf);
-            ++f_chunk; ++issued;
-        }
-    };
-    issue_next (0);
-    issue_next (1);
-    int fill = 2, qb = 0;                                     // LDS buffers of the chunk two ahead and of the current chunk
-    int since_stores = 2;                                     // chunks since a tile's stores were issued (2: none in flight)
-    int done = 0;                                             // chunks multiplied so far
+    // ---- the stream.  Chunk s of it sits in LDS buffer s & 1.  Between two barriers a wave multiplies the SECOND image of a chunk,
+    // whose operands it read before the barrier, and the FIRST image of the next: at the barrier every wave has read the whole of
+    // chunk s — its buffer is free for the pieces of chunk s + 2, issued between the products behind the barrier — and has seen its
+    // own pieces of chunk s + 1 land.  (With the barrier between a chunk's reads and the chunk before, all eight waves read
+    // operands at the same moment and the matrix pipes idled through every chunk's first read.)
+    next_chunk ();
+#pragma unroll
+    for (int idx = 0; idx < 10; ++idx) piece (0, idx);
+    asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier ();                            // chunk 0 has landed
+    asm volatile ("" ::: "memory");
+    next_chunk ();
+#pragma unroll
+    for (int idx = 0; idx < 10; ++idx) piece (1, idx);
+    int cur = 0;                                              // LDS buffer of the current chunk
+#ifdef I8_SLAB_TRACE
+    long long tr_ [16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, tp_ = (long long) __builtin_readcyclecounter ();
+    const long long tr_begin = tp_, tr_real = (long long) __builtin_amdgcn_s_memrealtime ();
+#define TR(i) do { const long long n_ = (long long) __builtin_readcyclecounter (); tr_ [i] += n_ - tp_; tp_ = n_; } while (0)
+#else
+#define TR(i) do { } while (0)
+#endif
+    bool stores_behind = false;                               // a tile's 32 stores were issued behind the pieces in flight
 
-    for (int within = rank; within < tiles_per_xcd; within += wgs_per_xcd) {
-        int st, j0;
-        if (!tile_at (within, st, j0)) continue;
-        // rows carry 30 fraction bits, this lane's channel 2^shift in its period's exponent block; the class sums are combined at
-        // weight 256^(4 - s) in units of 2^16: the result is scaled by 2^(-14 - shift).  (The load is issued by hand behind the
-        // first chunk's barrier, older than the DMAs issued after it: it has landed by the second chunk's counted wait, and the
-        // compiler, which does not see it, drains nothing for it)
-        const int *shift_at = q.shifts + ((j0 + jl * q.g) / q.eb_periods) * CG + c;
-        int shift_v = 0;
+    for (int k = 0; k < nseg; ++k) {
+        int within, c0, c1, st, j0;
+        segment (k, within, c0, c1);
+        tile_of (within, st, j0);
         i32x16 acc [2] [5];
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -1005,131 +1066,235 @@ void fir_i8_wide_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
             for (int s = 0; s < 5; ++s)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc [h] [s] [r] = 0;
-        // chunks in which some row of a register tile has a non-zero most significant digit (the few around the rows' centres:
+        // images in which some row of a register tile has a non-zero most significant digit (the few around the rows' centres:
         // taps fall off as 1 / distance): everywhere else the four products with that digit plane are exactly zero and not issued
-        // (through the scalar cache, like the tile table: an ordinary vector load would make the compiler drain the VM counter —
-        // DMAs and all — before its first use)
+        // (through the scalar cache, like the tile table)
         unsigned long long top [2];
         {
             const __attribute__ ((address_space (4))) unsigned long long *tm = (const __attribute__ ((address_space (4))) unsigned long long *) q.tile_masks + (st * q.g + j0 % q.g) * 2;
             top [0] = tm [0]; top [1] = tm [1];
         }
+        // this lane's channel's exponent in its period's block: loaded now, taken up behind the wait in front of the tile's first
+        // barrier (where this wave drains its memory operations anyway) — nothing in flight is waited for on its account later
+        int shift_v = q.shifts [((j0 + jl * q.g) / q.eb_periods) * CG + c];
 
-        for (int ch = 0; ch < nchunks; ++ch, ++done) {
-            // this wave's part of the current chunk has landed once nothing older than the next chunk's 6 DMAs (and a just finished
-            // tile's 32 stores) is outstanding
-            if (done + 1 >= issued) asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (since_stores < 2) asm volatile ("s_waitcnt vmcnt(38)" ::: "memory");
-            else asm volatile ("s_waitcnt vmcnt(6)" ::: "memory");
-            __builtin_amdgcn_s_barrier ();                    // every wave's part has; and every wave has read the chunk before
-            asm volatile ("" ::: "memory");
-            if (ch == 0) asm volatile ("global_load_dword %0, %1, off" : "=v" (shift_v) : "v" (shift_at) : "memory");
-            issue_next (fill);                                // the chunk two ahead -> the buffer the chunk before this one has left
-            fill = fill == NBUF - 1 ? 0 : fill + 1;
-            since_stores = since_stores < 2 ? since_stores + 1 : 2;
-
-            const unsigned char *Ab = Ab0 + qb * A_BUF, *Bb = Bb0 + qb * B_BUF;
-            qb = qb == NBUF - 1 ? 0 : qb + 1;
-            i32x4 av [2] [4], bv [4];
+        i32x4 av [2] [4], bv [4];
+        auto read_image = [&] (int im) {
+            const unsigned char *Ab = Ab0 + cur * SL_BUF + im * SL_IMG, *Bb = Bb0 + cur * SL_BUF + im * SL_IMG;
 #pragma unroll
             for (int pn = 0; pn < 4; ++pn) {
                 av [0] [pn] = *reinterpret_cast<const i32x4 *> (Ab + pn * 2048);
                 av [1] [pn] = *reinterpret_cast<const i32x4 *> (Ab + pn * 2048 + 512);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) bv [pn] [i] = *reinterpret_cast<const int *> (Bb + pn * 4096 + i * 512);
+                for (int i = 0; i < 4; ++i) bv [pn] [i] = *reinterpret_cast<const int *> (Bb + pn * 8192 + i * 512);
             }
-            __builtin_amdgcn_sched_group_barrier (0x100, 16, 0);
-            asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        // the products of one image; PIECES: a DMA piece of the stream's next-but-one chunk -> buffer `to` behind every second product
+        auto products = [&] (int sub, auto with_pieces, int to) {
+            constexpr bool PIECES = decltype (with_pieces)::value;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
+                int n = 0;                                    // products issued so far in this register tile's block
 #pragma unroll
                 for (int i = 1; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (i + j <= 4) acc [h] [i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8 (av [h] [i], bv [j], acc [h] [i + j], 0, 0, 0);
-                if ((top [h] >> ch) & 1ull) {
+                        if (i + j <= 4) {
+                            acc [h] [i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8 (av [h] [i], bv [j], acc [h] [i + j], 0, 0, 0);
+                            ++n;
+                            if (PIECES && (n == 2 || n == 4 || n == 6 || n == 8 || n == 9)) piece (to, h * 5 + (n == 9 ? 4 : n / 2 - 1));
+                        }
+                if (PIECES) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { __builtin_amdgcn_sched_group_barrier (0x008, 2, 0); __builtin_amdgcn_sched_group_barrier (0x020, 1, 0); }
+                    __builtin_amdgcn_sched_group_barrier (0x008, 1, 0); __builtin_amdgcn_sched_group_barrier (0x020, 1, 0);
+                }
+                if ((top [h] >> sub) & 1ull) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc [h] [j] = __builtin_amdgcn_mfma_i32_32x32x32_i8 (av [h] [0], bv [j], acc [h] [j], 0, 0, 0);
                 }
             }
+        };
+
+        for (int ch = c0; ch < c1; ++ch) {
+            TR (0);                                           // (0: everything between chunks — tile set-up, epilogue, exchange)
+            // ---- the chunk's first image
+            read_image (0);
+            __builtin_amdgcn_sched_group_barrier (0x100, 16, 0);
+            products (2 * ch, std::false_type {}, 0);
+            TR (4);
+            // ---- its second image (a tile's last chunk may have none): operands now, products behind the barrier
+            const bool two = 2 * ch + 1 < nsub;
+            if (two) read_image (1);
+            asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the chunk has been read: its buffer may be written again)
+            // this wave's pieces of the next chunk have landed once nothing but a just finished tile's 32 stores, issued behind them,
+            // is outstanding
+            if (stores_behind) asm volatile ("s_waitcnt vmcnt(32)" ::: "memory");
+            else asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+            stores_behind = false;
+            if (ch == c0) asm volatile ("" : "+v" (shift_v));   // (the exponent's load is waited for here)
+            TR (1);                                           // (1: reading the second image, waiting for this wave's pieces)
+            __builtin_amdgcn_s_barrier ();
+            asm volatile ("" ::: "memory");
+            TR (2);                                           // (2: the barrier)
+            next_chunk ();                                    // the stream's next-but-one chunk -> the buffer just read
+            TR (3);                                           // (3: moving the stream on)
+            if (two) products (2 * ch + 1, std::true_type {}, cur);
+            else {
+#pragma unroll
+                for (int idx = 0; idx < 10; ++idx) piece (cur, idx);
+            }
+            TR (5);
+            asm volatile ("" ::: "memory");
+            cur ^= 1;
         }
 
-        // ---- the tile's outputs: C/D layout of 32x32: row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31
+        // ---- the tile's outputs.  (In flight: the 10 pieces issued between the last products; they stay in flight.)
+        TR (0);
+        long long tot [2] [16];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tot [h] [r] = i8_total (acc [h] [0] [r], acc [h] [1] [r], acc [h] [2] [r], acc [h] [3] [r], acc [h] [4] [r]);
+        TR (9);
+        if (c0 != 0 || c1 != nch) {
+            // ---- part of a tile: leave the sums, count the arrival; the last wave to arrive goes on with everybody's
+            constexpr int COHERENT = 1 | 16;                 // (aux bits of the raw buffer instructions on gfx940+: sc0, sc1)
+            const int t = within - D * W;
+            auto owner_of = [&] (int chunk) {                 // the workgroup whose range holds this chunk of the run
+                int r = (int)(((long long) chunk * Weff) / Ct);
+                while (r + 1 < Weff && ((r + 1) * Ct) / Weff <= chunk) ++r;
+                return r;
+            };
+            const int r_first = owner_of (t * nch), r_last = owner_of ((t + 1) * nch - 1);
+            const unsigned int wave_bytes = 16u * 64u * 16u;
+            {
+                const int which = k == D ? 0 : 1;
+                const __amdgpu_buffer_rsrc_t rs_part = make_rsrc (sl.parts + ((size_t)((xcd * W + rank) * 2 + which) * 8 + wave) * wave_bytes, wave_bytes);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    u32x4 v;
+                    const unsigned long long x0 = (unsigned long long) tot [0] [r], x1 = (unsigned long long) tot [1] [r];
+                    v.x = (unsigned int) x0; v.y = (unsigned int)(x0 >> 32); v.z = (unsigned int) x1; v.w = (unsigned int)(x1 >> 32);
+                    __builtin_amdgcn_raw_buffer_store_b128 (v, rs_part, (r * 64 + lane) * 16, 0, COHERENT);
+                }
+            }
+            asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");       // (written through: the count below is only seen behind them)
+            unsigned int *count = sl.arrivals + ((size_t)(xcd * SL_MAX_SK + t) * 8 + wave);
+            unsigned int before = 0u;
+            if (lane == 0) before = __hip_atomic_fetch_add (count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            before = (unsigned int) __builtin_amdgcn_readfirstlane ((int) before);
+            if (before != (unsigned int)(r_last - r_first)) { TR (10); continue; }
+            if (lane == 0) __hip_atomic_store (count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // (for the next launch)
+            for (int rr = r_first; rr <= r_last; ++rr) {
+                if (rr == rank) continue;
+                const int which = (rr * Ct) / Weff / nch == t ? 0 : 1;      // (that workgroup's first tile of the run, or its last)
+                const __amdgpu_buffer_rsrc_t rs_part = make_rsrc (sl.parts + ((size_t)((xcd * W + rr) * 2 + which) * 8 + wave) * wave_bytes, wave_bytes);
+                u32x4 v [16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v [r] = __builtin_amdgcn_raw_buffer_load_b128 (rs_part, (r * 64 + lane) * 16, 0, COHERENT);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    tot [0] [r] += (long long)((unsigned long long) v [r].x | (unsigned long long) v [r].y << 32);
+                    tot [1] [r] += (long long)((unsigned long long) v [r].z | (unsigned long long) v [r].w << 32);
+                }
+            }
+        }
+        TR (10);
+        // rows carry 30 fraction bits, this lane's channel 2^shift in its period's exponent block; the total is in units of
+        // 2^-30 x 2^-shift x 2^16 (the class weights 256^(4 - s) are relative to the least significant kept class): scaled by
+        // 2^(-14 - shift), a power of two, and rounded ONCE to float
+        const int out_exp = -14 - shift_v;
         const unsigned int n_tile = a.n_begin + (unsigned int) j0 * g.P + (unsigned int)(st * 64);
         const int rows_valid = min (64, g.P - st * 64);
         const size_t left = (size_t)(a.n_end - n_tile) * CG * 4;
         const __amdgpu_buffer_rsrc_t rs_out = make_rsrc (a.out + (size_t) n_tile * CG, left > 0xffffff00ull ? 0xffffff00u : (unsigned int) left);
-        const int out_exp = -14 - shift_v;
+        float y [2] [16];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const unsigned int pass_rows = PASS && 2 * st + h < g.slot_tiles ? (unsigned int) tile_w0 [3 * (2 * st + h) + 1] : 0u;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int i_const = h * 32 + (r & 3) + 8 * (r >> 2);      // compile-time part of the slot
-                double v = (double) acc [h] [0] [r];
-#pragma unroll
-                for (int s = 1; s < 5; ++s) v = v * 256.0 + (double) acc [h] [s] [r];
-                float y = (float) __builtin_ldexp (v, out_exp);
-                const int i = i_const + 4 * (lane >> 5);
+                y [h] [r] = i8_round (tot [h] [r], out_exp);
                 if constexpr (PASS) {
+                    const int i = h * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    // nearest-filter mode, the position falls exactly on an input sample: the reference copies it (resampler.c:1141-1142)
                     if ((pass_rows >> (i & 31)) & 1u)
-                        y = load_frame (a, INT_MIN, g.canon_ip [st * 64 + i] + g.canon_fi [st * 64 + i] / a.F + (j0 + jl * q.g) * g.Q, c);
+                        y [h] [r] = load_frame (a, INT_MIN, g.canon_ip [st * 64 + i] + g.canon_fi [st * 64 + i] / a.F + (j0 + jl * q.g) * g.Q, c);
                 }
-                // (always 32 store instructions per tile — the counted waits rely on it: a slot past the period goes out of the
-                // resource's range, as frames at or past n_end do, and is dropped)
-                const unsigned int off = i < rows_valid ? out_off + (unsigned int)(i_const * CG) * 4u : 0xfffffff0u;
-                __builtin_amdgcn_raw_buffer_store_b32 (__float_as_uint (y), rs_out, (int) off, 0, 0);
             }
         }
-        since_stores = 0;
+        // (the 32 stores go out together and stay in flight, behind the pieces issued before them)
+        TR (11);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i_const = h * 32 + (r & 3) + 8 * (r >> 2);      // compile-time part of the slot
+                const int i = i_const + 4 * (lane >> 5);
+                // (always 32 store instructions per tile — the counted wait relies on it: a slot past the period goes out of the
+                // resource's range, as frames at or past n_end do, and is dropped)
+                const unsigned int off = i < rows_valid ? out_off + (unsigned int)(i_const * CG) * 4u : 0xfffffff0u;
+                __builtin_amdgcn_raw_buffer_store_b32 (__float_as_uint (y [h] [r]), rs_out, (int) off, 0, 0);
+            }
+        stores_behind = true;
+        TR (12);
     }
     asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef I8_SLAB_TRACE
+    TR (0);
+    tr_ [6] = tp_ - tr_begin; tr_ [7] = (long long) total; tr_ [15] = (long long) __builtin_amdgcn_s_memrealtime () - tr_real;
+    if (lane == 0) for (int i = 0; i < 16; ++i) sl.trace [((size_t) blockIdx.x * 8 + wave) * 16 + i] = tr_ [i];
+#endif
+#undef TR
 }
 
-// The stand-by of fir_i8_wide_kernel, launched behind it: a launch whose samples the digits cannot hold (flag raised by the staging
-// pass) is produced in f32 by the streaming kernel's own tile loop, from the tables the staging pass has left for it — the bits
-// of fir_mfma_stream_kernel.  Every other launch: the workgroups read the flag and leave.
-template <int CG, bool PASS>
-__global__ __launch_bounds__ (2 * MF_THREADS)
-void fir_i8_standby_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
-{
-    if (*q.flag != q.epoch) return;
-    __shared__ __attribute__ ((aligned (16))) float As_ [2] [32 * MF_LD];
-    __shared__ __attribute__ ((aligned (16))) float Bs_ [2] [MF_COLS * MF_LD];
-    stand_by_tiles<CG, PASS> (a, g, wgs_per_xcd, As_, Bs_);
-}
 
 } // namespace
 
-// 64-slot tiles (fir_i8_wide_kernel) for streams whose 4-frame blocks are whole 16-byte vectors: ARTAMD_I8_WIDE=1.  Off by default:
-// the kernel is correct (the same bits as the 32-slot kernels: exact integer sums) and moves 40 % fewer bytes into the LDS per
-// product, but measures the same 97 us on the headline launch (profiles/r3_wide_tiles_experiment.txt) and costs a launch more.
-bool artfir_i8_wide_enabled ()
+// Slabs (fir_i8_slab_kernel: tiles of 64 slots x 256 columns, one workgroup per CU, tiles cut to the launch) for streams whose
+// 4-frame blocks are whole 16-byte vectors.  ARTAMD_I8_SLAB=0 (or ARTAMD_I8_DMA=0) switches them off — the 32-slot kernels then
+// run every launch, and periods are taken so as to fill THEIR tiles (A/B runs; the results are the same bits either way).
+bool artfir_i8_slab_enabled ()
 {
-    static const bool on = [] { const char *e = getenv ("ARTAMD_I8_WIDE"); const char *d = getenv ("ARTAMD_I8_DMA"); return e && *e == '1' && !(d && *d == '0'); } ();
+    static const bool on = [] { const char *e = getenv ("ARTAMD_I8_SLAB"); const char *d = getenv ("ARTAMD_I8_DMA"); return !(e && *e == '0') && !(d && *d == '0'); } ();
     return on;
 }
-static bool i8_wide_tiles (int cgt) { return artfir_i8_wide_enabled () && cgt >= 4; }
+// slabs per XCD from which a launch is given to the slab kernel (below: more, smaller tiles fill the chip better)
+static int i8_slab_min_tiles ()
+{
+    static const int v = [] { const char *e = getenv ("ARTAMD_I8_SLAB_MIN"); return e && *e ? atoi (e) : 8; } ();
+    return v;
+}
 
 // The planes buffer of a launch: [header: flag (art_internal.h)][row masks][exponents][A digit planes][X digit planes per exponent block];
 // returns its size, 0 if the launch is not for this path
 static size_t i8_layout (const ArtFirArgs *a, const MfmaGeom &g, int cgt, I8Geom &q, char *base, unsigned int outputs = 0)
 {
     if (!cgt || g.tile_rows != 32 || (g.ktot % I8_KC)) return 0;
-    q.tr = i8_wide_tiles (cgt) ? 64 : 32;
+    // (outputs != 0: sizing a call's buffer before its launches are cut — any launch of the call has at most this many periods)
+    const unsigned int total = outputs ? outputs + (unsigned int) g.P : a->n_end - a->n_begin, periods = (total + g.P - 1) / g.P;
+    const int gg = (g.Q % 4 == 0) ? 1 : (g.Q % 2 == 0) ? 2 : 4;
+    q.tr = 32; q.cols = I8_COLS;
+    if (artfir_i8_slab_enabled () && cgt >= 4) {
+        // slabs where the launch has enough of them (decided from this context's own columns: every fixed-point kernel leaves the
+        // same bits, so a shard need not decide as its stream would)
+        const int ppw64 = SL_COLS / cgt;
+        const int sgs = (int)((periods + (unsigned int)(gg * ppw64) - 1) / (unsigned int)(gg * ppw64));
+        const int per_xcd = ((sgs + 7) / 8) * gg * ((g.P + 63) / 64);
+        if (per_xcd >= i8_slab_min_tiles ()) { q.tr = 64; q.cols = SL_COLS; }
+    }
     for (;;) {  // (as matrix_geometry's ktot, for tiles of tr rows; + 3: a tile's K columns start on a 4-frame block, up to 3 frames early)
         const int shift_max = (int)((q.tr - 1.0) * g.Q / g.P) + 2;
         q.ktot = ((a->T + shift_max + 3 + I8_KC - 1) / I8_KC) * I8_KC;
-        // (the 64-slot kernel's counted waits want three chunks per tile; and one mask bit per chunk)
-        if (q.tr == 64 && (q.ktot / I8_KC < 3 || q.ktot / I8_KC > 64)) { q.tr = 32; continue; }
+        // (the slab kernel wants a few chunks per tile; and one mask bit per 32-tap image)
+        if (q.tr == 64 && (q.ktot / I8_KC < 4 || q.ktot / I8_KC > 64)) { q.tr = 32; q.cols = I8_COLS; continue; }
         break;
     }
     q.tiles = (g.P + q.tr - 1) / q.tr;
-    const int ppw = I8_COLS / cgt > I8_MAX_PPW ? I8_MAX_PPW : I8_COLS / cgt;
+    const int ppw = q.cols / cgt > I8_MAX_PPW ? I8_MAX_PPW : q.cols / cgt;
     q.g = (g.Q % 4 == 0) ? 1 : (g.Q % 2 == 0) ? 2 : 4;
     q.gq4 = q.g * g.Q / 4;
-    // (outputs != 0: sizing a call's buffer before its launches are cut — any launch of the call has at most this many periods)
-    const unsigned int total = outputs ? outputs + (unsigned int) g.P : a->n_end - a->n_begin, periods = (total + g.P - 1) / g.P;
     q.super_groups = (int)((periods + (unsigned int)(q.g * ppw) - 1) / (unsigned int)(q.g * ppw));
     q.sg_per_xcd = (q.super_groups + 7) / 8;
     if (q.ktot / I8_KC > 64) return 0;                                  // (one mask bit per chunk)
@@ -1170,7 +1335,9 @@ static size_t i8_layout (const ArtFirArgs *a, const MfmaGeom &g, int cgt, I8Geom
     q.shifts = (int *)(base + ART_I8_HEAD_BYTES + masks + teams);
     q.a_planes = (unsigned char *) base + head;
     q.x_planes_w = (unsigned int *)(base + head + a_bytes); q.x_planes = (const unsigned char *) q.x_planes_w;
-    return head + a_bytes + q.x_bytes;
+    // (slabs: behind the planes, the parts of the tiles that are cut between workgroups — two per workgroup)
+    q.parts = q.tr == 64 ? (unsigned char *) base + ((head + a_bytes + q.x_bytes + 255) & ~(size_t) 255) : nullptr;
+    return q.tr == 64 ? ((head + a_bytes + q.x_bytes + 255) & ~(size_t) 255) + (size_t) 8 * SL_WGS * 2 * SL_PART_BYTES : head + a_bytes + q.x_bytes;
 }
 
 size_t artfir_i8_bytes (const ArtFirArgs *a, const MfmaGeom &g, int cgt, unsigned int outputs)
@@ -1223,19 +1390,56 @@ int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGe
     { static const int k_env = [] { const char *e = getenv ("ARTAMD_I8_WGS"); return e && *e ? atoi (e) : 0; } (); if (k_env > 0 && k_env < tiles_per_xcd) wgs_per_xcd = k_env; }
     const bool pass = !a->interpolate && !a->lowpass;
     if (q.tr == 64) {
-        // 64-slot tiles: four-wave workgroups (the roll's extra workgroups counted for 256 threads), and the stand-by as a launch of
-        // its own behind the kernel — one workgroup per CU, which reads the flag and leaves
-        const unsigned int roll256 = a->roll_dst ? (unsigned int)((a->H * a->C + MF_THREADS - 1) / MF_THREADS) : 0u;
-        const dim3 wgrid ((unsigned int)(8 * wgs_per_xcd) + roll256);
-        const int sb_tiles = g.groups_per_xcd * g.slot_tiles, sb_wgs = sb_tiles < 32 ? sb_tiles : 32;
-        const dim3 sbgrid ((unsigned int)(8 * sb_wgs));
-#define I8_WIDE(CGT) do { if (pass) { hipLaunchKernelGGL ((fir_i8_wide_kernel<CGT, true>), wgrid, dim3 (MF_THREADS), 0, st, *a, g, q, wgs_per_xcd); \
-                                      hipLaunchKernelGGL ((fir_i8_standby_kernel<CGT, true>), sbgrid, dim3 (2 * MF_THREADS), 0, st, *a, g, q, sb_wgs); } \
-                          else { hipLaunchKernelGGL ((fir_i8_wide_kernel<CGT, false>), wgrid, dim3 (MF_THREADS), 0, st, *a, g, q, wgs_per_xcd); \
-                                 hipLaunchKernelGGL ((fir_i8_standby_kernel<CGT, false>), sbgrid, dim3 (2 * MF_THREADS), 0, st, *a, g, q, sb_wgs); } } while (0)
-        switch (cgt) { case 32: I8_WIDE (32); break; case 16: I8_WIDE (16); break; case 8: I8_WIDE (8); break; default: I8_WIDE (4); }
-#undef I8_WIDE
+        // slabs: one eight-wave workgroup per CU (all of its LDS), which also rolls the history and carries the stand-by
+        I8Slab sl;
+        sl.wgs_per_xcd = SL_WGS;
+        sl.parts = q.parts;
+        sl.arrivals = (unsigned int *)((char *) a->planes + ART_I8_FLAG_BYTES);
+        {   // tiles of each XCD's list that hold outputs: a prefix of the list (a tile holds outputs iff its first column's period does)
+            const int ppw = q.cols / cgt > I8_MAX_PPW ? I8_MAX_PPW : q.cols / cgt;
+            const unsigned int n_out = a->n_end - a->n_begin;
+            for (int x = 0; x < 8; ++x) {
+                int live = 0; bool prefix = true;
+                for (int w = 0; w < tiles_per_xcd; ++w) {
+                    const int stt = w % q.tiles, t2 = w / q.tiles, jr = t2 % q.g, sg = x * q.sg_per_xcd + t2 / q.g;
+                    const bool ok = sg < q.super_groups && (unsigned long long)(sg * q.g * ppw + jr) * (unsigned int) g.P + (unsigned int)(stt * 64) < n_out;
+                    if (ok) { if (live != w) prefix = false; ++live; }
+                }
+                if (!prefix) return 0;                        // (cannot happen: see the kernel's comment; the 32-slot path would be taken by the caller)
+                sl.live [x] = live;
+            }
+        }
+        const dim3 wgrid ((unsigned int)(8 * SL_WGS));
+#ifdef I8_SLAB_TRACE
+        static long long *d_trace = nullptr;
+        if (!d_trace) (void) hipMalloc (&d_trace, (size_t) 8 * SL_WGS * 8 * 16 * sizeof (long long));
+        sl.trace = d_trace;
+#endif
+#define I8_SLAB(CGT) do { if (pass) hipLaunchKernelGGL ((fir_i8_slab_kernel<CGT, true>), wgrid, dim3 (SL_THREADS), 0, st, *a, g, q, sl); \
+                          else hipLaunchKernelGGL ((fir_i8_slab_kernel<CGT, false>), wgrid, dim3 (SL_THREADS), 0, st, *a, g, q, sl); } while (0)
+        switch (cgt) { case 32: I8_SLAB (32); break; case 16: I8_SLAB (16); break; case 8: I8_SLAB (8); break; default: I8_SLAB (4); }
+#undef I8_SLAB
         if (a->ev_stop) arthip_event_record (a->ev_stop, (void *) st);
+#ifdef I8_SLAB_TRACE
+        {
+            static int n_launch = 0;
+            if (++n_launch == 40) {
+                static long long h [8 * SL_WGS * 8 * 16];
+                (void) hipStreamSynchronize (st);
+                (void) hipMemcpy (h, d_trace, sizeof (h), hipMemcpyDeviceToHost);
+                const char *names [16] = { "tile set-up", "wait own pieces", "barrier", "stream on", "image 0 (+ pieces)", "image 1", "whole kernel", "chunks",
+                                           "drain before outputs", "totals", "exchange", "round", "stores", "-", "-", "whole kernel (100 MHz)" };
+                for (int wv = 0; wv < 8; wv += 4) {
+                    fprintf (stderr, "slab trace, wave %d, mean over %d workgroups (cycles; per chunk in brackets):\n", wv, 8 * SL_WGS);
+                    double chunks = 0; for (int b = 0; b < 8 * SL_WGS; ++b) chunks += (double) h [((size_t) b * 8 + wv) * 16 + 7];
+                    for (int i = 0; i < 16; ++i) {
+                        double sum = 0, mx = 0; for (int b = 0; b < 8 * SL_WGS; ++b) { const double v = (double) h [((size_t) b * 8 + wv) * 16 + i]; sum += v; if (v > mx) mx = v; }
+                        fprintf (stderr, "   %-20s %10.0f  max %10.0f  [%8.1f]\n", names [i], sum / (8 * SL_WGS), mx, sum / chunks);
+                    }
+                }
+            }
+        }
+#endif
         return 1;
     }
     const dim3 sgrid ((unsigned int)(8 * wgs_per_xcd) + roll_blocks);

@@ -144,8 +144,11 @@ const char *artamdLastError (void);                  /* NULL while the count is 
 
 /* How many periods of an exact rational ratio (outputsPerPeriod = the numerator of the reduced ratio) the matrix-core kernels take at
  * a time: their tiles hold 32 consecutive outputs of one period, so short periods (2x conversions: 2 outputs) or badly fitting ones
- * are taken several at a time — 1 while the padding stays within 15 %.  Informational (the choice is the library's own). */
+ * are taken several at a time — 1 while the padding stays within 15 %.  Informational (the choice is the library's own: the 4-byte
+ * build applies the rule with the 64 rows of its fixed-point slab kernel's tiles, which are whole 32-row tiles too — ...Rows (p, 64) —
+ * unless ARTAMD_I8_SLAB=0). */
 int artamdPeriodMultiple (int outputsPerPeriod);
+int artamdPeriodMultipleRows (int outputsPerPeriod, int rows);
 
 /* ---- decimator, device pointers ---- */
 void decimateHipSetStream (Decimate *cxt, void *hipStream);

@@ -292,16 +292,3 @@ def test_fixed_point_long_call_with_many_ring_epochs():
     uo, go, yo = o.process(x [:n], int(n * ratio) + 4000, ratio, threads=2)
     yo = np.array(yo)
     assert tolerance_ok(outs [7] [:len(yo) - 2000], yo [:len(yo) - 2000]) [0]
-
-
-def test_the_64_slot_kernel_passes_this_file_too():
-    """ARTAMD_I8_WIDE=1 (read once per process) switches streams of 4 channels and more to fir_i8_wide_kernel — 64-slot tiles, four-wave
-    workgroups that stage for themselves, the stand-by as a launch of its own — and the period rule to 64-slot tiles: every test of this
-    file, and the short-period ratios, in a process with the switch on"""
-    import os, subprocess, sys
-    env = dict(os.environ, ARTAMD_I8_WIDE="1")
-    here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-                        os.path.join(here, "test_gpu_fixed_point.py"), os.path.join(here, "test_gpu_short_periods.py"),
-                        "-k", "not 64_slot and not the_rule"], env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -173,3 +173,10 @@ def test_period_rule_fills_the_matrix_tiles():
         padded = -(-mu * p // 32) * 32
         assert mu >= 1 and (mu == 1 or mu * p <= 512)
         assert padded / (mu * p) <= 1.15 + 1e-12, (p, mu)
+    # the same rule for the 64-row tiles of the fixed-point slab kernel (what the 4-byte build applies): 44.1k -> 48k two periods at a
+    # time, 96k -> 44.1k three; whatever fills 64-row tiles within 15 % fills 32-row tiles within 15 % too
+    assert [L.artamdPeriodMultipleRows(p, 64) for p in (160, 147, 2, 1, 80, 320, 64)] == [2, 3, 32, 64, 4, 1, 1]
+    for p in range(1, 700):
+        mu = L.artamdPeriodMultipleRows(p, 64)
+        assert mu >= 1 and (mu == 1 or mu * p <= 1024)
+        assert -(-mu * p // 64) * 64 / (mu * p) <= 1.15 + 1e-12 and -(-mu * p // 32) * 32 / (mu * p) <= 1.15 + 1e-12, (p, mu)
