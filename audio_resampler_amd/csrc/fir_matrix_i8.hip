@@ -1044,7 +1044,7 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
     asm volatile ("" ::: "memory");
     next_chunk ();
 #pragma unroll
-    for (int idx = 0; idx < 10; ++idx) piece (1, idx);
+    for (int idx = 0; idx < 5; ++idx) piece (1, idx);
     int cur = 0;                                              // LDS buffer of the current chunk
 #ifdef I8_SLAB_TRACE
     long long tr_ [16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, tp_ = (long long) __builtin_readcyclecounter ();
@@ -1053,7 +1053,6 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
 #else
 #define TR(i) do { } while (0)
 #endif
-    bool stores_behind = false;                               // a tile's 32 stores were issued behind the pieces in flight
 
     for (int k = 0; k < nseg; ++k) {
         int within, c0, c1, st, j0;
@@ -1089,9 +1088,10 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
                 for (int i = 0; i < 4; ++i) bv [pn] [i] = *reinterpret_cast<const int *> (Bb + pn * 8192 + i * 512);
             }
         };
-        // the products of one image; PIECES: a DMA piece of the stream's next-but-one chunk -> buffer `to` behind every second product
-        auto products = [&] (int sub, auto with_pieces, int to) {
-            constexpr bool PIECES = decltype (with_pieces)::value;
+        // the products of one image, and five DMA pieces of the chunk being issued (pieces first .. first + 4 -> buffer `to`) spread
+        // between them, one behind every fourth product or so: issued in a burst the pieces of eight waves queue up in front of the
+        // CU's one address unit (~20 cycles a piece), and a wave stuck behind them multiplies nothing
+        auto products = [&] (int sub, int to, int first) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 int n = 0;                                    // products issued so far in this register tile's block
@@ -1102,12 +1102,22 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
                         if (i + j <= 4) {
                             acc [h] [i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8 (av [h] [i], bv [j], acc [h] [i + j], 0, 0, 0);
                             ++n;
-                            if (PIECES && (n == 2 || n == 4 || n == 6 || n == 8 || n == 9)) piece (to, h * 5 + (n == 9 ? 4 : n / 2 - 1));
+                            if (h == 0 && n == 3) piece (to, first);
+                            if (h == 0 && n == 7) piece (to, first + 1);
+                            if (h == 1 && n == 2) piece (to, first + 2);
+                            if (h == 1 && n == 5) piece (to, first + 3);
+                            if (h == 1 && n == 8) piece (to, first + 4);
                         }
-                if (PIECES) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { __builtin_amdgcn_sched_group_barrier (0x008, 2, 0); __builtin_amdgcn_sched_group_barrier (0x020, 1, 0); }
-                    __builtin_amdgcn_sched_group_barrier (0x008, 1, 0); __builtin_amdgcn_sched_group_barrier (0x020, 1, 0);
+                if (h == 0) {
+                    __builtin_amdgcn_sched_group_barrier (0x008, 3, 0); __builtin_amdgcn_sched_group_barrier (0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier (0x008, 4, 0); __builtin_amdgcn_sched_group_barrier (0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier (0x008, 2, 0);
+                }
+                else {
+                    __builtin_amdgcn_sched_group_barrier (0x008, 2, 0); __builtin_amdgcn_sched_group_barrier (0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier (0x008, 3, 0); __builtin_amdgcn_sched_group_barrier (0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier (0x008, 3, 0); __builtin_amdgcn_sched_group_barrier (0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier (0x008, 1, 0);
                 }
                 if ((top [h] >> sub) & 1ull) {
 #pragma unroll
@@ -1121,17 +1131,13 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
             // ---- the chunk's first image
             read_image (0);
             __builtin_amdgcn_sched_group_barrier (0x100, 16, 0);
-            products (2 * ch, std::false_type {}, 0);
+            products (2 * ch, cur ^ 1, 5);                    // (with the second five pieces of the chunk announced behind the last barrier)
             TR (4);
             // ---- its second image (a tile's last chunk may have none): operands now, products behind the barrier
             const bool two = 2 * ch + 1 < nsub;
             if (two) read_image (1);
             asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the chunk has been read: its buffer may be written again)
-            // this wave's pieces of the next chunk have landed once nothing but a just finished tile's 32 stores, issued behind them,
-            // is outstanding
-            if (stores_behind) asm volatile ("s_waitcnt vmcnt(32)" ::: "memory");
-            else asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
-            stores_behind = false;
+            asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");         // (this wave's pieces of the next chunk have landed)
             if (ch == c0) asm volatile ("" : "+v" (shift_v));   // (the exponent's load is waited for here)
             TR (1);                                           // (1: reading the second image, waiting for this wave's pieces)
             __builtin_amdgcn_s_barrier ();
@@ -1139,10 +1145,10 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
             TR (2);                                           // (2: the barrier)
             next_chunk ();                                    // the stream's next-but-one chunk -> the buffer just read
             TR (3);                                           // (3: moving the stream on)
-            if (two) products (2 * ch + 1, std::true_type {}, cur);
+            if (two) products (2 * ch + 1, cur, 0);             // (with the first five pieces)
             else {
 #pragma unroll
-                for (int idx = 0; idx < 10; ++idx) piece (cur, idx);
+                for (int idx = 0; idx < 5; ++idx) piece (cur, idx);
             }
             TR (5);
             asm volatile ("" ::: "memory");
@@ -1237,7 +1243,6 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
                 const unsigned int off = i < rows_valid ? out_off + (unsigned int)(i_const * CG) * 4u : 0xfffffff0u;
                 __builtin_amdgcn_raw_buffer_store_b32 (__float_as_uint (y [h] [r]), rs_out, (int) off, 0, 0);
             }
-        stores_behind = true;
         TR (12);
     }
     asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1260,10 +1265,11 @@ bool artfir_i8_slab_enabled ()
     static const bool on = [] { const char *e = getenv ("ARTAMD_I8_SLAB"); const char *d = getenv ("ARTAMD_I8_DMA"); return !(e && *e == '0') && !(d && *d == '0'); } ();
     return on;
 }
-// slabs per XCD from which a launch is given to the slab kernel (below: more, smaller tiles fill the chip better)
+// slabs per XCD from which a launch is given to the slab kernel (below — measured, tools/micro/slab_sizes.sh — more, smaller tiles
+// fill the chip better and walk their K range sooner)
 static int i8_slab_min_tiles ()
 {
-    static const int v = [] { const char *e = getenv ("ARTAMD_I8_SLAB_MIN"); return e && *e ? atoi (e) : 8; } ();
+    static const int v = [] { const char *e = getenv ("ARTAMD_I8_SLAB_MIN"); return e && *e ? atoi (e) : 64; } ();
     return v;
 }
 
