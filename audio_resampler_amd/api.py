@@ -121,6 +121,7 @@ def _bind(width):
         "resampleHipLastKernel": (C.c_int, [RP]),
         "resampleHipLastHandedBack": (C.c_uint, [RP]),
         "resampleHipLastFixedPoint": (C.c_int, [RP, C.POINTER(C.c_double)]),
+        "resampleHipLastFixedPointKernel": (C.c_int, [RP]),
         "resampleHipSetTiming": (None, [RP, C.c_int]),
         "resampleHipReadTiming": (C.c_double, [RP, C.POINTER(C.c_int)]),
         "resampleHipReadPrepTiming": (C.c_double, [RP]),
@@ -271,6 +272,10 @@ def _bind(width):
             pairs = C.c_double(0.0)
             state = self.L.resampleHipLastFixedPoint(self.p, C.byref(pairs))
             return state, pairs.value
+
+        def fixed_point_kernel(self):
+            """the form of the fixed-point kernel the last call's last launch was given to (art_hip.h), as its name; None: not fixed point"""
+            return {1: "fir_i8_stream_kernel", 2: "fir_i8_dma_kernel", 3: "fir_i8_slab_kernel"}.get(self.L.resampleHipLastFixedPointKernel(self.p))
 
         def handed_back(self):
             return self.L.resampleHipLastHandedBack(self.p)

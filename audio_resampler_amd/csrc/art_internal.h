@@ -56,6 +56,8 @@ typedef struct {
     int stream_C;                        /* channels of the whole stream when this context is a shard of a multi-device context (0: = C): the
                                           * kernel choice is made for the stream, so that a shard and an ordinary context of the same stream
                                           * run the same kernels and produce the same bits */
+    int stream_plain;                    /* a shard of a stream whose channel slices are not all 1, 2, 4, 8, 16 or 32 wide: the matrix path keeps to
+                                          * the generic f32 instantiation an ordinary context of such a stream runs: no channel of the stream gets other arithmetic */
     int interpolate, lowpass;            /* SUBSAMPLE_INTERPOLATE / INCLUDE_LOWPASS in effect */
     int mode;                            /* ART_MODE_* */
     double ratio;
@@ -77,9 +79,9 @@ typedef struct {
     /* device memory for the K-split streaming kernel of launches with few tiles (arthip_fir_split_bytes; NULL: unsplit): the first
      * ART_SPLIT_HEAD_BYTES are arrival counters, zero whenever no launch is in flight (zeroed by the owner when allocated) */
     void *split; size_t split_bytes;
-    /* host, optional, 3 ints filled when the fixed-point kernel is enqueued: the launch's flag value (the first word of
+    /* host, optional, 4 ints filled when the fixed-point kernel is enqueued: the launch's flag value (the first word of
      * `planes` equals it afterwards iff the kernel stood down), mask words behind the header (at planes + ART_I8_HEAD_BYTES),
-     * chunks per tile */
+     * chunks per tile, the kernel's form (1 register-staged, 2 LDS-DMA, 3 slabs) */
     int *fixed_out;
     /* optional HIP events recorded immediately before/after the dominant kernel's launch (host side only) */
     void *ev_start, *ev_stop;

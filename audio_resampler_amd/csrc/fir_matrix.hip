@@ -823,7 +823,9 @@ static int matrix_geometry (const ArtFirArgs *a, MfmaGeom &g)
     }
     // compile-time channel count where the whole stream is one column group and the buffers allow vector loads
     const bool small = (size_t) a->in_frames * a->C * 4 < 0xffff0000ull && ((uintptr_t) a->in % 16) == 0 && ((uintptr_t) a->hist % 16) == 0;
-    const int cgt = (small && (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32)) ? a->C : 0;
+    // (a shard of a stream that an ordinary context would run on the generic instantiation — channel count or slices not of the
+    // compiled widths — runs the generic instantiation too: the wave-specialised kernels round differently in 1 sample of 30)
+    const int cgt = (small && !a->stream_plain && (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32)) ? a->C : 0;
     g.tile_rows = 32;
     g.slot_tiles = (g.P + g.tile_rows - 1) / g.tile_rows;
     g.cg = a->C < 32 ? a->C : 32;
@@ -849,7 +851,7 @@ static int matrix_geometry (const ArtFirArgs *a, MfmaGeom &g)
 // 21.7 -> 16.2 us) and nowhere else.  Kernel preference 8 forces 2 / 4 / 8 parts (tests, experiments: ARTAMD_SPLIT_KS).
 static int matrix_split_parts (const ArtFirArgs *a, const MfmaGeom &g, unsigned int outputs, int kernel_pref)
 {
-    if (kernel_pref == 5 || kernel_pref == 6 || kernel_pref == 7) return 1;
+    if (kernel_pref == 5 || kernel_pref == 6 || kernel_pref == 7 || a->stream_plain) return 1;
     static const bool off = [] { const char *e = getenv ("ARTAMD_NO_SPLIT"); return e && *e && *e != '0'; } ();
     if (off) return 1;
     const int C = a->stream_C > a->C ? a->stream_C : a->C;
@@ -891,7 +893,7 @@ bool artfir_matrix_spans_segments (const ArtFirArgs *a, const ArtSegTable *segs,
 // bytes of digit planes the fixed-point kernel wants for a call of this shape (the host sizes a->planes with it before the launch)
 size_t artfir_planes_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref)
 {
-    if (!a->period_out || a->mode != ART_MODE_FAST || kernel_pref == 5 || kernel_pref == 6 || kernel_pref == 8) return 0;
+    if (!a->period_out || a->mode != ART_MODE_FAST || kernel_pref == 5 || kernel_pref == 6 || kernel_pref == 8 || a->stream_plain) return 0;
     // Where it pays (MI355X, tools/bench_shapes.py with and without ARTAMD_NO_FIXED, profiles/r2_fixed_point_shapes.txt): the
     // integer kernel gains in proportion to outputs x channels x taps, its staging pass costs in proportion to the input
     // and its extra launch ~4 us: long filters and big calls win (8 ch x 988 taps: from ~90k frames per call, +27 % at 1M;

@@ -1362,7 +1362,8 @@ int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGe
     int ep = ++launches;
     if (ep <= 0) { launches = 1; ep = 1; }                             // (the flag word is zero when the buffer is allocated)
     q.epoch = ep;
-    if (a->fixed_out) { a->fixed_out [0] = ep; a->fixed_out [1] = q.tiles * q.g * q.tr; a->fixed_out [2] = q.ktot / I8_KC; }
+    static const bool dma = [] { const char *e = getenv ("ARTAMD_I8_DMA"); return !(e && *e == '0'); } ();
+    if (a->fixed_out) { a->fixed_out [0] = ep; a->fixed_out [1] = q.tiles * q.g * q.tr; a->fixed_out [2] = q.ktot / I8_KC; a->fixed_out [3] = q.tr == 64 ? 3 : (dma && cgt >= 4) ? 2 : 1; }
 
     {   // block of the launch's first window start: the reference's position arithmetic for output n_begin (as locate ())
         int e = 0;
@@ -1454,7 +1455,6 @@ int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGe
 #define I8_DMA(CGT) do { if (pass) hipLaunchKernelGGL ((fir_i8_dma_kernel<CGT, true>), sgrid, dim3 (2 * MF_THREADS), 0, st, *a, g, q, wgs_per_xcd); \
                          else hipLaunchKernelGGL ((fir_i8_dma_kernel<CGT, false>), sgrid, dim3 (2 * MF_THREADS), 0, st, *a, g, q, wgs_per_xcd); } while (0)
     // (ARTAMD_I8_DMA=0: the register-staged kernel for every channel count — comparisons; the results are the same bits)
-    static const bool dma = [] { const char *e = getenv ("ARTAMD_I8_DMA"); return !(e && *e == '0'); } ();
     if (dma && cgt >= 4) switch (cgt) { case 32: I8_DMA (32); break; case 16: I8_DMA (16); break; case 8: I8_DMA (8); break; default: I8_DMA (4); }
     else switch (cgt) { case 32: I8_GO (32); break; case 16: I8_GO (16); break; case 8: I8_GO (8); break; case 4: I8_GO (4); break; case 2: I8_GO (2); break; default: I8_GO (1); }
 #undef I8_DMA

@@ -24,17 +24,29 @@
  * fall back to: a failure is printed, counted (artamdErrorCount / artamdLastError: tools check them before they trust the audio
  * they write) and, with ARTAMD_ABORT_ON_ERROR=1, fatal on the spot. */
 static int pcm_errors;
-static char pcm_last_error [256];
+static char pcm_last_error [256], pcm_last_error_out [256];
+static pthread_mutex_t pcm_error_lock = PTHREAD_MUTEX_INITIALIZER;      /* (callers hold different locks: the message has its own) */
 static void pcm_fail (const char *what)
 {
+    static int abort_on_error = -1;
+    pthread_mutex_lock (&pcm_error_lock);
+    if (abort_on_error < 0) { const char *e = getenv ("ARTAMD_ABORT_ON_ERROR"); abort_on_error = e && *e && *e != '0'; }
     snprintf (pcm_last_error, sizeof (pcm_last_error), "%s: %s", what, arthip_last_error ());
     fprintf (stderr, "artamd: %s\n", pcm_last_error);
     __atomic_add_fetch (&pcm_errors, 1, __ATOMIC_RELAXED);
-    const char *e = getenv ("ARTAMD_ABORT_ON_ERROR");
-    if (e && *e && *e != '0') abort ();
+    const int fatal = abort_on_error;
+    pthread_mutex_unlock (&pcm_error_lock);
+    if (fatal) abort ();
 }
 int artamdErrorCount (void) { return __atomic_load_n (&pcm_errors, __ATOMIC_RELAXED); }
-const char *artamdLastError (void) { return pcm_errors ? pcm_last_error : NULL; }
+const char *artamdLastError (void)
+{
+    if (!artamdErrorCount ()) return NULL;
+    pthread_mutex_lock (&pcm_error_lock);               /* (a whole message, never a torn one) */
+    memcpy (pcm_last_error_out, pcm_last_error, sizeof (pcm_last_error_out));
+    pthread_mutex_unlock (&pcm_error_lock);
+    return pcm_last_error_out;
+}
 
 static void butterworth (double freq, double *K_out, double *norm_out, double *b1, double *b2)
 {
@@ -250,10 +262,24 @@ void biquad_apply_buffer (Biquad *f, artsample_t *buffer, int num_samples, int s
     biquad_run_host (f, buffer, num_samples, stride, 0);
 }
 
+/* One value through the section: the reference's per-sample association (biquad.c:78-102 — the highest delay first, each delay's
+ * feed-forward and feedback products subtracted from one another before they join the sum), evaluated where the state lives: the
+ * caller's struct, in host memory.  (Rounds 1-3 sent the struct and the sample to the GPU and back: one launch and 46 us per
+ * sample for a dozen flops; runs of samples — biquad_apply_buffer, the decimator's noise shapers — stay on the device.  Compiled
+ * -ffp-contract=off: the bits of the device kernels' sample form, tests/test_gpu_parity.py.) */
 artsample_t biquad_apply_sample (Biquad *f, artsample_t input)
 {
-    biquad_run_host (f, &input, 1, 1, 1);
-    return input;
+    art_s sum = input * f->a [0];
+    int i = f->index & 3;
+
+    for (int k = f->order > 4 ? 4 : f->order; k >= 1; --k) {
+        const int d = (i - k + 1) & 3;
+        sum += (f->x [d] * f->a [k]) - (f->b [k] * f->y [d]);
+    }
+    f->index = i = (i + 1) & 3;
+    f->x [i] = input;
+    f->y [i] = sum;
+    return sum;
 }
 
 /* chunks the time-parallel biquad had to recompute since the process started (host-pointer calls; diagnostics) */
@@ -383,7 +409,12 @@ void biquadBankApplyInterleavedDevice (BiquadBank *b, artsample_t *d_buffer, int
                 arthip_sync (sh->stream);
                 arthip_free (sh->d_slice);
                 sh->slice_cap = need + need / 2;
-                if (!(sh->d_slice = arthip_malloc (sh->slice_cap))) { sh->slice_cap = 0; fprintf (stderr, "artamd: sharded biquad bank: %s\n", arthip_last_error ()); continue; }
+                if (!(sh->d_slice = arthip_malloc (sh->slice_cap))) {        /* (counted: this shard's channels stay unfiltered, as an ordinary bank's would) */
+                    sh->slice_cap = 0;
+                    pcm_fail ("sharded biquad bank: device allocation failed (a shard's channels left unfiltered)");
+                    arthip_event_record (b->ev_shard [k], sh->stream);
+                    continue;
+                }
             }
             arthip_slice_copy (sh->d_slice, (size_t) width * wps, d_buffer + first, (size_t) b->C * wps, width * wps, (size_t) numFrames, sh->stream);
             biquadBankApplyInterleavedDevice (sh, sh->d_slice, numFrames);
@@ -724,6 +755,20 @@ static void dec_sharded_device_call (Decimate *cxt, const art_s *d_input, int fr
     const int C = cxt->numChannels, B = cxt->outputBytes, prev = arthip_current_device ();
     const int wps = (int)(sizeof (art_s) / 4);
 
+    /* every shard's buffers first: a shard that cannot get them would leave its channels of the interleaved output unwritten, so
+     * the whole call then leaves silence behind, and the failure is counted (art_hip.h: the error contract) */
+    for (int k = 0; k < hip->nshards; ++k) {
+        Decimate *leaf = hip->shards [k];
+        const int width = hip->shard_first [k + 1] - hip->shard_first [k];
+        arthip_set_device (leaf->hip->device);
+        if (dec_reserve (leaf, (size_t) frames * width * sizeof (art_s), (size_t) frames * width * B)) {
+            pcm_fail ("sharded decimator: device allocation failed (output zeroed)");
+            arthip_set_device (hip->device);
+            arthip_zero (d_output, (size_t) frames * C * B, hip->stream);
+            if (prev >= 0) arthip_set_device (prev);
+            return;
+        }
+    }
     arthip_set_device (hip->device);
     arthip_event_record (hip->ev_parent, hip->stream);
     for (int k = 0; k < hip->nshards; ++k) {
@@ -733,10 +778,6 @@ static void dec_sharded_device_call (Decimate *cxt, const art_s *d_input, int fr
         ArtDecArgs a;
         arthip_set_device (sp->device);
         arthip_stream_wait_event (sp->stream, hip->ev_parent);
-        if (dec_reserve (leaf, (size_t) frames * width * sizeof (art_s), (size_t) frames * width * B)) {
-            fprintf (stderr, "artamd: sharded decimator: device allocation failed: %s\n", arthip_last_error ());
-            continue;
-        }
         arthip_slice_copy (sp->d_in, (size_t) width * wps, d_input + first, (size_t) C * wps, width * wps, (size_t) frames, sp->stream);
         dec_args (leaf, &a);
         dec_swap_if (leaf, arthip_decimate (&a, sp->d_in, frames, sp->d_out, sp->stream));
@@ -765,7 +806,11 @@ long decimateHipClipped (Decimate *cxt)
     unsigned long long total = 0;
     if (cxt->hip->nshards) {
         long sum = 0;
-        arthip_sync (cxt->hip->stream);
+        {
+            DEC_ENTER (cxt->hip);
+            arthip_sync (cxt->hip->stream);
+            DEC_LEAVE (cxt->hip);
+        }
         for (int k = 0; k < cxt->hip->nshards; ++k) sum += decimateHipClipped (cxt->hip->shards [k]);
         return sum;
     }
@@ -838,7 +883,7 @@ static int dec_finish_shards (Decimate *cxt)
         struct artamd_decimator *sp = leaf->hip;
         const int first = hip->shard_first [k], width = hip->shard_first [k + 1] - first;
         arthip_set_device (sp->device);
-        if (arthip_sync (sp->stream)) { fprintf (stderr, "artamd: sharded decimator: %s\n", arthip_last_error ()); continue; }
+        if (arthip_sync (sp->stream)) { pcm_fail ("sharded decimator: a shard's stream failed (its channels are not to be trusted)"); continue; }
         const unsigned char *m = sp->h_state;
         const unsigned long long total = *(const unsigned long long *) m;
         memcpy (cxt->feedback + first, m + ((unsigned char *) sp->d_feedback - sp->d_state), sizeof (art_s) * width);
@@ -919,10 +964,15 @@ int decimateProcessLE (Decimate *cxt, const artsample_t *const *input, int numIn
     if (hip->nshards) {
         /* planes need no slicing: a shard's channels are a run of the caller's planes; all shards are enqueued before any is waited for */
         const int prev = arthip_current_device ();
+        arthip_set_device (hip->device);                /* (the context's stream on the context's device) */
         arthip_sync (hip->stream);
         for (int k = 0; k < hip->nshards; ++k) {
             arthip_set_device (hip->shards [k]->hip->device);
-            dec_planar_begin (hip->shards [k], input + hip->shard_first [k], numInputFrames, output + hip->shard_first [k]);
+            if (dec_planar_begin (hip->shards [k], input + hip->shard_first [k], numInputFrames, output + hip->shard_first [k])) {
+                /* (counted; the shard's planes are the caller's host memory: silence instead of whatever was there) */
+                pcm_fail ("sharded decimator: device allocation failed (a shard's planes zeroed)");
+                for (int c = hip->shard_first [k]; c < hip->shard_first [k + 1]; ++c) memset (output [c], 0, (size_t) numInputFrames * cxt->outputBytes);
+            }
         }
         if (prev >= 0) arthip_set_device (prev);
         return dec_finish_shards (cxt);

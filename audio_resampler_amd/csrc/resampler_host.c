@@ -58,6 +58,7 @@ struct artamd_resampler {
     int floor_active;                       /* ring index 0 is a hard history floor (after a flush-time rewind) */
     int kernel_pref, last_kernel;
     int stream_channels;                     /* a shard: channels of the whole stream (kernel choice); 0 otherwise */
+    int stream_irregular;                    /* a shard of a stream whose slices are not all 1/2/4/8/16/32 wide: f32 matrix kernels only */
     /* cached rational structure of the current ratio */
     double period_ratio; int period_out, period_in;
     /* optional HIP-event timing of FIR launches */
@@ -66,7 +67,7 @@ struct artamd_resampler {
     void *d_scratch; size_t scratch_cap;     /* MFMA path: effective rows + canonical positions of one launch */
     void *d_planes; size_t planes_cap;       /* fixed-point matrix kernel: digit planes of one launch (flag word first) */
     void *d_split; size_t split_cap;         /* K-split streaming kernel: arrival counters (zero at rest) + partial sums of one launch */
-    int last_fixed [3];                      /* its last launch of the last call: flag value (0: none), mask words, chunks per tile */
+    int last_fixed [4];                      /* its last launch of the last call: flag value (0: none), mask words, chunks per tile, kernel form (art_hip.h) */
     unsigned int *d_fix; size_t fix_cap;    /* [0] per-launch, [1] running count of outputs the matrix kernels evaluated off-pattern */
     void *d_batch; size_t batch_cap;         /* argument table of the batched calls led by this context */
     unsigned long batch_stamp;               /* last batched call this context took part in (duplicate check) */
@@ -506,17 +507,48 @@ static Resample *init_sharded (int numChannels, int numTaps, int numFilters, dou
     hip->ev_parent = arthip_order_event_create ();
     int ok = hip->shards && hip->shard_first && hip->ev_shard && hip->ev_parent;
 
-    /* contiguous, balanced channel slices: the first (channels % count) shards get one channel more */
-    const int base = numChannels / count, extra = numChannels % count;
+    /* Contiguous channel slices.  A shard decides its kernels as its whole stream would (stream_channels), and the matrix-core
+     * kernels are compiled for 1, 2, 4, 8, 16 and 32 channels: with every slice one of those widths all shards of a stream run the
+     * same kernels — the ordinary context's bits.  So the channels are written as a sum of `count` such widths where that is possible
+     * (binary digits of the channel count, the largest part halved until there are enough: 12 over 5 = 4 2 2 2 2, 8 over 3 = 4 2 2);
+     * where it is not (7 channels on 2 devices) the slices are balanced and the stream is marked irregular: every shard then keeps to
+     * the generic f32 matrix kernel an ordinary context of such a stream runs (no fixed point, no K split, no wave-specialised
+     * form: channels of one stream never get different arithmetic). */
+    /* (a stream whose own channel count is not one of those widths runs the generic f32 matrix kernel as an ordinary context: its
+     * shards keep to f32 too) */
+    int widths [MAX_DEVICES], parts = 0, irregular = numChannels > 32 || (numChannels & (numChannels - 1));
+    {
+        int left = numChannels;
+        while (left > 0 && parts < count) {              /* the channel count's binary digits, 32 at most per part */
+            int w = 32;
+            while (w > left) w >>= 1;
+            widths [parts++] = w; left -= w;
+        }
+        if (left) parts = 0;                             /* (more parts than shards) */
+    }
+    while (parts && parts < count) {                     /* halve the largest part until every shard has one */
+        int big = 0;
+        for (int i = 1; i < parts; ++i) if (widths [i] >= widths [big]) big = i;      /* (the last of the widest: wide slices first) */
+        if (widths [big] == 1) break;
+        widths [big] >>= 1;
+        for (int i = parts; i > big + 1; --i) widths [i] = widths [i - 1];
+        widths [big + 1] = widths [big];
+        ++parts;
+    }
+    if (parts != count) {
+        const int base = numChannels / count, extra = numChannels % count;
+        for (int s = 0; s < count; ++s) widths [s] = base + (s < extra ? 1 : 0);
+        for (int s = 0; s < count; ++s) if (widths [s] > 32 || (widths [s] & (widths [s] - 1))) irregular = 1;
+    }
     for (int s = 0; ok && s < count; ++s) {
-        const int width = base + (s < extra ? 1 : 0);
+        const int width = widths [s];
         hip->shard_first [s + 1] = hip->shard_first [s] + width;
         arthip_set_device (devices [s]);                  /* (artamd_shard_plan has made sure it can address `prev`'s memory) */
         hip->shards [s] = init_leaf (width, numTaps, numFilters, lowpassRatio, flags & ~RESAMPLE_MULTITHREADED, 1);
         hip->ev_shard [s] = arthip_order_event_create ();
         hip->nshards = s + 1;
         ok = hip->shards [s] && hip->ev_shard [s];
-        if (ok) hip->shards [s]->hip->stream_channels = numChannels;
+        if (ok) { hip->shards [s]->hip->stream_channels = numChannels; hip->shards [s]->hip->stream_irregular = irregular; }
     }
     if (prev >= 0) arthip_set_device (prev);
 
@@ -889,6 +921,13 @@ int resampleHipLastFixedPoint (Resample *cxt, double *pairsPerChunk)
     return flag == hip->last_fixed [0] ? 2 : 1;
 }
 
+/* which form of the fixed-point kernel the last call's last launch was given to (art_hip.h); 0: none */
+int resampleHipLastFixedPointKernel (Resample *cxt)
+{
+    struct artamd_resampler *hip = cxt->hip->nshards ? cxt->hip->shards [0]->hip : cxt->hip;
+    return hip->last_fixed [0] ? hip->last_fixed [3] : 0;
+}
+
 int  resampleHipLastKernel (Resample *cxt) { return cxt->hip->nshards ? cxt->hip->shards [0]->hip->last_kernel : cxt->hip->last_kernel; }
 
 /* outputs the matrix kernels have evaluated off their canonical pattern so far (synchronises) */
@@ -1151,7 +1190,7 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
         a.in_frames = is_flush ? (flush_in ? T / 2 : 0) : (int) res.input_used;
         a.out = d_out; a.out_pitch = out_pitch;
         a.C = C; a.T = T; a.F = cxt->numFilters; a.H = H;
-        a.stream_C = hip->stream_channels;
+        a.stream_C = hip->stream_channels; a.stream_plain = hip->stream_irregular;
         a.interpolate = (cxt->flags & SUBSAMPLE_INTERPOLATE) != 0;
         a.lowpass = (cxt->flags & INCLUDE_LOWPASS) != 0;
         /* the double-precision build has one arithmetic: EXTEND_CONVOLUTION_MATH only matters for 4-byte samples
@@ -1240,7 +1279,10 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
                 a.segs_truncated = whole;
                 int k = arthip_fir (&a, &tab, hip->kernel_pref, hip->stream);
                 a.segs_truncated = 0;
-                if (k == -2 && whole) { whole = 0; s0 = -ART_MAX_SEGS; continue; }      /* (declined: nothing enqueued — again, cut) */
+                if (k == -2 && whole) {                /* (declined: nothing enqueued — again, cut) */
+                    if (hip->timing) hip->ev_count -= 3;        /* (the three events go back: only ev_pre was recorded, none is read) */
+                    whole = 0; s0 = -ART_MAX_SEGS; continue;
+                }
                 if (k >= 0 && (k & ART_FIR_ROLLED)) { rolled = 1; k &= ~ART_FIR_ROLLED; }
                 if (k < 0) { fprintf (stderr, "artamd: FIR launch failed: %s\n", arthip_last_error ()); res.input_used = res.output_generated = 0; return res; }
                 hip->last_kernel = k;
@@ -1304,7 +1346,7 @@ static int batch_plan (Resample *cxt, const art_s *d_in, int nIn, art_s *d_out, 
     a->in = d_in; a->in_pitch = 0; a->in_frames = (int) res->input_used;
     a->out = d_out; a->out_pitch = 0;
     a->C = C; a->T = T; a->F = cxt->numFilters; a->H = H;
-    a->stream_C = hip->stream_channels;
+    a->stream_C = hip->stream_channels; a->stream_plain = hip->stream_irregular;
     a->interpolate = (cxt->flags & SUBSAMPLE_INTERPOLATE) != 0;
     a->lowpass = (cxt->flags & INCLUDE_LOWPASS) != 0;
     a->mode = (!ART_WIDE && (cxt->flags & EXTEND_CONVOLUTION_MATH)) ? ART_MODE_PRECISE : ART_MODE_FAST;

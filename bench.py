@@ -16,6 +16,8 @@ timing barrier and the max-over-ranks reduction.
   --scaling weak   (default) 8 channels per GPU, the stream has 8N channels; N = 1 is the metric's config
   --scaling strong ONE 32-channel stream (--total-channels), 32/N channels per GPU: BASELINE.json configs[3]
                    (4 channels per GPU at N = 8)
+Whatever --scaling says, the line also carries "config_d": the strong-scaling figure of configs[3] (one 32-channel stream shared
+among the N ranks), measured in the same run — the driver's default command line reports both.
 
 Prints ONE JSON line on rank 0.
 """
@@ -106,7 +108,7 @@ def main():
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 general, 2 matrix path, 5 f32 tile kernel, 6 f32 streaming kernel, 7 fixed point wherever possible")
     ap.add_argument("--preroll-ms", type=float, default=200.0, help="untimed device pre-roll before the warmup steps (clock ramp); 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pmc-json", default=None, help="traffic file written by tools/pmc_traffic.py in the same lease (else the committed profiles/ figure is reported, labelled as such)")
+    ap.add_argument("--pmc-json", default=None, help="traffic file written by tools/roofline_report.py from the rocprofv3 --pmc passes of the same lease (tools/refresh_evidence.sh; else the committed profiles/ figure is reported, labelled as such)")
     args = ap.parse_args()
 
     import torch
@@ -198,6 +200,7 @@ def main():
     dt, out_frames, kernel_ms, launches, prep_ms = timed_region()
     kernel_used = rs.last_kernel()
     fixed_state, fixed_pairs = rs.fixed_point()           # 1: the matrix path ran in fixed point on the integer matrix cores
+    fixed_kernel_name = rs.fixed_point_kernel()           # which form of the fixed-point kernel (asked of the library, not inferred)
 
     # Beside the headline, in the same run and on the same context (never `value`):
     #  * the same call at the block size the CPU baseline uses (65,536 frames): the like-for-like figure;
@@ -211,7 +214,36 @@ def main():
         f32 = timed_region()
         rs.set_kernel(0)
 
+    # BASELINE.json configs[3] in the same run, whatever --scaling says: ONE 32-channel stream (--total-channels) whose channels are
+    # shared among the ranks, 32/N per GPU (4 per GPU at N = 8) — the STRONG-scaling figure beside the weak-scaling `value`
+    # (reference fan-out: resampler.c:442-470, one worker per channel of one context).  Its own context and buffers, W warmup + K
+    # timed steps between barriers like the headline; never `value`.
+    config_d = None
+    if args.scaling == "weak" and not args.kernel and args.total_channels >= world:
+        lo_d, hi_d = channel_slice(args.total_channels, world, rank)
+        Cd = hi_d - lo_d
+        d_in_d = torch.from_numpy(stream_slice(block, lo_d, hi_d)).cuda()
+        d_out_d = torch.empty(cap, Cd, device="cuda", dtype=torch.float32)
+        rs_d = A.Resampler(Cd, TAPS, FILTERS, 0.0, A.BLACKMAN_HARRIS | A.SUBSAMPLE_INTERPOLATE)
+        rs_d.advance(TAPS / 2.0)
+        rs_d.set_stream(torch.cuda.current_stream().cuda_stream)
+        for _ in range(args.warmup):
+            rs_d.process_device(d_in_d, block, d_out_d, cap, ratio)
+        barrier()
+        rs_d.set_timing(True)
+        frames_d = 0
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            frames_d += rs_d.process_device(d_in_d, block, d_out_d, cap, ratio)[1]
+        barrier()
+        dt_d = time.perf_counter() - t0
+        k_ms_d, launches_d = rs_d.read_timing()
+        rs_d.set_timing(False)
+        config_d = (dt_d, frames_d, Cd, k_ms_d, launches_d, rs_d.fixed_point_kernel() or {1: "general", 2: "mfma (f32)"}.get(rs_d.last_kernel()))
+        del rs_d, d_in_d, d_out_d
+
     dev = "cuda" if backend == "nccl" else "cpu"
+    agg_d = agree_and_aggregate(dist, dev, config_d[0], config_d[1], config_d[2], config_d[3], config_d[4]) if config_d else None
     agg = agree_and_aggregate(dist, dev, dt, out_frames, Cn, kernel_ms, launches)
     agg_cold = agree_and_aggregate(dist, dev, cold[0], cold[1], Cn, cold[2], cold[3])
     agg_small = agree_and_aggregate(dist, dev, small[0], small[1], Cn, small[2], small[3]) if small else None
@@ -238,15 +270,16 @@ def main():
         tflops_useful = rate * ((2 * TAPS * fixed_pairs if fixed else 2 * TAPS) if kernel_used == 2 else FLOP_PER_SAMPLE) / 1e12
         tflops_ref_form = rate * FLOP_PER_SAMPLE / 1e12
         gbs = rate * BYTES_PER_SAMPLE / 1e9
-        # HBM traffic of the dominant kernel is a PMC measurement (tools/pmc.sh: separate rocprofv3 --pmc passes, FETCH_SIZE
+        # HBM traffic of the dominant kernel is a PMC measurement (tools/refresh_evidence.sh: separate rocprofv3 --pmc passes, FETCH_SIZE
         # with the gfx950 wide-read correction + WRITE_SIZE); it cannot be taken inside this process, so the committed
         # per-launch figure is reported when — and only when — this run is the workload it was measured on.
         traffic = traffic_source = None
-        for name in ([args.pmc_json] if args.pmc_json else []) + ["r3_traffic.json", "r2_traffic.json"]:
+        for name in ([args.pmc_json] if args.pmc_json else []) + ["r4_traffic.json", "r3_traffic.json"]:
             try:
                 tr = json.load(open(name if os.path.isabs(name) or os.path.exists(name) else os.path.join(ROOT, "profiles", name)))
                 w = tr["workload"]
-                if kernel_used == 2 and bool(tr.get("fixed_point", False)) == fixed and (w["block_frames"], w["channels"], w["taps"]) == (block, Cn, TAPS) and launches == args.steps:
+                if kernel_used == 2 and bool(tr.get("fixed_point", False)) == fixed and (w["block_frames"], w["channels"], w["taps"]) == (block, Cn, TAPS) and launches == args.steps \
+                        and tr.get("kernel", fixed_kernel_name) == fixed_kernel_name:
                     traffic = tr["traffic_bytes_per_launch"]
                     traffic_source = (f"--pmc-json {name}: rocprofv3 --pmc passes of this command in the same lease" if name == args.pmc_json else
                                       f"committed profiles/{name}: rocprofv3 --pmc passes of this command on an earlier box (not measured in this run)")
@@ -272,18 +305,19 @@ def main():
                        "stream_channels": total_ch, "channels_per_gpu": Cn, "block_frames": block, "taps": TAPS, "filters": FILTERS,
                        "fir_kernel": "mfma-i8 (fixed point)" if fixed else {1: "general", 2: "mfma"}.get(kernel_used, str(kernel_used)),
                        "parallelism": f"channel-shard x{world}, no data-path collective",
-                       "accuracy": ("default mode, fixed-point matrix kernel, block floating point (one power-of-two exponent per channel and launch, "
-                                    "from the channel's peak |x|): |y - fp64-accumulate| <= half a float ulp of y + 2^-26 x that peak — RELATIVE to the "
-                                    "channel's level in the call like float arithmetic (rms error ~0.5 x the reference float loop's at any "
-                                    "amplitude), not an absolute grid; within one call a passage far below the channel's peak keeps the peak's "
-                                    "grid (floor 2^-31 x peak); RESAMPLE_STRICT_ORDER is bit-exact") if fixed else
+                       "accuracy": ("default mode, fixed-point matrix kernel, block floating point (one power-of-two exponent per channel and EXPONENT "
+                                    "BLOCK of ~9,400 input frames — 0.2 s — from the channel's peak |x| over the frames the block's outputs read): "
+                                    "|y - fp64-accumulate| <= half a float ulp of y + 2^-26 x that peak — RELATIVE to the channel's level around the "
+                                    "output like float arithmetic (rms error ~0.5 x the reference float loop's at any amplitude), not an absolute "
+                                    "grid; inside an exponent block a passage far below the channel's peak keeps the peak's grid (floor 2^-31 x "
+                                    "peak); RESAMPLE_STRICT_ORDER is bit-exact") if fixed else
                                    ("default mode: |y - fp64-accumulate| <= 2^-23 max(1,|y|) (2 ulp on < 0.1 % of samples when |y| > 1, as the "
                                     "reference's own float build); RESAMPLE_STRICT_ORDER is bit-exact")},
             "roofline": {"bound": "mfma", "achieved": round(tflops_exec, 3), "peak": peak, "unit": "TFLOP/s",
                          "unit_note": "integer multiply-adds of v_mfma_i32_32x32x32_i8, 2 ops each (TOP/s), against the dense int8 MFMA peak" if fixed else "f32 MFMA",
                          "frac": round(tflops_exec / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_unit": "bytes/launch (HBM, PMC)", "algorithmic_bytes_per_launch": int(per_launch_samples * BYTES_PER_SAMPLE),
-                         "kernel": ("fir_i8_dma_kernel" if Cn >= 4 else "fir_i8_stream_kernel") if fixed else "fir_mfma_stream_kernel", "avg_kernel_ms": round(avg_ms, 4), "launches": launches,
+                         "kernel": fixed_kernel_name if fixed else "fir_mfma_stream_kernel", "avg_kernel_ms": round(avg_ms, 4), "launches": launches,
                          "avg_prep_ms": round(prep_ms / max(launches, 1), 4),
                          "prep_note": "HIP events: what each launch spends before its dominant kernel (fixed point: peak pass + digit-plane staging pass; f32: row-table pass)",
                          "flop_per_sample_executed": round(executed_per_sample, 1), "bytes_per_sample": round(BYTES_PER_SAMPLE, 3),
@@ -313,6 +347,14 @@ def main():
             line["value_f32_note"] = ("same W + K steps with the f32 matrix-core kernel pinned (kernel preference 6: exact-f32 FMA chains with fp64 flushes — "
                                       "what launches below the fixed-point threshold, and the fixed-point kernel's stand-by, run); f32_frac = executed "
                                       "2 x Kpad flop per sample over the f32-MFMA peak")
+        if agg_d:
+            line["config_d"] = {"value": round(agg_d["samples_total"] / agg_d["seconds_max"] / 1e6, 2), "unit": "Msamples/s", "scaling": "strong",
+                                "stream_channels": args.total_channels, "channels_per_gpu": config_d[2], "n_gpus": world,
+                                "ms_per_step": round(agg_d["seconds_max"] / args.steps * 1e3, 4), "fir_kernel": config_d[5],
+                                "frames_consistent": bool(agg_d["frames_consistent"]),
+                                "workload": f"BASELINE.json configs[3]: ONE {args.total_channels}-channel 44.1k->48k preset -4 stream, its channels shared among "
+                                            f"the {world} rank(s) ({config_d[2]} per GPU here; 4 per GPU at N = 8), {block} input frames per call, same W + K steps "
+                                            "between barriers as the headline; the strong-scaling figure (total work fixed as N grows), never `value`"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(Cn)
         print(json.dumps(line), flush=True)

@@ -66,6 +66,10 @@ int  resampleHipLastKernel (Resample *cxt);          /* which kernel produced th
  * 2 = it was enqueued and stood down for the f32 kernel behind it (a sample outside (-1.98, 1.98) or not finite).
  * *pairsPerChunk (may be NULL): digit-pair products issued per 32-tap chunk, 9 .. 13.  Synchronises. */
 int  resampleHipLastFixedPoint (Resample *cxt, double *pairsPerChunk);
+/* the form of the fixed-point kernel the last call's last launch was given to: 0 none, 1 fir_i8_stream_kernel (register-staged: 1 and 2
+ * channels, ARTAMD_I8_DMA=0), 2 fir_i8_dma_kernel (LDS-DMA staging, 32-slot tiles), 3 fir_i8_slab_kernel (64 x 256 tiles, big launches).
+ * All three leave the same bits. */
+int  resampleHipLastFixedPointKernel (Resample *cxt);
 unsigned int resampleHipLastHandedBack (Resample *cxt);   /* outputs the matrix-core kernels evaluated at their own exact position, off their slot's canonical pattern, so far */
 /* HIP-event timing of the dominant FIR kernel only (events recorded on the context's stream immediately
  * before and after that kernel's launch; the fix-up and history kernels are outside the bracket).  Enable, run calls, then read: returns accumulated kernel milliseconds and the launch count

@@ -6,10 +6,20 @@
  * have the reference's layout (reference resampler.h:44-48), so that a caller compiled against
  * either header (ART art.c:827-1136, artest.c:385-594) links and runs unmodified.
  *
- * All arithmetic runs in hand-written gfx950 HIP kernels (audio_resampler_amd/csrc/sinc_fir.hip);
- * the host side (audio_resampler_amd/csrc/resampler_host.c) only designs the filter bank and
- * replays the scalar position state machine.  There is NO CPU fallback: every process call
- * needs a GPU and the init functions return NULL (message on stderr) without one.
+ * All arithmetic runs in hand-written gfx950 HIP kernels (audio_resampler_amd/csrc/fir_general.hip,
+ * fir_matrix.hip, fir_matrix_i8.hip, fir_matrix64.hip; the launch rule is fir_dispatch.hip); the host
+ * side (audio_resampler_amd/csrc/resampler_host.c) only designs the filter bank and replays the
+ * scalar position state machine.  There is NO CPU fallback: every process call needs a GPU and the
+ * init functions return NULL (message on stderr) without one.
+ *
+ * One deviation from the reference to know about.  The reference's fixed-ratio output (resampler.c:323-335,
+ * 533-535) is bitwise independent of how the input is cut into calls.  Here that holds with
+ * RESAMPLE_STRICT_ORDER (art_hip.h: the reference's own summation order, bit for bit).  In the DEFAULT mode
+ * the size of a call picks the kernel (general / f32 matrix cores / fixed point on the integer matrix
+ * cores), each of which rounds differently inside the parity bar: the same stream cut into other blocks
+ * gives output that is within 2^-23 max(1,|y|) of the double-accumulate result either way — two cuts differ
+ * by at most twice that — but not the same bits (tests/test_gpu_parity.py: bounded there).  Counts and
+ * positions (input_used, output_generated, resampleGetPosition) do not depend on the cut in any mode.
  *
  * Device-pointer / stream extensions live in art_hip.h.
  */

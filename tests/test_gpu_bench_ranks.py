@@ -41,3 +41,10 @@ def test_bench_runs_with_two_ranks(scaling):
     frames_per_step = 262144 * 48000 / 44100
     assert abs(line ["value"] * 1e6 * line ["ms_per_step"] * 1e-3 / (frames_per_step * cfg ["stream_channels"]) - 1.0) < 0.01
     assert line ["roofline"] ["launches"] == 4
+    # BASELINE.json configs[3] rides along in the default (weak) command line: one 32-channel stream shared among the ranks
+    if scaling == "weak":
+        d = line ["config_d"]
+        assert d ["scaling"] == "strong" and d ["stream_channels"] == 32 and d ["channels_per_gpu"] == 16 and d ["n_gpus"] == 2 and d ["frames_consistent"]
+        assert abs(d ["value"] * 1e6 * d ["ms_per_step"] * 1e-3 / (frames_per_step * 32) - 1.0) < 0.01
+    else:
+        assert "config_d" not in line

@@ -204,6 +204,40 @@ def test_fixed_ratio_output_is_block_size_invariant():
         assert np.array_equal(s[:n].view(np.uint32), streams[0][:n].view(np.uint32))
 
 
+def test_default_mode_cuts_differ_by_no_more_than_the_bar():
+    """include/resampler.h, the deviation stated there: in the DEFAULT mode a call's size picks the kernel (general / f32 matrix cores /
+    fixed point), so a fixed-ratio stream cut into other blocks is not the same bits as the reference's is (resampler.c:533-535) — but
+    every cut is within the parity bar of the double-accumulate result, two cuts within twice the bar of each other, and counts and
+    positions do not depend on the cut.  8 channels x 988 taps so that every kind of kernel takes part."""
+    ch, T, total = 8, 988, 300000
+    x, _ = noise(ch * total)
+    x = x.reshape(-1, ch)
+    o = OracleResampler(ch, T, 160, flags=BH | INTERP | LOWPASS | PRECISE, fixed=(44100.0, 48000.0, 0)); o.advance(T / 2)
+    uo, go, truth = o.process(x, int(total * 1.1) + T, 0.0, threads=8)
+    truth = np.array(truth)
+    streams, kinds = [], set()
+    for block in (900, 7000, 50000, 300000):
+        r = HipResampler(ch, T, 160, flags=BH | INTERP | LOWPASS, fixed=(44100.0, 48000.0, 0))
+        r.advance(T / 2)
+        ys, used = [], 0
+        for p in range(0, total, block):
+            u, g, y = r.process(x[p:p + block], int(block * 1.1) + T, 0.0)
+            assert u == min(block, total - p)
+            used += u
+            ys.append(np.array(y))
+            kinds.add((r.last_kernel(), r.fixed_point()[0]))
+        streams.append(np.concatenate(ys))
+        assert used == uo
+    assert {(1, 0), (2, 0), (2, 1)} <= kinds, kinds              # general, f32 matrix cores and fixed point all ran
+    n = min(min(len(s) for s in streams), len(truth))
+    assert all(len(s) == len(streams[0]) for s in streams)      # the same number of frames whatever the cut
+    for s in streams:
+        assert tolerance_ok(s[:n], truth[:n])[0]
+    for s in streams[1:]:
+        d = np.abs(s[:n].astype(np.float64) - streams[0][:n].astype(np.float64))
+        assert np.all(d <= 2.0 * 2.0 ** -23 * np.maximum(1.0, np.abs(truth[:n].astype(np.float64))))
+
+
 def test_reset_and_getters():
     L = A.lib()
     r = HipResampler(2, 156, 320, flags=BH | INTERP | LOWPASS, fixed=(96000.0, 44100.0, 0))

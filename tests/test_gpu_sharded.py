@@ -278,6 +278,38 @@ def test_sharded_and_ordinary_context_choose_the_same_kernel_at_every_call_size(
     assert (1, 0) in kinds and (2, 0) in kinds and (2, 1) in kinds, kinds      # every kind of kernel was exercised
 
 
+def test_slices_are_widths_the_matrix_kernels_are_compiled_for(monkeypatch):
+    """a shard decides as its stream would, and the matrix-core kernels exist for 1, 2, 4, 8, 16, 32 channels: the channels are cut into
+    such widths wherever the shard count allows (12 over 5 = 4 2 2 2 2, not 3 3 2 2 2) — all shards then run the same kernels; where
+    it does not (7 channels on 2 shards), and where the stream's own channel count is not such a width (an ordinary 12-channel
+    context runs the generic f32 matrix kernel), the shards keep to the f32 kernels.  Either way: the ordinary context's bits at
+    every call size, kernel choice left to the library (round 3's advice: 3-channel shards ran f32 beside fixed-point siblings)"""
+    for ch, shards, want in ((12, 5, [4, 2, 2, 2, 2]), (8, 3, [4, 2, 2]), (7, 2, [4, 3]), (24, 3, [8, 8, 8]), (6, 4, [2, 2, 1, 1]), (16, 3, [8, 4, 4])):
+        monkeypatch.setenv("ARTAMD_SHARDS", str(shards))
+        r = A.Resampler(ch, 48, 48, 0.0, BH | INTERP | MT)
+        assert [n for _, _, n in r.shards()] == want, (ch, shards, r.shards())
+    for ch, shards in ((12, 5), (7, 2), (16, 3)):
+        monkeypatch.setenv("ARTAMD_SHARDS", str(shards))
+        sizes = [300, 9000, 30000, 140000]
+        x = _stream(ch, sum(sizes))
+        plain = HipResampler(ch, T, T, 0.0, BH | INTERP); sharded = HipResampler(ch, T, T, 0.0, BH | INTERP | MT)
+        assert len(sharded.shards()) == shards
+        pos = 0
+        for r in (plain, sharded):
+            r.advance(T / 2)
+        kinds = []
+        for n in sizes:
+            cap = int(n * R) + 2000
+            a = plain.process(x [pos:pos + n], cap, R); ka = (plain.last_kernel(), plain.fixed_point() [0])
+            b = sharded.process(x [pos:pos + n], cap, R); kb = (sharded.last_kernel(), sharded.fixed_point() [0])
+            pos += n
+            assert a [:2] == b [:2] and ka == kb, (ch, n, ka, kb)
+            assert np.array_equal(np.array(a [2]).view(np.uint32), np.array(b [2]).view(np.uint32)), (ch, n, ka, kb)
+            kinds.append(kb)
+        # 16 channels over 3 shards = 8 4 4: the big call runs in fixed point on every shard; the other two streams never do
+        assert ((2, 1) in kinds) == (ch == 16), (ch, kinds)
+
+
 # ---- the other two stages spread the same way: DECIMATE_MULTITHREADED (reference decimator.c:92-93, 119-136) and a multi-device biquad bank ----
 
 DEC_FLAGS = [A.DITHER_HIGHPASS | A.SHAPING_ATH_CURVE, A.DITHER_FLAT, A.SHAPING_3RD_ORDER, 0]

@@ -12,7 +12,7 @@ import pytest
 import _golden as G
 import audio_resampler_amd as A
 from audio_resampler_amd.api import ArtamdPosition, ArtamdSegment, ResampleResult, f32p
-from _oracle import OracleResampler, BH, INTERP, LOWPASS, FIXED, FLUSHED, SNAP
+from _oracle import OracleResampler, noise, BH, INTERP, LOWPASS, FIXED, FLUSHED, SNAP
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -180,3 +180,23 @@ def test_period_rule_fills_the_matrix_tiles():
         mu = L.artamdPeriodMultipleRows(p, 64)
         assert mu >= 1 and (mu == 1 or mu * p <= 1024)
         assert -(-mu * p // 64) * 64 / (mu * p) <= 1.15 + 1e-12 and -(-mu * p // 32) * 32 / (mu * p) <= 1.15 + 1e-12, (p, mu)
+
+
+def test_biquad_sample_form_on_the_host_matches_the_reference_vectors():
+    """biquad_apply_sample is the one per-sample entry point of the boundary (reference biquad.c:78-102): evaluated on the host, where the
+    caller's Biquad struct — the state — lives; orders 1..4 against the vectors made from the compiled reference (tests/golden/biquad.npz),
+    bit for bit, with no GPU in sight"""
+    import ctypes as C
+    import _golden as G
+    L = A.lib()
+    z = G.load("biquad")
+    for order in (1, 2, 3, 4):
+        co = A.BiquadCoefficients(*[float(v) for v in z[f"order{order}/coeffs"]])
+        x1, _ = noise(600)
+        bs = A.Biquad()
+        L.biquad_init(C.byref(bs), C.byref(co), 0.8)
+        assert bs.order == order
+        ys = np.array([L.biquad_apply_sample(C.byref(bs), float(v)) for v in x1[:600]], np.float32)
+        want = z[f"order{order}/sample"]
+        n = min(len(want), 600)
+        assert np.array_equal(ys[:n].view(np.uint32), want[:n].view(np.uint32))
