@@ -1027,9 +1027,6 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
     // rows' image [plane][16-tap half][row 0..63][16 taps]; X image [plane][column half][4-tap block][column 0..127][4 taps]
     const unsigned char *Ab0 = smem_ + (lane >> 5) * 1024 + (lane & 31) * 16;
     const unsigned char *Bb0 = smem_ + SL_A_IMG + (wave >> 2) * 4096 + (lane >> 5) * 2048 + (col & 127) * 4;
-    // output offset of this lane inside a tile: (period jl * g, slot 4 * (lane >> 5), channel c); the row's own 0..3 / +8 / +16 / +24
-    // (+ 32 for the second register tile) slots are immediates of the store
-    const unsigned int out_off = (unsigned int)((jl * q.g * g.P + 4 * (lane >> 5)) * CG + c) * 4u;
 
     // ---- the stream.  Chunk s of it sits in LDS buffer s & 1.  Between two barriers a wave multiplies the SECOND image of a chunk,
     // whose operands it read before the barrier, and the FIRST image of the next: at the barrier every wave has read the whole of
@@ -1230,19 +1227,44 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
                 }
             }
         }
-        // (the 32 stores go out together and stay in flight, behind the pieces issued before them)
+        // ---- the stores.  A lane holds, per block of four registers, four consecutive slots (frames) of ONE channel: stored as they
+        // are, an instruction writes 64 scattered dwords — 32-byte runs, eight of them per wave — and the tile's 256 such instructions
+        // queue in front of the CU's address unit long after the products have ended (the next tile's first pieces behind them).  The
+        // four lanes of a quad hold four consecutive channels: a 4 x 4 transposition inside the quad (two DPP exchanges) leaves every
+        // lane one frame's four channels, 16 contiguous bytes — eight 16-byte stores per tile instead of 32 dword stores, whole
+        // 128-byte lines per eight lanes of an 8-channel stream.
         TR (11);
+        {
+            const int qm = lane & 3;                          // this lane's place in its quad = the slot it ends up with
+            const unsigned int q_off = (unsigned int)((jl * q.g * g.P + 4 * (lane >> 5) + qm) * CG + (c & ~3)) * 4u;
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i_const = h * 32 + (r & 3) + 8 * (r >> 2);      // compile-time part of the slot
-                const int i = i_const + 4 * (lane >> 5);
-                // (always 32 store instructions per tile — the counted wait relies on it: a slot past the period goes out of the
-                // resource's range, as frames at or past n_end do, and is dropped)
-                const unsigned int off = i < rows_valid ? out_off + (unsigned int)(i_const * CG) * 4u : 0xfffffff0u;
-                __builtin_amdgcn_raw_buffer_store_b32 (__float_as_uint (y [h] [r]), rs_out, (int) off, 0, 0);
-            }
+                for (int rb = 0; rb < 4; ++rb) {
+                    unsigned int t [4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) t [u] = __float_as_uint (y [h] [4 * rb + u]);
+                    // (lane bit 0 <-> register bit 0, then lane bit 1 <-> register bit 1)
+#pragma unroll
+                    for (int pr = 0; pr < 4; pr += 2) {
+                        const unsigned int send = (qm & 1) ? t [pr] : t [pr + 1];
+                        const unsigned int recv = (unsigned int) __builtin_amdgcn_mov_dpp ((int) send, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+                        if (qm & 1) t [pr] = recv; else t [pr + 1] = recv;
+                    }
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const unsigned int send = (qm & 2) ? t [pr] : t [pr + 2];
+                        const unsigned int recv = (unsigned int) __builtin_amdgcn_mov_dpp ((int) send, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+                        if (qm & 2) t [pr] = recv; else t [pr + 2] = recv;
+                    }
+                    u32x4 v; v.x = t [0]; v.y = t [1]; v.z = t [2]; v.w = t [3];
+                    const int i_const = h * 32 + 8 * rb;      // compile-time part of the slot
+                    const int i = i_const + 4 * (lane >> 5) + qm;
+                    // (a slot past the period goes out of the resource's range, as frames at or past n_end do, and is dropped)
+                    const unsigned int off = i < rows_valid ? q_off + (unsigned int)(i_const * CG) * 4u : 0xfffffff0u;
+                    __builtin_amdgcn_raw_buffer_store_b128 (v, rs_out, (int) off, 0, 0);
+                }
+        }
         TR (12);
     }
     asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
