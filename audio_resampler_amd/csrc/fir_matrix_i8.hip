@@ -63,8 +63,9 @@ struct I8Geom {
     int super_groups;                     // groups of g * ppw consecutive periods
     int sg_per_xcd;
     unsigned char *a_planes;
-    unsigned long long *a_masks;          // [variant][row]: bit c set = chunk c of the row has a non-zero most significant digit
-    unsigned long long *tile_masks;       // [variant][32-row half]: the OR over the half's rows (quantise launch; read by fir_i8_slab_kernel)
+    unsigned long long *a_masks;          // [digit plane 0, 1][variant][row]: bit c set = chunk c of the row has a non-zero digit in that plane
+    unsigned long long *tile_masks;       // [digit plane 0, 1][variant][32-row half]: the OR over the half's rows (quantise launch; read by fir_i8_slab_kernel)
+    int mask_words;                       // tiles * g * tr: the second plane's masks sit this many words behind the first's
     const unsigned char *x_planes;        // (written through x_planes_w by the staging pass)
     unsigned int *x_planes_w;
     // exponent blocks: block e = periods [e * eb_periods, (e + 1) * eb_periods) of the launch; its planes hold 4-frame blocks
@@ -307,10 +308,10 @@ void i8_stage_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g, I8Geom q)
         const int r = max (p0.ip - a.T / 2 + 1 + jr * g.Q + I8_PADF, 0) & 3;
         const int shift = p.ip - p0.ip + r;
         bool bad = false;
-        __shared__ unsigned long long s_mask;
-        if (tid == 0) s_mask = 0ull;
+        __shared__ unsigned long long s_mask, s_mask1;
+        if (tid == 0) { s_mask = 0ull; s_mask1 = 0ull; }
         __syncthreads ();
-        unsigned long long mine = 0ull;
+        unsigned long long mine = 0ull, mine1 = 0ull;
         // [variant][chunk][plane][16-tap half][row][16 taps]: the tr * 128 bytes a workgroup stages per chunk are contiguous
         const int chunk_bytes = q.tr * 128, plane_bytes = q.tr * 32, half_bytes = q.tr * 16;
         unsigned char *base = q.a_planes + (size_t) variant * (q.ktot / I8_KC) * chunk_bytes + row * 16;
@@ -335,10 +336,12 @@ void i8_stage_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g, I8Geom q)
 #pragma unroll
             for (int pn = 0; pn < 4; ++pn) *reinterpret_cast<unsigned int *> (base + (size_t)(k4 >> 5) * chunk_bytes + pn * plane_bytes + ((k4 >> 4) & 1) * half_bytes + (k4 & 15)) = pl [pn];
             if (pl [0]) mine |= 1ull << (k4 >> 5);
+            if (pl [1]) mine1 |= 1ull << (k4 >> 5);
         }
         if (mine) atomicOr (&s_mask, mine);
+        if (mine1) atomicOr (&s_mask1, mine1);
         __syncthreads ();
-        if (tid == 0) q.a_masks [variant * q.tr + row] = s_mask;
+        if (tid == 0) { q.a_masks [variant * q.tr + row] = s_mask; q.a_masks [q.mask_words + variant * q.tr + row] = s_mask1; }
         if (bad) *q.flag = q.epoch;
         return;
     }
@@ -349,9 +352,9 @@ void i8_stage_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g, I8Geom q)
         // (behind the X workgroups of the quantise launch: the rows' masks of the launch before it, per 32-row register tile)
         const int e = (xid - q.ebs * groups * q.slices) * I8_STAGE_THREADS + tid, halves = q.tr / 32;
         if (e < q.tiles * q.g * halves) {
-            unsigned long long m = 0ull;
-            for (int r = 0; r < 32; ++r) m |= q.a_masks [(e / halves) * q.tr + (e % halves) * 32 + r];
-            q.tile_masks [e] = m;
+            unsigned long long m = 0ull, m1 = 0ull;
+            for (int r = 0; r < 32; ++r) { m |= q.a_masks [(e / halves) * q.tr + (e % halves) * 32 + r]; m1 |= q.a_masks [q.mask_words + (e / halves) * q.tr + (e % halves) * 32 + r]; }
+            q.tile_masks [e] = m; q.tile_masks [q.tiles * q.g * halves + e] = m1;
         }
         return;
     }
@@ -577,10 +580,12 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
             for (int r = 0; r < 16; ++r) acc [s] [r] = 0;
         // chunks in which some row of this tile has a non-zero most significant digit (the few around the rows' centres: taps
         // fall off as 1 / distance): everywhere else the four products with that digit plane are exactly zero and not issued
-        unsigned long long top = q.a_masks [(st * q.g + j0 % q.g) * 32 + (lane & 31)];
+        // (and likewise the second digit plane — zero in the window's tails, where the taps are below 2^-15: its four products too)
+        unsigned long long top = q.a_masks [(st * q.g + j0 % q.g) * 32 + (lane & 31)], sec = q.a_masks [q.mask_words + (st * q.g + j0 % q.g) * 32 + (lane & 31)];
 #pragma unroll
-        for (int off = 1; off < 32; off <<= 1) top |= __shfl_xor (top, off);
+        for (int off = 1; off < 32; off <<= 1) { top |= __shfl_xor (top, off); sec |= __shfl_xor (sec, off); }
         const unsigned int top_lo = __builtin_amdgcn_readfirstlane ((unsigned int) top), top_hi = __builtin_amdgcn_readfirstlane ((unsigned int)(top >> 32));
+        const unsigned int sec_lo = __builtin_amdgcn_readfirstlane ((unsigned int) sec), sec_hi = __builtin_amdgcn_readfirstlane ((unsigned int)(sec >> 32));
 
         for (int ch = 0; ch < nchunks; ++ch, ++qn) {
             // (one loop body, the LDS buffer chosen by address: two bodies made the compiler keep two copies of the accumulators)
@@ -597,10 +602,14 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
             __builtin_amdgcn_sched_group_barrier (0x100, 8, 0);
             __syncthreads ();
 #pragma unroll
-            for (int i = 1; i < 4; ++i)
+            for (int i = 2; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (i + j <= 4) acc [i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8 (av [i], bv [j], acc [i + j], 0, 0, 0);
+            if (((ch < 32 ? sec_lo >> ch : sec_hi >> (ch - 32)) & 1u) != 0u) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc [1 + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8 (av [1], bv [j], acc [1 + j], 0, 0, 0);
+            }
             if (((ch < 32 ? top_lo >> ch : top_hi >> (ch - 32)) & 1u) != 0u) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc [j] = __builtin_amdgcn_mfma_i32_32x32x32_i8 (av [0], bv [j], acc [j], 0, 0, 0);
@@ -800,10 +809,12 @@ void fir_i8_dma_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
             for (int r = 0; r < 16; ++r) acc [s] [r] = 0;
         // chunks in which some row of this tile has a non-zero most significant digit (the few around the rows' centres: taps
         // fall off as 1 / distance): everywhere else the four products with that digit plane are exactly zero and not issued
-        unsigned long long top = q.a_masks [(st * q.g + j0 % q.g) * 32 + (lane & 31)];
+        // (and likewise the second digit plane — zero in the window's tails, where the taps are below 2^-15: its four products too)
+        unsigned long long top = q.a_masks [(st * q.g + j0 % q.g) * 32 + (lane & 31)], sec = q.a_masks [q.mask_words + (st * q.g + j0 % q.g) * 32 + (lane & 31)];
 #pragma unroll
-        for (int off = 1; off < 32; off <<= 1) top |= __shfl_xor (top, off);
+        for (int off = 1; off < 32; off <<= 1) { top |= __shfl_xor (top, off); sec |= __shfl_xor (sec, off); }
         const unsigned int top_lo = __builtin_amdgcn_readfirstlane ((unsigned int) top), top_hi = __builtin_amdgcn_readfirstlane ((unsigned int)(top >> 32));
+        const unsigned int sec_lo = __builtin_amdgcn_readfirstlane ((unsigned int) sec), sec_hi = __builtin_amdgcn_readfirstlane ((unsigned int)(sec >> 32));
 
         for (int ch = 0; ch < nchunks; ++ch) {
             const unsigned char *Ab = Ab0 + qb * A_BUF, *Bb = Bb0 + qb * B_BUF;
@@ -822,10 +833,14 @@ void fir_i8_dma_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
             __builtin_amdgcn_s_barrier ();
             asm volatile ("" ::: "memory");
 #pragma unroll
-            for (int i = 1; i < 4; ++i)
+            for (int i = 2; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (i + j <= 4) acc [i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8 (av [i], bv [j], acc [i + j], 0, 0, 0);
+            if (((ch < 32 ? sec_lo >> ch : sec_hi >> (ch - 32)) & 1u) != 0u) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc [1 + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8 (av [1], bv [j], acc [1 + j], 0, 0, 0);
+            }
             if (((ch < 32 ? top_lo >> ch : top_hi >> (ch - 32)) & 1u) != 0u) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc [j] = __builtin_amdgcn_mfma_i32_32x32x32_i8 (av [0], bv [j], acc [j], 0, 0, 0);
@@ -1065,10 +1080,11 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
         // images in which some row of a register tile has a non-zero most significant digit (the few around the rows' centres:
         // taps fall off as 1 / distance): everywhere else the four products with that digit plane are exactly zero and not issued
         // (through the scalar cache, like the tile table)
-        unsigned long long top [2];
+        unsigned long long top [2], sec [2];                  // (sec: the same for the second digit plane — zero in the window's tails)
         {
             const __attribute__ ((address_space (4))) unsigned long long *tm = (const __attribute__ ((address_space (4))) unsigned long long *) q.tile_masks + (st * q.g + j0 % q.g) * 2;
             top [0] = tm [0]; top [1] = tm [1];
+            sec [0] = tm [q.tiles * q.g * 2]; sec [1] = tm [q.tiles * q.g * 2 + 1];
         }
         // this lane's channel's exponent in its period's block: loaded now, taken up behind the wait in front of the tile's first
         // barrier (where this wave drains its memory operations anyway) — nothing in flight is waited for on its account later
@@ -1092,29 +1108,34 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 int n = 0;                                    // products issued so far in this register tile's block
+                // the rows' two lower digit planes: always (five products, the pieces between them)
 #pragma unroll
-                for (int i = 1; i < 4; ++i)
+                for (int i = 2; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         if (i + j <= 4) {
                             acc [h] [i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8 (av [h] [i], bv [j], acc [h] [i + j], 0, 0, 0);
                             ++n;
-                            if (h == 0 && n == 3) piece (to, first);
-                            if (h == 0 && n == 7) piece (to, first + 1);
-                            if (h == 1 && n == 2) piece (to, first + 2);
-                            if (h == 1 && n == 5) piece (to, first + 3);
-                            if (h == 1 && n == 8) piece (to, first + 4);
+                            if (h == 0 && n == 2) piece (to, first);
+                            if (h == 0 && n == 4) piece (to, first + 1);
+                            if (h == 1 && n == 1) piece (to, first + 2);
+                            if (h == 1 && n == 3) piece (to, first + 3);
+                            if (h == 1 && n == 5) piece (to, first + 4);
                         }
                 if (h == 0) {
-                    __builtin_amdgcn_sched_group_barrier (0x008, 3, 0); __builtin_amdgcn_sched_group_barrier (0x020, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier (0x008, 4, 0); __builtin_amdgcn_sched_group_barrier (0x020, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier (0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier (0x008, 2, 0); __builtin_amdgcn_sched_group_barrier (0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier (0x008, 2, 0); __builtin_amdgcn_sched_group_barrier (0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier (0x008, 1, 0);
                 }
                 else {
+                    __builtin_amdgcn_sched_group_barrier (0x008, 1, 0); __builtin_amdgcn_sched_group_barrier (0x020, 1, 0);
                     __builtin_amdgcn_sched_group_barrier (0x008, 2, 0); __builtin_amdgcn_sched_group_barrier (0x020, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier (0x008, 3, 0); __builtin_amdgcn_sched_group_barrier (0x020, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier (0x008, 3, 0); __builtin_amdgcn_sched_group_barrier (0x020, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier (0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier (0x008, 2, 0); __builtin_amdgcn_sched_group_barrier (0x020, 1, 0);
+                }
+                // the second plane: zero in the window's tails; the first: zero all but around the rows' centres
+                if ((sec [h] >> sub) & 1ull) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc [h] [1 + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8 (av [h] [1], bv [j], acc [h] [1 + j], 0, 0, 0);
                 }
                 if ((top [h] >> sub) & 1ull) {
 #pragma unroll
@@ -1353,12 +1374,13 @@ static size_t i8_layout (const ArtFirArgs *a, const MfmaGeom &g, int cgt, I8Geom
     q.x_bytes = (size_t) q.ebs * 4 * q.eb_plane_bytes;
     q.b0 = 0;
     const size_t a_bytes = (size_t) q.tiles * q.g * (q.ktot / I8_KC) * (size_t)(q.tr * 128);
-    const size_t masks = (size_t) q.tiles * q.g * q.tr * 8 + (size_t) q.tiles * q.g * (q.tr / 32) * 8, shifts = (size_t) q.ebs * a->C * 4;
+    const size_t masks = 2 * ((size_t) q.tiles * q.g * q.tr * 8 + (size_t) q.tiles * q.g * (q.tr / 32) * 8), shifts = (size_t) q.ebs * a->C * 4;
     const size_t teams = (size_t) q.ebs * q.slices * a->C * 4;
     const size_t head = (ART_I8_HEAD_BYTES + masks + teams + shifts + 255) & ~(size_t) 255;
     q.flag = (int *) base; q.epoch = 0;
     q.a_masks = (unsigned long long *)(base + ART_I8_HEAD_BYTES);
-    q.tile_masks = q.a_masks + (size_t) q.tiles * q.g * q.tr;
+    q.mask_words = q.tiles * q.g * q.tr;
+    q.tile_masks = q.a_masks + 2 * (size_t) q.mask_words;
     q.peaks = (unsigned int *)(base + ART_I8_HEAD_BYTES + masks);
     q.shifts = (int *)(base + ART_I8_HEAD_BYTES + masks + teams);
     q.a_planes = (unsigned char *) base + head;

@@ -894,7 +894,8 @@ static void *timing_event (struct artamd_resampler *hip)
 
 /* Did the last call's FIR run on the fixed-point matrix kernel?  0: no; 1: yes; 2: it was enqueued and stood down (a sample
  * outside (-1.98, 1.98) or not finite: the f32 kernel behind it produced the call).  *pairsPerChunk (optional): digit-pair
- * products issued per 32-tap chunk and 32 x 32 outputs, averaged over the tile families (9 .. 13).  Synchronises. */
+ * products issued per 32-tap chunk and 32 x 32 outputs, averaged over the tile families (5 .. 13: the products with a digit plane of
+ * the rows that is all zero in a chunk — the first away from the rows' centres, the second in the window's tails — are not issued).  Synchronises. */
 int resampleHipLastFixedPoint (Resample *cxt, double *pairsPerChunk)
 {
     struct artamd_resampler *hip = cxt->hip->nshards ? cxt->hip->shards [0]->hip : cxt->hip;
@@ -903,18 +904,21 @@ int resampleHipLastFixedPoint (Resample *cxt, double *pairsPerChunk)
     ENTER_DEVICE (hip);
     int flag = 0;
     const int words = hip->last_fixed [1], chunks = hip->last_fixed [2];
-    unsigned long long *masks = malloc (sizeof (unsigned long long) * (size_t)(words > 0 ? words : 1));
+    /* (the rows' masks of the first two digit planes, one after the other) */
+    unsigned long long *masks = malloc (sizeof (unsigned long long) * (size_t)(words > 0 ? 2 * words : 1));
     arthip_d2h (&flag, hip->d_planes, sizeof (flag), hip->stream);
-    if (masks && words > 0) arthip_d2h (masks, (char *) hip->d_planes + ART_I8_HEAD_BYTES, sizeof (unsigned long long) * (size_t) words, hip->stream);
+    if (masks && words > 0) arthip_d2h (masks, (char *) hip->d_planes + ART_I8_HEAD_BYTES, sizeof (unsigned long long) * (size_t)(2 * words), hip->stream);
     arthip_sync (hip->stream);
     if (pairsPerChunk && masks && words > 0 && chunks > 0) {
-        double full = 0.0;
-        for (int v = 0; v < words; v += 32) {                 /* a tile family's mask = OR over its 32 rows */
-            unsigned long long m = 0;
-            for (int r = 0; r < 32; ++r) m |= masks [v + r];
-            for (; m; m &= m - 1) full += 1.0;
-        }
-        *pairsPerChunk = 9.0 + 4.0 * full / ((double)(words / 32) * chunks);
+        double full [2] = { 0.0, 0.0 };
+        for (int pl = 0; pl < 2; ++pl)
+            for (int v = 0; v < words; v += 32) {             /* a tile family's mask = OR over its 32 rows */
+                unsigned long long m = 0;
+                for (int r = 0; r < 32; ++r) m |= masks [pl * words + v + r];
+                for (; m; m &= m - 1) full [pl] += 1.0;
+            }
+        /* 5 products with the rows' two lower digit planes always, 4 more per chunk whose second plane is not all zero, 4 more where the first is not */
+        *pairsPerChunk = 5.0 + 4.0 * (full [0] + full [1]) / ((double)(words / 32) * chunks);
     }
     free (masks);
     LEAVE_DEVICE (hip);

@@ -258,7 +258,8 @@ def test_samples_the_digits_cannot_hold_hand_the_launch_to_the_f32_kernel(what, 
 
 def test_fixed_point_kernel_skips_the_zero_digit_plane_and_is_chosen_where_it_pays():
     """diagnostics: of the 13 digit-pair products per chunk, the 4 with the rows' most significant digit are only issued in the
-    chunks around the rows' centres (taps fall off as 1 / distance) — on the headline filter, fewer than 10 of 13 on average.
+    chunks around the rows' centres (taps fall off as 1 / distance), the 4 with the second digit not in the window's tails (taps below
+    2^-15) — on the headline filter, between 8 and 9 of 13 on average.
     The automatic choice takes the fixed-point kernel for long filters in big calls only (fir_matrix.hip, artfir_planes_bytes)."""
     ratio = 48000 / 44100
     for ch, T, frames, want in ((8, 988, 300000, 1), (8, 988, 60000, 0), (2, 380, 1000000, 0)):
@@ -268,7 +269,7 @@ def test_fixed_point_kernel_skips_the_zero_digit_plane_and_is_chosen_where_it_pa
         state, pairs = r.fixed_point()
         assert u == frames and r.last_kernel() == 2 and state == want, (ch, T, frames, state)
         if want:
-            assert 9.0 < pairs < 10.0, pairs
+            assert 8.0 < pairs < 9.0, pairs
 
 
 def test_fixed_point_long_call_with_many_ring_epochs():
