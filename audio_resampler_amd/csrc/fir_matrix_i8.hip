@@ -987,6 +987,7 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
     const __attribute__ ((address_space (4))) int *tile_w0 = (const __attribute__ ((address_space (4))) int *) g.tile_w0;
 
     int f_seg = -1, f_ch = 0, f_c1 = 0;
+    unsigned long long f_live [2] = { 0ull, 0ull };           // the fetched tile's images in which the rows' digit plane 0 / 1 is not all zero (either register tile)
     __amdgpu_buffer_rsrc_t f_ra = make_rsrc (nullptr, 0u), f_rb = f_ra;
     unsigned int f_va = 0u, f_vb = 0u;                        // the lanes' offsets of the stream's next chunk
     auto open_segment = [&] () {                              // the next segment of this workgroup's list (there is one)
@@ -1002,6 +1003,11 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
         f_rb = make_rsrc (q.x_planes + from, (unsigned int) min (q.x_bytes - from, (size_t) 0xfffffff0u));
         const unsigned int fa_bytes = (unsigned int) nsub * A_STEP;
         f_ra = make_rsrc (q.a_planes + (size_t)(st * q.g + j0 % q.g) * fa_bytes, fa_bytes);
+        {
+            const __attribute__ ((address_space (4))) unsigned long long *tm = (const __attribute__ ((address_space (4))) unsigned long long *) q.tile_masks + (st * q.g + j0 % q.g) * 2;
+            f_live [0] = tm [0] | tm [1];
+            f_live [1] = tm [q.tiles * q.g * 2] | tm [q.tiles * q.g * 2 + 1];
+        }
         f_ch = c0;
         f_va = a_off + (unsigned int)(2 * c0) * A_STEP;
         f_vb = boff + (unsigned int)((j0 + m * q.g) / q.eb_periods - eb) * eb_hop + (unsigned int)(2 * c0) * B_STEP;
@@ -1014,10 +1020,16 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
     // the resources are empty and the pieces fetch nothing.
     int total = D * nch + (hi - lo), issued = 0;              // chunks of this workgroup's stream; handed to the DMA so far
     unsigned int d_va = 0u, d_vb = 0u;                        // the lanes' offsets of the chunk being issued
+    // (this wave's piece of the rows belongs to digit plane wave >> 1: where that plane is all zero in an image — its products are not
+    // issued — the piece is not fetched either: a scalar offset past the resource's end, zeros into the LDS, nothing through the L2.
+    // The rows' first plane lives in 4 of 33 images, the second in 24: a quarter of the rows' bytes stay where they are)
+    int d_skip [2] = { 0, 0 };
     auto next_chunk = [&] () {
         if (issued < total) {
             if (f_seg < 0 || f_ch == f_c1) open_segment ();
             d_va = f_va; d_vb = f_vb;
+#pragma unroll
+            for (int im = 0; im < 2; ++im) d_skip [im] = (wave >> 1) < 2 && !((f_live [wave >> 1] >> (2 * f_ch + im)) & 1ull) ? 0x7ffffff0 : 0;
             f_va += 2 * A_STEP; f_vb += 2 * B_STEP;
             ++f_ch; ++issued;
         }
@@ -1026,8 +1038,14 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
     auto piece = [&] (int buf, int idx) {
         const int im = idx / 5, pc = idx % 5;
         unsigned char *img = smem_ + buf * SL_BUF + im * SL_IMG;
-        if (pc == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds (f_ra, (lds_ptr_t)(img + wave * 1024), 16, (int)(d_va + (unsigned int) im * A_STEP), 0, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds (f_rb, (lds_ptr_t)(img + SL_A_IMG + (pc - 1) * 8192 + wave * 1024), 16, (int)(d_vb + (unsigned int) im * B_STEP), (pc - 1) * plane_step, 0, 0);
+#ifndef I8_SLAB_A_AUX
+#define I8_SLAB_A_AUX 0
+#endif
+#ifndef I8_SLAB_X_AUX
+#define I8_SLAB_X_AUX 0
+#endif
+        if (pc == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds (f_ra, (lds_ptr_t)(img + wave * 1024), 16, (int)(d_va + (unsigned int) im * A_STEP), d_skip [im], 0, I8_SLAB_A_AUX);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds (f_rb, (lds_ptr_t)(img + SL_A_IMG + (pc - 1) * 8192 + wave * 1024), 16, (int)(d_vb + (unsigned int) im * B_STEP), (pc - 1) * plane_step, 0, I8_SLAB_X_AUX);
     };
 
     {   // the two waves of a SIMD share its matrix pipe: left alone they fall into step (both read, then both multiply);
@@ -1192,7 +1210,18 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
             };
             const int r_first = owner_of (t * nch), r_last = owner_of ((t + 1) * nch - 1);
             const unsigned int wave_bytes = 16u * 64u * 16u;
-            {
+            unsigned int *count = sl.arrivals + ((size_t)(xcd * SL_MAX_SK + t) * 8 + wave);
+            // (the part a workgroup walks LAST — the head of the run's next tile — usually finds the tile's other part long arrived: it
+            // looks first, and if only itself is missing it is the one that finishes and leaves nothing behind: half of the parts'
+            // bytes, and a written-through store's round trip, saved)
+            unsigned int before = 0u;
+            bool look = k == nseg - 1 && k != D;
+            if (look) {
+                if (lane == 0) before = __hip_atomic_load (count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                before = (unsigned int) __builtin_amdgcn_readfirstlane ((int) before);
+                look = before == (unsigned int)(r_last - r_first);
+            }
+            if (!look) {
                 const int which = k == D ? 0 : 1;
                 const __amdgpu_buffer_rsrc_t rs_part = make_rsrc (sl.parts + ((size_t)((xcd * W + rank) * 2 + which) * 8 + wave) * wave_bytes, wave_bytes);
 #pragma unroll
@@ -1202,12 +1231,10 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
                     v.x = (unsigned int) x0; v.y = (unsigned int)(x0 >> 32); v.z = (unsigned int) x1; v.w = (unsigned int)(x1 >> 32);
                     __builtin_amdgcn_raw_buffer_store_b128 (v, rs_part, (r * 64 + lane) * 16, 0, COHERENT);
                 }
+                asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");       // (written through: the count below is only seen behind them)
+                if (lane == 0) before = __hip_atomic_fetch_add (count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                before = (unsigned int) __builtin_amdgcn_readfirstlane ((int) before);
             }
-            asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");       // (written through: the count below is only seen behind them)
-            unsigned int *count = sl.arrivals + ((size_t)(xcd * SL_MAX_SK + t) * 8 + wave);
-            unsigned int before = 0u;
-            if (lane == 0) before = __hip_atomic_fetch_add (count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            before = (unsigned int) __builtin_amdgcn_readfirstlane ((int) before);
             if (before != (unsigned int)(r_last - r_first)) { TR (10); continue; }
             if (lane == 0) __hip_atomic_store (count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // (for the next launch)
             for (int rr = r_first; rr <= r_last; ++rr) {

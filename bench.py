@@ -321,6 +321,10 @@ def main():
                          "unit_note": "integer multiply-adds of v_mfma_i32_32x32x32_i8, 2 ops each (TOP/s), against the dense int8 MFMA peak" if fixed else "f32 MFMA",
                          "frac": round(tflops_exec / peak, 4),
                          "frac_of_sustained_live_peak": round(tflops_exec / SUSTAINED_LIVE_I8_TOPS, 4) if fixed else None,
+                         "frac_at_round3_products": round(rate * 2 * kpad * 9.5 / 1e12 / peak, 4) if fixed else None,
+                         "frac_at_round3_products_note": ("the same samples/s priced at round 3's 9.5 products per chunk (this round skips the products with the "
+                                                          "rows' second digit plane where it is all zero: fewer operations EXECUTED, so `frac` does not rise "
+                                                          "with the speed-up; this figure is the one comparable with rounds 2-3)") if fixed else None,
                          "sustained_live_peak": SUSTAINED_LIVE_I8_TOPS if fixed else None,
                          "sustained_live_peak_note": ("v_mfma_i32_32x32x32_i8 alone, operands in registers, pseudo-random bytes, 0.6 s: 3,030-3,190 TOP/s at "
                                                       "1.70-1.93 GHz (zero operands: 4,530 at 2.39 GHz) — tools/micro/mfma_sustain.hip, profiles/r4_mfma_sustain.txt: "

@@ -5,6 +5,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-evidence}
+RND=${2:-r4}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -43,8 +44,8 @@ python $R/tools/bench_configs.py --steps 30 > $OUT/configs.jsonl 2> $OUT/configs
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc -o calib_fetch -- $R/tools/micro/fetch_calib > $OUT/fetch_calib.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc -o calib_write -- $R/tools/micro/fetch_calib >> $OUT/fetch_calib.log 2>&1
 # the same bench line with the traffic measured in THIS lease (roofline_report.py writes the json from the passes above)
-python $R/tools/roofline_report.py $OUT $OUT/report r3 > $OUT/report.log 2>&1
-python $R/bench.py --pmc-json $OUT/report/r3_traffic.json > $OUT/bench_pmc.json 2> $OUT/bench_pmc.err
+python $R/tools/roofline_report.py $OUT $OUT/report $RND > $OUT/report.log 2>&1
+python $R/bench.py --pmc-json $OUT/report/${RND}_traffic.json > $OUT/bench_pmc.json 2> $OUT/bench_pmc.err
 python $R/tools/bench_wide.py --block 1048576 --steps 20 > $OUT/wide.jsonl 2>/dev/null
 bash $R/tools/bench_fixed_point.sh > $OUT/fixed_point_shapes.txt 2>&1
 ARTAMD_HOST_TRACE=1 python $R/tools/bench_host_api.py > $OUT/host_api.txt 2>&1
