@@ -246,8 +246,8 @@ void i8_stage_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g, I8Geom q)
 {
     const int tid = threadIdx.x;
     // (PEAK launch: the row workgroups come first in the grid — latency chains, they finish under the X workgroups' traffic)
-    // (32-slot tiles: the residue-0 row workgroups write the f32 tables too — 320 workgroups fewer, 1.1 us of the peak pass)
-    const unsigned int t_wgs = PEAK && q.tr != 32 ? (unsigned int) g.slot_tiles * 32u : 0u;
+    // (the residue-0 row workgroups write the f32 tables too — 320 workgroups fewer, 1.1 us of the peak pass)
+    const unsigned int t_wgs = 0u;
     const unsigned int a_wgs = PEAK ? t_wgs + (unsigned int)(q.tiles * q.g * q.tr) : 0u;
     // what mfma_prepare_kernel leaves for the f32 streaming kernels (that kernel is not launched at all then), for row `row` of the
     // 32-row slot tile `st`: the effective row in float, the canonical position, the tile's origin and pass-through rows
@@ -299,7 +299,7 @@ void i8_stage_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g, I8Geom q)
         const int ab = (int)(blockIdx.x - t_wgs);
         const int variant = ab / q.tr, row = ab - variant * q.tr;
         const int st = variant / q.g, jr = variant - st * q.g;
-        if (q.tr == 32 && jr == 0) write_tables (st, row);
+        if (jr == 0 && (q.tr == 32 ? st : 2 * st + (row >> 5)) < g.slot_tiles) write_tables (q.tr == 32 ? st : 2 * st + (row >> 5), row & 31);
         const int rows_valid = min (q.tr, g.P - st * q.tr);
         const Pos p0 = locate<INTERP> (a, segs, a.n_begin + st * q.tr);
         const Pos p = locate<INTERP> (a, segs, a.n_begin + st * q.tr + min (row, rows_valid - 1));
@@ -1446,7 +1446,7 @@ int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGe
         q.b0 = (la > 0 ? la : 0) >> 2;
     }
     const unsigned int x_wgs = (unsigned int)(q.ebs * (a->C / q.cgrp) * q.slices);
-    const dim3 pgrid (x_wgs + (q.tr != 32 ? (unsigned int) g.slot_tiles * 32u : 0u) + (unsigned int)(q.tiles * q.g * q.tr)), xgrid (x_wgs + (unsigned int)((q.tiles * q.g * (q.tr / 32) + I8_STAGE_THREADS - 1) / I8_STAGE_THREADS));
+    const dim3 pgrid (x_wgs + (unsigned int)(q.tiles * q.g * q.tr)), xgrid (x_wgs + (unsigned int)((q.tiles * q.g * (q.tr / 32) + I8_STAGE_THREADS - 1) / I8_STAGE_THREADS));
     if (a->interpolate) {
         hipLaunchKernelGGL ((i8_stage_kernel<true, true>), pgrid, dim3 (I8_STAGE_THREADS), 0, st, *a, *segs, g, q);
         hipLaunchKernelGGL ((i8_stage_kernel<true, false>), xgrid, dim3 (I8_STAGE_THREADS), 0, st, *a, *segs, g, q);
