@@ -1339,7 +1339,7 @@ bool artfir_i8_slab_enabled ()
 // fill the chip better and walk their K range sooner)
 static int i8_slab_min_tiles ()
 {
-    static const int v = [] { const char *e = getenv ("ARTAMD_I8_SLAB_MIN"); return e && *e ? atoi (e) : 64; } ();
+    static const int v = [] { const char *e = getenv ("ARTAMD_I8_SLAB_MIN"); return e && *e ? atoi (e) : 16; } ();
     return v;
 }
 
