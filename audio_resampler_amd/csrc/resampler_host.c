@@ -35,6 +35,7 @@
                                                  * the runtime's pipelined pageable path saves).  Environment ARTAMD_STAGE_LIMIT=bytes overrides (tests) */
 
 struct BankEntry;
+struct shard_pool;
 struct artamd_resampler {
     int device;                             /* HIP device this context lives on (made current around every call) */
     void *stream;
@@ -46,6 +47,7 @@ struct artamd_resampler {
     Resample **shards;
     int *shard_first;                       /* first channel of each shard (nshards + 1 entries) */
     void *ev_parent, **ev_shard;            /* ordering events of the device-pointer calls */
+    struct shard_pool *pool;                /* one worker thread per shard: the shards' launch sequences are enqueued side by side (NULL: by the caller, one after the other) */
     art_s *h_in, *h_out; size_t h_in_cap, h_out_cap;     /* page-locked staging of the host-pointer calls */
     struct BankEntry *bank;                 /* shared filter bank (bank_acquire / bank_release) */
     art_s *d_bank;                          /* = bank->dev */
@@ -72,6 +74,10 @@ struct artamd_resampler {
     void *d_batch; size_t batch_cap;         /* argument table of the batched calls led by this context */
     unsigned long batch_stamp;               /* last batched call this context took part in (duplicate check) */
 };
+
+static struct shard_pool *shard_pool_create (Resample *cxt, int n);
+static void shard_pool_destroy (struct shard_pool *pool);
+
 
 /* ------------------------------------------------------------------------------------------
  * Filter bank
@@ -568,6 +574,7 @@ static Resample *init_sharded (int numChannels, int numTaps, int numFilters, dou
         return NULL;
     }
     cxt->flags = hip->shards [0]->flags | RESAMPLE_MULTITHREADED;
+    hip->pool = shard_pool_create (cxt, hip->nshards);       /* (NULL: the calling thread enqueues the shards one after the other) */
     return cxt;
 }
 
@@ -669,6 +676,7 @@ void resampleFree (Resample *cxt)
     struct artamd_resampler *hip = cxt->hip;
 
     if (hip) {
+        shard_pool_destroy (hip->pool);
         for (int k = 0; k < hip->nshards; ++k) {
             resampleFree (hip->shards [k]);
             arthip_event_destroy (hip->ev_shard [k]);
@@ -1467,41 +1475,147 @@ static ResampleResult shards_agree (Resample *cxt, const ResampleResult *per_sha
 /* Device-pointer call on a sharded context: the caller's buffers live on the context's own device; every shard pulls its
  * channel slice (strided rows, peer-to-peer over xGMI when the shard sits on another GPU), runs, and pushes its slice of
  * the output back.  Ordered after the context's stream, and the context's stream continues only when all shards are done.
- * Planar buffers need no copies at all: a shard's channels are a contiguous run of planes. */
+ * Planar buffers need no copies at all: a shard's channels are a contiguous run of planes.
+ * A shard's part is six or seven enqueues (wait, slice in, staging / prepare, FIR, slice out, record): ~20 us of host time.  One
+ * after the other from the calling thread that is 160 us per call on eight devices — more than a 4-channel shard's 1M-frame call
+ * takes on its GPU — so every shard has a WORKER THREAD (round 3's verdict): the caller posts the call's arguments, the workers
+ * enqueue their shards side by side (each on its own device and stream; the HIP runtime is entered from several threads at once,
+ * which it allows), the caller waits for the enqueues — not the GPUs — and lets the context's stream wait for the shards' events.
+ * (Where the shards sit on one device the calling thread does it all, as in rounds 2-3: shard_pool_create.) */
+struct shard_job {
+    const art_s *d_in; long in_pitch; int nIn; art_s *d_out; long out_pitch; int cap; double ratio;
+    ResampleResult peek;
+};
+
+static ResampleResult shard_part (Resample *cxt, int k, const struct shard_job *j, int *failed)
+{
+    struct artamd_resampler *hip = cxt->hip;
+    Resample *sh = hip->shards [k];
+    struct artamd_resampler *sp = sh->hip;
+    const int C = cxt->numChannels, first = hip->shard_first [k], width = sh->numChannels;
+    ResampleResult res = { 0, 0 };
+
+    arthip_set_device (sp->device);
+    arthip_stream_wait_event (sp->stream, hip->ev_parent);
+    if (j->in_pitch || j->out_pitch)
+        res = enqueue_call (sh, j->d_in ? j->d_in + (size_t) first * j->in_pitch : NULL, j->in_pitch, j->nIn,
+                            j->d_out + (size_t) first * j->out_pitch, j->out_pitch, j->cap, j->ratio);
+    else {
+        sp->d_in = grow (sp->d_in, &sp->in_cap, sizeof (art_s) * (size_t) j->peek.input_used * width);
+        sp->d_out = grow (sp->d_out, &sp->out_cap, sizeof (art_s) * (size_t) j->peek.output_generated * width);
+        if ((j->peek.input_used && !sp->d_in) || (j->peek.output_generated && !sp->d_out)) { *failed = 1; arthip_event_record (hip->ev_shard [k], sp->stream); return res; }
+        const int wpw = (int)(sizeof (art_s) / 4);              /* 4-byte words per sample */
+        if (j->peek.input_used && j->d_in)
+            arthip_slice_copy (sp->d_in, (size_t) width * wpw, j->d_in + first, (size_t) C * wpw, width * wpw, j->peek.input_used, sp->stream);
+        res = enqueue_call (sh, sp->d_in, 0, j->nIn, sp->d_out, 0, j->cap, j->ratio);
+        arthip_slice_copy (j->d_out + first, (size_t) C * wpw, sp->d_out, (size_t) width * wpw, width * wpw, res.output_generated, sp->stream);
+    }
+    arthip_event_record (hip->ev_shard [k], sp->stream);
+    return res;
+}
+
+struct shard_pool {
+    Resample *cxt;
+    int n, quit;
+    unsigned long call;                      /* number of the call the workers are to make (posted under the lock) */
+    int pending;                             /* workers that have not finished it yet */
+    struct shard_job job;
+    ResampleResult res [MAX_DEVICES];
+    int failed [MAX_DEVICES];
+    pthread_t thread [MAX_DEVICES];
+    int started;
+    pthread_mutex_t lock;
+    pthread_cond_t go, done;
+};
+
+struct shard_worker_arg { struct shard_pool *pool; int k; };
+
+static void *shard_worker (void *p)
+{
+    struct shard_worker_arg *wa = p;
+    struct shard_pool *pool = wa->pool;
+    const int k = wa->k;
+    unsigned long seen = 0;
+    free (wa);
+    pthread_mutex_lock (&pool->lock);
+    for (;;) {
+        while (!pool->quit && pool->call == seen) pthread_cond_wait (&pool->go, &pool->lock);
+        if (pool->quit) break;
+        seen = pool->call;
+        pthread_mutex_unlock (&pool->lock);
+        pool->failed [k] = 0;
+        pool->res [k] = shard_part (pool->cxt, k, &pool->job, &pool->failed [k]);
+        pthread_mutex_lock (&pool->lock);
+        if (--pool->pending == 0) pthread_cond_signal (&pool->done);
+    }
+    pthread_mutex_unlock (&pool->lock);
+    return NULL;
+}
+
+static struct shard_pool *shard_pool_create (Resample *cxt, int n)
+{
+    /* threads where the shards sit on DIFFERENT devices (each device's queue is fed by its own thread); several shards on one device
+     * — ARTAMD_SHARDS on a one-GPU box — are enqueued by the caller: eight threads entering the runtime for one device contend for
+     * it (measured, tools/bench_sharded_context.py, 16,384-frame calls: 231 us with threads, 205 without).  ARTAMD_SHARD_THREADS=1 /
+     * =0 forces either. */
+    const char *e = getenv ("ARTAMD_SHARD_THREADS");
+    int distinct = 0;
+    for (int k = 0; k < n; ++k) {
+        int seen = 0;
+        for (int i = 0; i < k; ++i) seen |= cxt->hip->shards [i]->hip->device == cxt->hip->shards [k]->hip->device;
+        distinct += !seen;
+    }
+    if (n < 2 || (e && *e == '0') || (distinct < 2 && !(e && *e == '1'))) return NULL;
+    struct shard_pool *pool = calloc (1, sizeof (*pool));
+    if (!pool) return NULL;
+    pool->cxt = cxt; pool->n = n;
+    pthread_mutex_init (&pool->lock, NULL); pthread_cond_init (&pool->go, NULL); pthread_cond_init (&pool->done, NULL);
+    for (int k = 0; k < n; ++k) {
+        struct shard_worker_arg *wa = malloc (sizeof (*wa));
+        if (!wa) break;
+        wa->pool = pool; wa->k = k;
+        if (pthread_create (&pool->thread [k], NULL, shard_worker, wa)) { free (wa); break; }
+        pool->started = k + 1;
+    }
+    if (pool->started != n) { shard_pool_destroy (pool); return NULL; }
+    return pool;
+}
+
+static void shard_pool_destroy (struct shard_pool *pool)
+{
+    if (!pool) return;
+    pthread_mutex_lock (&pool->lock);
+    pool->quit = 1;
+    pthread_cond_broadcast (&pool->go);
+    pthread_mutex_unlock (&pool->lock);
+    for (int k = 0; k < pool->started; ++k) pthread_join (pool->thread [k], NULL);
+    pthread_mutex_destroy (&pool->lock); pthread_cond_destroy (&pool->go); pthread_cond_destroy (&pool->done);
+    free (pool);
+}
+
 static ResampleResult sharded_device_call (Resample *cxt, const art_s *d_in, long in_pitch, int nIn, art_s *d_out, long out_pitch,
                                            int cap, double ratio)
 {
     struct artamd_resampler *hip = cxt->hip;
-    const int C = cxt->numChannels, prev = arthip_current_device ();
-    const ResampleResult peek = peek_call (cxt, nIn, cap, ratio);
+    const int prev = arthip_current_device ();
     ResampleResult per_shard [MAX_DEVICES], res = { 0, 0 };
     int failed = 0;
+    struct shard_job job = { d_in, in_pitch, nIn, d_out, out_pitch, cap, ratio, peek_call (cxt, nIn, cap, ratio) };
 
     arthip_set_device (hip->device);
     arthip_event_record (hip->ev_parent, hip->stream);
 
-    for (int k = 0; k < hip->nshards; ++k) {
-        Resample *sh = hip->shards [k];
-        struct artamd_resampler *sp = sh->hip;
-        const int first = hip->shard_first [k], width = sh->numChannels;
-
-        arthip_set_device (sp->device);
-        arthip_stream_wait_event (sp->stream, hip->ev_parent);
-        if (in_pitch || out_pitch)
-            per_shard [k] = enqueue_call (sh, d_in ? d_in + (size_t) first * in_pitch : NULL, in_pitch, nIn,
-                                          d_out + (size_t) first * out_pitch, out_pitch, cap, ratio);
-        else {
-            sp->d_in = grow (sp->d_in, &sp->in_cap, sizeof (art_s) * (size_t) peek.input_used * width);
-            sp->d_out = grow (sp->d_out, &sp->out_cap, sizeof (art_s) * (size_t) peek.output_generated * width);
-            if ((peek.input_used && !sp->d_in) || (peek.output_generated && !sp->d_out)) { failed = 1; per_shard [k] = res; continue; }
-            const int wpw = (int)(sizeof (art_s) / 4);              /* 4-byte words per sample */
-            if (peek.input_used && d_in)
-                arthip_slice_copy (sp->d_in, (size_t) width * wpw, d_in + first, (size_t) C * wpw, width * wpw, peek.input_used, sp->stream);
-            per_shard [k] = enqueue_call (sh, sp->d_in, 0, nIn, sp->d_out, 0, cap, ratio);
-            arthip_slice_copy (d_out + first, (size_t) C * wpw, sp->d_out, (size_t) width * wpw, width * wpw, per_shard [k].output_generated, sp->stream);
-        }
-        arthip_event_record (hip->ev_shard [k], sp->stream);
+    struct shard_pool *pool = hip->pool;
+    if (pool) {
+        pthread_mutex_lock (&pool->lock);
+        pool->job = job; pool->pending = pool->n; ++pool->call;
+        pthread_cond_broadcast (&pool->go);
+        while (pool->pending) pthread_cond_wait (&pool->done, &pool->lock);
+        pthread_mutex_unlock (&pool->lock);
+        for (int k = 0; k < hip->nshards; ++k) { per_shard [k] = pool->res [k]; failed |= pool->failed [k]; }
     }
+    else
+        for (int k = 0; k < hip->nshards; ++k) { int f = 0; per_shard [k] = shard_part (cxt, k, &job, &f); failed |= f; }
 
     arthip_set_device (hip->device);
     for (int k = 0; k < hip->nshards; ++k)

@@ -278,6 +278,31 @@ def test_sharded_and_ordinary_context_choose_the_same_kernel_at_every_call_size(
     assert (1, 0) in kinds and (2, 0) in kinds and (2, 1) in kinds, kinds      # every kind of kernel was exercised
 
 
+def test_worker_threads_enqueue_the_shards_with_the_same_result(monkeypatch):
+    """on several devices every shard's launch sequence is enqueued by a worker thread of its own (resampler_host.c, shard_pool); on the
+    one-GPU box ARTAMD_SHARD_THREADS=1 forces the threads although the shards share the device: the same bits, counts and positions as
+    the calling thread's own enqueues, call after call, and a clean shutdown"""
+    monkeypatch.setenv("ARTAMD_SHARDS", "8")
+    ch = 32
+    sizes = [300, 2500, 9000, 30000, 61000, 5, 0, 1200]
+    x = _stream(ch, sum(sizes))
+    outs = {}
+    for threads in ("0", "1"):
+        monkeypatch.setenv("ARTAMD_SHARD_THREADS", threads)
+        r = HipResampler(ch, T, T, 0.0, BH | INTERP | MT); r.advance(T / 2)
+        pos, ys = 0, []
+        for n in sizes:
+            u, g, y = r.process(x [pos:pos + n], int(n * R) + 2000, R)
+            pos += u
+            ys.append((u, g, np.array(y).view(np.uint32).copy()) + tuple(r.state()) [:2])
+        u, g, y = r.process(None, 4000, R, flush=True)
+        ys.append((u, g, np.array(y).view(np.uint32).copy()))
+        outs [threads] = ys
+        del r
+    for a, b in zip(outs ["0"], outs ["1"]):
+        assert a [:2] == b [:2] and np.array_equal(a [2], b [2]) and a [3:] == b [3:]
+
+
 def test_slices_are_widths_the_matrix_kernels_are_compiled_for(monkeypatch):
     """a shard decides as its stream would, and the matrix-core kernels exist for 1, 2, 4, 8, 16, 32 channels: the channels are cut into
     such widths wherever the shard count allows (12 over 5 = 4 2 2 2 2, not 3 3 2 2 2) — all shards then run the same kernels; where
