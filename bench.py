@@ -283,7 +283,7 @@ def main():
                 tr = json.load(open(name if os.path.isabs(name) or os.path.exists(name) else os.path.join(ROOT, "profiles", name)))
                 w = tr["workload"]
                 if kernel_used == 2 and bool(tr.get("fixed_point", False)) == fixed and (w["block_frames"], w["channels"], w["taps"]) == (block, Cn, TAPS) and launches == args.steps \
-                        and tr.get("kernel", fixed_kernel_name) == fixed_kernel_name:
+                        and (fixed_kernel_name or "fir_mfma") in tr.get("kernel", fixed_kernel_name or "fir_mfma"):
                     traffic = tr["traffic_bytes_per_launch"]
                     traffic_source = (f"--pmc-json {name}: rocprofv3 --pmc passes of this command in the same lease" if name == args.pmc_json else
                                       f"committed profiles/{name}: rocprofv3 --pmc passes of this command on an earlier box (not measured in this run)")

@@ -54,7 +54,7 @@ st = stats("headline")
 fixed = str(bench.get("dtype", "")).startswith("i8")
 frag = "fir_i8_" if fixed else "fir_mfma"
 kname, (calls, avg_ns, pct) = find(st, frag)
-c = counters("headline", frag)
+c = counters("headline", kname)          # (the headline kernel by its full name: bench.py also runs config D — 32 channels — on the same kernel template)
 spl = bench["roofline"]["algorithmic_bytes_per_launch"] / bench["roofline"]["bytes_per_sample"]
 exec_flop = bench["roofline"]["flop_per_sample_executed"]
 tf = spl * exec_flop / (avg_ns * 1e-9) / 1e12
@@ -86,7 +86,7 @@ if os.path.exists(p6):
     b6 = json.load(open(p6)); shutil.copy(p6, os.path.join(dst, f"{rnd}_final_bench_f32.json"))
     st6 = stats("headline_f32"); k6, v6 = find(st6, "fir_mfma_stream")
     if k6:
-        c6 = counters("headline_f32", "fir_mfma_stream")
+        c6 = counters("headline_f32", k6)
         tf6 = spl * b6["roofline"]["flop_per_sample_executed"] / (v6[1] * 1e-9) / 1e12
         tr6 = int(c6["FETCH_SIZE"] * 1024 * 2 + c6["WRITE_SIZE"] * 1024) if ("FETCH_SIZE" in c6 and "WRITE_SIZE" in c6) else None
         rows.append((f"headline workload on the f32 streaming kernel (--kernel 6): {b6['value']} Msamples/s", k6, v6[0], v6[1], b6["roofline"]["flop_per_sample_executed"],
