@@ -38,6 +38,19 @@ __device__ __forceinline__ art_s load_frame (const ArtFirArgs &a, int lin_floor,
     return a.in_pitch ? a.in [(size_t) ch * a.in_pitch + f] : a.in [(size_t) f * a.C + ch];
 }
 
+// the same value through ONE load (address and validity selected first): several of these can be in flight from a loop, where
+// load_frame's separate loads meet at a merge and each waits for its own
+__device__ __forceinline__ art_s load_frame_flat (const ArtFirArgs &a, int lin_floor, int lin, int ch)
+{
+    const bool in_hist = lin < a.H;
+    const int f = lin - a.H;
+    const bool ok = lin >= lin_floor && lin >= 0 && ch < a.C && (in_hist || f < a.in_frames);
+    const art_s *ptr = in_hist ? a.hist + ((size_t) lin * a.C + ch) : a.in_pitch ? a.in + ((size_t) ch * a.in_pitch + f) : a.in + ((size_t) f * a.C + ch);
+    art_s v = 0;
+    if (ok) v = *ptr;
+    return v;
+}
+
 // last segment whose first output is <= n
 __device__ __forceinline__ int find_segment (const ArtSegTable &segs, unsigned int n)
 {

@@ -18,7 +18,7 @@ constexpr int GEN_MAX_TILE = 32;
 // reduction and the per-output bookkeeping are then paid once per FOUR outputs, which is most of the cost when taps x
 // channels is small).  G depends on the tap count only, never on the tile, so a frame's value does not depend on how a
 // call is cut up.
-template <int CG, bool INTERP, bool PRECISE, int G>
+template <int CG, bool INTERP, bool PRECISE, int G, bool PIPE = false>
 __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const ArtSegTable &segs, int tile, unsigned int bx, unsigned int by)
 {
     constexpr int SUBS = 64 / G;
@@ -68,11 +68,60 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
     const int lin_lo = s_ip [0] - half + 1;
     const int span = s_ip [cnt - 1] + half + 1 - lin_lo;
 
+    if constexpr (PIPE) {
+        // (four loads in flight per thread: one at a time, a long span's rounds are as many trips to memory)
+        for (int e0 = tid; e0 < span * CG; e0 += 4 * GEN_THREADS) {
+            art_s v [4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = e0 + j * GEN_THREADS, f = e / CG, c = e - f * CG;
+                v [j] = load_frame_flat (a, segs.lin_floor, e < span * CG ? lin_lo + f : -1, ch0 + c);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (e0 + j * GEN_THREADS < span * CG) xs [e0 + j * GEN_THREADS] = v [j];
+        }
+    }
+    else
     for (int e = tid; e < span * CG; e += GEN_THREADS) {
         int f = e / CG, c = e - f * CG;
         xs [e] = load_frame (a, segs.lin_floor, lin_lo + f, ch0 + c);
     }
     __syncthreads ();
+
+    // PIPE (long filters, four channels or more — the host's choice, never a tile's: the bits are the same either way): a lane's taps
+    // of one output U mirrored pairs (x 2 rows) at a time, ALL of a round's loads issued before the first multiply-add waits for one,
+    // and the first round of the wave's NEXT output issued before this output's reduction.  The plain loop below waits for each
+    // pair: 31 dependent trips to the L2 per output at 988 taps, which is what a call of a few thousand frames spends its time on
+    // (profiles/r4_general_kernel_experiment.txt: 8 ch x 988 taps, 65,536 frames 80 -> 68 us; short filters and stereo lose).
+    // Which taps a lane takes, and in which order, is unchanged.
+    constexpr int U = 8, STRIDE = (GEN_THREADS / 64) * SUBS;
+    const __amdgpu_buffer_rsrc_t r_bank = __builtin_amdgcn_make_buffer_rsrc (const_cast<art_s *> (a.bank), 0, (int)((unsigned int)(a.F + 1) * (unsigned int) a.T * (unsigned int) sizeof (art_s)), 0x00020000);
+    art_s c0v [U] [2], c1v [U] [2];
+    // (buffer loads: a lane past the row's half reads what it then drops — possibly past the bank's end, which reads as zero)
+    auto tap = [&] (unsigned int voff, unsigned int soff) -> art_s {
+        if constexpr (sizeof (art_s) == 4) return __uint_as_float (__builtin_amdgcn_raw_buffer_load_b32 (r_bank, (int) voff, (int) soff, 0));
+        else {
+            typedef unsigned int u32x2_ __attribute__ ((ext_vector_type (2)));
+            const u32x2_ w = __builtin_amdgcn_raw_buffer_load_b64 (r_bank, (int) voff, (int) soff, 0);
+            return (art_s) __longlong_as_double ((long long)(((unsigned long long) w.y << 32) | w.x));
+        }
+    };
+    auto fetch = [&] (int i, int round) {
+        constexpr unsigned int SZ = sizeof (art_s);
+        const unsigned int row = (unsigned int) s_fi [i] * (unsigned int) a.T;
+        const unsigned int lo = (row + (unsigned int)(l + round * U * G)) * SZ;                  // side 0: tap l + round * U * G, + u * G
+        const unsigned int hi = (row + (unsigned int)(a.T - 1 - l - round * U * G)) * SZ;        // side 1: its mirror, - u * G
+        const unsigned int next_row = INTERP ? (unsigned int) a.T * SZ : 0u;
+        const int steps = (half - round * U * G + G - 1) / G;                                    // (the same for every lane: a short round issues no idle loads)
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (u < steps) {
+                c0v [u] [0] = tap (lo, (unsigned int)(u * G) * SZ); c0v [u] [1] = tap (hi - (unsigned int)(u * G) * SZ, 0u);
+                if (INTERP) { c1v [u] [0] = tap (lo, next_row + (unsigned int)(u * G) * SZ); c1v [u] [1] = tap (hi - (unsigned int)(u * G) * SZ, next_row); }
+            }
+    };
+    auto index_of = [&] (int i0) { return i0 + sub < cnt ? i0 + sub : cnt - 1; };
+    if constexpr (PIPE) { if (wave * SUBS < cnt) fetch (index_of (wave * SUBS), 0); }
 
     for (int i0 = wave * SUBS; i0 < cnt; i0 += (GEN_THREADS / 64) * SUBS) {
         const bool live = i0 + sub < cnt;                       // (a dead group recomputes the tile's last frame and drops it)
@@ -85,6 +134,7 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
             // exact sample hit in nearest-filter mode: the reference copies the sample through
 #pragma unroll
             for (int c = 0; c < CG; ++c) result [c] = x [(size_t)(half - 1 + fi / a.F) * CG + c];
+            if constexpr (PIPE) { if (i0 + (GEN_THREADS / 64) * SUBS < cnt) fetch (index_of (i0 + (GEN_THREADS / 64) * SUBS), 0); }     // (these lanes' next output)
         }
         else {
             const art_s *h0 = a.bank + (size_t) fi * a.T;
@@ -96,6 +146,38 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
             // Taps are visited in mirrored pairs from the window edges towards the centre (as the
             // reference does): partial sums stay small until the dominant central taps arrive, which
             // keeps the float accumulation error at or below the reference's.
+            if constexpr (PIPE) {
+                const int rounds = (half + G * U - 1) / (G * U);
+                for (int r = 0; r < rounds; ++r) {
+                    if (r) fetch (i, r);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int p = l + (r * U + u) * G;
+                        if (p < half) {
+#pragma unroll
+                            for (int side = 0; side < 2; ++side) {
+                                const int k = side ? a.T - 1 - p : p;
+                                const art_s c0 = c0v [u] [side];
+                                const art_s c1 = INTERP ? c1v [u] [side] : 0.0f;
+#pragma unroll
+                                for (int c = 0; c < CG; ++c) {
+                                    const art_s v = x [(size_t) k * CG + c];
+                                    if (PRECISE) {
+                                        acc0 [c] = acc0 [c] + (Acc) c0 * (Acc) v;
+                                        if (INTERP) acc1 [c] = acc1 [c] + (Acc) c1 * (Acc) v;
+                                    }
+                                    else {
+                                        acc0 [c] = fused ((Acc) c0, (Acc) v, acc0 [c]);
+                                        if (INTERP) acc1 [c] = fused ((Acc) c1, (Acc) v, acc1 [c]);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                if (i0 + STRIDE < cnt) fetch (index_of (i0 + STRIDE), 0);      // (the next output's first round travels under this one's reduction)
+            }
+            else
             for (int p = l; p < half; p += G) {
 #pragma unroll
                 for (int side = 0; side < 2; ++side) {
@@ -163,11 +245,11 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
   }
 }
 
-template <int CG, bool INTERP, bool PRECISE, int G>
+template <int CG, bool INTERP, bool PRECISE, int G, bool PIPE>
 __global__ __launch_bounds__ (GEN_THREADS)
 void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile)
 {
-    fir_general_body<CG, INTERP, PRECISE, G> (a, segs, tile, blockIdx.x, blockIdx.y);
+    fir_general_body<CG, INTERP, PRECISE, G, PIPE> (a, segs, tile, blockIdx.x, blockIdx.y);
 }
 
 
@@ -308,15 +390,18 @@ int launch_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st
     int tile; size_t lds; dim3 grid;
     if (!general_geometry<CG> (a, &tile, &lds, &grid)) return -1;
     const bool precise = (a.mode & 3) == ART_MODE_PRECISE;
+    static const bool pipe_on = [] { const char *e = getenv ("ARTAMD_GENERAL_PIPE"); return !(e && *e == '0'); } ();      // (A/B runs and the bit-identity test)
 
 #define GO(I, P) do { const int gg = general_group (a.T); if (gg == 16) GO_ (I, P, 16); else if (gg == 32) GO_ (I, P, 32); else GO_ (I, P, 64); } while (0)
-#define GO_(I, P, GG) do { auto k = fir_general_kernel<CG, I, P, GG>; \
+#define GO_(I, P, GG) do { if (CG >= 4 && a.T >= 512 && pipe_on) GO__ (I, P, GG, (CG >= 4)); else GO__ (I, P, GG, false); } while (0)
+#define GO__(I, P, GG, PP) do { auto k = fir_general_kernel<CG, I, P, GG, PP>; \
         if (lds > 48 * 1024) (void) hipFuncSetAttribute ((const void *) k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
         hipLaunchKernelGGL (k, grid, dim3 (GEN_THREADS), lds, st, a, segs, tile); } while (0)
     if (a.interpolate) { if (precise) GO (true, true); else GO (true, false); }
     else               { if (precise) GO (false, true); else GO (false, false); }
 #undef GO
 #undef GO_
+#undef GO__
     return 0;
 }
 

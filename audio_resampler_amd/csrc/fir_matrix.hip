@@ -796,12 +796,18 @@ bool artfir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int
     bool enough;
     if (C == 1 || C == 2 || C == 4 || C == 8 || C == 16 || C == 32) {
         // (up to 256 taps the general kernel works four frames per wave: its per-frame cost roughly halves; with long filters
-        // a mid-sized call is cut into 16-frame tiles that each stage ~T frames: 1.5x per frame below ~40k outputs — measured)
-        const double k_ns = ((0.2 + 0.04 * C) + 0.00007 * C * a->T) * (general_group (a->T) == 16 ? 0.47 : 0.85) *
-                            ((a->T >= 512 && total < 40000u) ? 1.5 : 1.0);
+        // a mid-sized call is cut into 16-frame tiles that each stage ~T frames, and the more column groups the grid has the
+        // fewer frames each of its workgroups shares that staging with: the per-frame cost below ~40k outputs is 1.5x at 4
+        // channels, 2.3x at 8, 5x at 32; one or two channels pay 1.7x at any size — re-fitted to tools/bench_crossover2.py,
+        // profiles/r4_dispatch_crossover.txt: the rule had 32 ch x 988 taps on the general kernel up to 5k frames where the
+        // matrix path is ahead from 2k on, 1-2 ch x 988 taps up to 100k frames where it is ahead from 45k on)
+        const double k_base = ((0.2 + 0.04 * C) + 0.00007 * C * a->T) * (general_group (a->T) == 16 ? 0.47 : 0.85) * (a->T >= 512 && C <= 2 ? 1.7 : 1.0);
+        const double k_mid = k_base * (a->T >= 512 && C > 2 ? 1.5 * pow ((double) C / 4.0, 0.6) : 1.0);      // below ~40k outputs
         const double chunks = (a->T + 63) / 32;
         const double floor_ns = 13500.0 + 550.0 * chunks + (C <= 2 ? 2000.0 : 0.0);
-        enough = total * k_ns >= floor_ns - 5000.0;
+        // (one threshold, so that a longer call never goes back to the general kernel)
+        const double need = (floor_ns - 5000.0) / k_mid < 40000.0 ? (floor_ns - 5000.0) / k_mid : (floor_ns - 5000.0) / k_base;
+        enough = (double) total >= need;
     }
     else
         enough = (double) total * C * a->T >= 1.2e8;
