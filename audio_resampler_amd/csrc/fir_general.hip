@@ -372,7 +372,11 @@ bool general_geometry (const ArtFirArgs &a, int *tile_out, size_t *lds_out, dim3
     // (`crowd` = launches of this size sharing the grid — the batched entry point: many streams fill the chip together, so
     // each keeps larger tiles.  An output's value does not depend on the tile it is computed in.)
     const unsigned int total_outputs = a.n_end - a.n_begin;
-    while (tile > 4 && (unsigned long long)((total_outputs + tile - 1) / tile) * crowd < 1024u) tile >>= 1;
+    // (not below one pass of the workgroup's four waves — 8 outputs at 32 lanes per output, 16 at 16: a smaller tile idles waves and
+    // doubles the workgroups for nothing; at 4 outputs a 4,096-frame call of 8 ch x 988 taps was 1,115 workgroups, more than the
+    // 1,024 the chip holds at once: 20.7 us against 13.7 at 2,896 frames)
+    const int pass = (GEN_THREADS / 64) * (64 / general_group (a.T));
+    while (tile > pass && (unsigned long long)((total_outputs + tile - 1) / tile) * crowd < 1024u) tile >>= 1;
     if (tile < 1) tile = 1;
     long span = a.T + (long) ceil (tile / a.ratio) + 3;
     size_t lds = (size_t) span * CG * sizeof (art_s);
