@@ -260,7 +260,7 @@ def test_sharded_and_ordinary_context_choose_the_same_kernel_at_every_call_size(
     for small calls, f32 matrix kernel for middling ones, fixed point for big ones), so the two contexts agree bit for bit at
     every size — the default mode, no kernel pinned"""
     ch = 32
-    sizes = [300, 2500, 9000, 30000, 61000]
+    sizes = [300, 1200, 2500, 9000, 30000, 61000]
     x = _stream(ch, sum(sizes))
     plain, sharded = _pair(ch, BH | INTERP)
     kinds = []
