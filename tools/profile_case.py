@@ -1,5 +1,5 @@
 """One named workload, a few dozen launches, for rocprofv3 (kernel stats and --pmc passes): the kernels bench.py does not reach.
-Usage: python tools/profile_case.py CASE [steps]     CASE in: general_E general_P general_A matrix_B matrix_D4 matrix_D32 fixed_D4 fixed_D32 wide biquad biquad_serial decimate strict
+Usage: python tools/profile_case.py CASE [steps]     CASE in: general_E general_P matrix_P general_A matrix_B matrix_D4 matrix_D32 fixed_D4 fixed_D32 wide biquad biquad_serial decimate strict
 Prints one JSON line: what ran, samples per launch, algorithmic flop and bytes per sample (tools/roofline_report.py reads it)."""
 import ctypes as C, json, math, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -13,15 +13,17 @@ stream = torch.cuda.current_stream().cuda_stream
 BH, IN = A.BLACKMAN_HARRIS, A.SUBSAMPLE_INTERPOLATE
 
 
-def resampler_case(ch, taps, filters, flags, block, kernel=0, ratio_fn=None, dtype=np.float32, mod=A):
+def resampler_case(ch, taps, filters, flags, block, kernel=0, ratio_fn=None, dtype=np.float32, mod=A, ring=1):
+    """ring: distinct input / output buffer pairs the steps walk round — with ring x (in + out) bytes past the 256 MiB Infinity Cache every
+    launch's input comes from HBM and the memory-side counters see it (a 4 MB input re-read every step never leaves the cache)"""
     rs = mod.Resampler(ch, taps, filters, 0.0, flags); rs.advance(taps / 2.0); rs.set_stream(stream)
     if kernel: rs.set_kernel(kernel)
-    x, _ = noise(block * ch); d_in = torch.from_numpy(x.reshape(block, ch).astype(dtype)).cuda()
-    ratio = 48000 / 44100; cap = int((block + taps // 2) * ratio * 1.001 + 10); d_out = torch.empty(cap, ch, device="cuda", dtype=d_in.dtype)
+    x, _ = noise(block * ch); d_ins = [torch.from_numpy(x.reshape(block, ch).astype(dtype)).cuda() for _ in range(ring)]
+    ratio = 48000 / 44100; cap = int((block + taps // 2) * ratio * 1.001 + 10); d_outs = [torch.empty(cap, ch, device="cuda", dtype=d_ins [0].dtype) for _ in range(ring)]
     k = [0]
     def step():
         r = ratio_fn(k[0]) if ratio_fn else ratio; k[0] += 1
-        u, g = rs.process_device(d_in, block, d_out, cap, r); return g * ch
+        u, g = rs.process_device(d_ins [k[0] % ring], block, d_outs [k[0] % ring], cap, r); return g * ch
     return step, rs
 
 
@@ -29,9 +31,12 @@ info = {"case": case}
 if case == "general_E":        # BASELINE configs[4]: stereo ASRC, preset -3, nearest filter, ratio moving +-100 ppm per 65,536-frame block
     step, rs = resampler_case(2, 380, 380, BH, 65536, ratio_fn=lambda k: 48000 / 44100 * (1 + 100e-6 * math.sin(2 * math.pi * k / 64)))
     info.update(kernel="fir_general_kernel", flop_per_sample=2 * 380, bytes_per_sample=4 * 44100 / 48000 + 4, peak="fp32")
-elif case == "general_P":      # BASELINE configs[0]: mono preset -1 (48 x 48) interpolating
-    step, rs = resampler_case(1, 48, 48, BH | IN, 1 << 20, kernel=1)         # (1: the general kernel pinned — at 1M frames the library itself takes the matrix path)
+elif case == "general_P":      # BASELINE configs[0]: mono preset -1 (48 x 48) interpolating, the general kernel pinned; 40 buffer pairs = 344 MB: past the Infinity Cache
+    step, rs = resampler_case(1, 48, 48, BH | IN, 1 << 20, kernel=1, ring=40)         # (1: the general kernel pinned — at 1M frames the library itself takes the matrix path: matrix_P)
     info.update(kernel="fir_general_kernel", flop_per_sample=4 * 48 + 3, bytes_per_sample=4 * 44100 / 48000 + 4, peak="fp32")
+elif case == "matrix_P":       # the same config as the library runs it: the f32 matrix kernel, one launch for the call's 1,456 ring epochs (2 chunks: K = 64)
+    step, rs = resampler_case(1, 48, 48, BH | IN, 1 << 20, ring=40)
+    info.update(kernel="fir_mfma", flop_per_sample=2 * 64, bytes_per_sample=4 * 44100 / 48000 + 4, peak="fp32")
 elif case == "general_A":      # the headline shape on the general kernel
     step, rs = resampler_case(8, 988, 988, BH | IN, 1 << 20, kernel=1)
     info.update(kernel="fir_general_kernel", flop_per_sample=4 * 988 + 3, bytes_per_sample=4 * 44100 / 48000 + 4, peak="fp32")

@@ -34,7 +34,7 @@ allpasses headline python $R/bench.py --steps 3 --warmup 1 --preroll-ms 60 --no-
 pmc headline p2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS -- python $R/bench.py --steps 3 --warmup 1 --preroll-ms 60 --no-cpu-baseline
 prof headline_f32 $BENCH --kernel 6
 allpasses headline_f32 python $R/bench.py --steps 3 --warmup 1 --preroll-ms 60 --no-cpu-baseline --kernel 6
-for c in fixed_D4 fixed_D32 general_E general_P general_A matrix_B matrix_D4 matrix_D32 wide biquad biquad_serial decimate strict; do
+for c in fixed_D4 fixed_D32 general_E general_P matrix_P general_A matrix_B matrix_D4 matrix_D32 wide biquad biquad_serial decimate strict; do
   python $R/tools/profile_case.py $c > $OUT/case_$c.json 2> $OUT/case_$c.err
   prof $c python $R/tools/profile_case.py $c 12
   allpasses $c python $R/tools/profile_case.py $c 4

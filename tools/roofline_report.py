@@ -94,7 +94,7 @@ if os.path.exists(p6):
         summary.append(("headline_f32", k6, c6))
 
 # ---- the other kernels
-for case in ("fixed_D4", "fixed_D32", "matrix_B", "matrix_D4", "matrix_D32", "general_E", "general_P", "general_A", "strict", "wide", "biquad", "biquad_serial", "decimate"):
+for case in ("fixed_D4", "fixed_D32", "matrix_B", "matrix_D4", "matrix_D32", "general_E", "general_P", "matrix_P", "general_A", "strict", "wide", "biquad", "biquad_serial", "decimate"):
     p = os.path.join(src, f"case_{case}.json")
     if not os.path.exists(p): continue
     try: info = json.loads(open(p).read().strip().splitlines()[-1])
