@@ -221,6 +221,51 @@ SCHEMES = {"current (band/4k, singles, pairs, quads)": sched_current,
            "in order, band 2k": make_inorder(2),
            "in order, band 4k, near=2": make_inorder(4, False, 4, 2),
            }
+
+def make_row_windows(margin_lo=6, margin_hi=7, lead=4, near=1, right_every=4, quad_rows=8):
+    """round 4: ONE accumulator through the band; behind every MFMA pair (4 k of an 8-k group) only the register quads whose rows
+    (8 consecutive slots: 4 per half-wave) have a central tap within the group's 8 k's — [centre - margin_lo - lead, centre + margin_hi) — are
+    flushed and cleared; the other rows' sums ride on (they are tail sums there)"""
+    def sched(Am, X, band_lo, band_hi):
+        K = Am.shape[1]; nch = K // KC
+        lo_b, hi_b = band_lo // KC, (band_hi + KC - 1) // KC
+        # the rows' centres from the matrix itself (first non-zero column + T/2 - 1)
+        shift = np.array([np.flatnonzero(Am[i])[0] for i in range(32)]); shift = shift - shift[0]
+        total = np.zeros((32, X.shape[1]), np.float64)
+        acc = None
+        for cc in range(0, max(0, lo_b - near)):
+            acc = chain(Am, X, kernel_order(cc * KC), acc)
+        if acc is not None: total += acc.astype(np.float64)
+        acc = np.zeros((32, X.shape[1]), np.float32)
+        wins = []
+        for q in range(32 // quad_rows):
+            rows = list(range(q * quad_rows, (q + 1) * quad_rows))
+            c_lo = T // 2 - 1 + shift[rows[0]]; c_hi = T // 2 - 1 + shift[rows[-1]]
+            wins.append((rows, c_lo - margin_lo - lead, c_hi + margin_hi))
+        for cc in range(max(0, lo_b - near), min(nch, hi_b + near)):
+            ks = kernel_order(cc * KC)
+            for g in range(0, KC, 4):
+                acc = chain(Am, X, ks[g:g + 4], acc)
+                k0 = cc * KC + (g // 8) * 8
+                for rows, w_lo, w_hi in wins:
+                    if k0 < w_hi and k0 + 8 > w_lo:
+                        total[rows] += acc[rows].astype(np.float64); acc[rows] = 0
+        total += acc.astype(np.float64)
+        acc = None; j = 0
+        for cc in range(min(nch, hi_b + near), nch):
+            acc = chain(Am, X, kernel_order(cc * KC), acc); j += 1
+            if right_every and j % right_every == 0: total += acc.astype(np.float64); acc = None
+        if acc is not None: total += acc.astype(np.float64)
+        return total.astype(np.float32)
+    return sched
+SCHEMES = {"current (band/4k, singles, pairs, quads)": sched_current,
+           "in order, band 4k, right/4 (shipped)": make_inorder(4),
+           "row-quad windows [-6-4, +7), 8-row quads": make_row_windows(),
+           "row-quad windows, no lead": make_row_windows(lead=0),
+           "row-quad windows, margins 4/5": make_row_windows(4, 5),
+           "row-quad windows, margins 8/9": make_row_windows(8, 9),
+           "in order, band 8k": make_inorder(8),
+           }
 if __name__ == "__main__":
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
     for sname, sig in SIGNALS.items():
