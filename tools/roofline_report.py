@@ -32,9 +32,18 @@ def counters(name, fragment):
             d["_ns"] = int(row["End_Timestamp"]) - int(row["Start_Timestamp"]); d["_vgpr"] = row["VGPR_Count"]; d["_lds"] = row["LDS_Block_Size"]
             d["_scratch"] = row["Scratch_Size"]; d["_grid"] = row["Grid_Size"]
         if rows:
-            last = rows[max(rows)]
-            for k, v in last.items():
-                best[k] = v
+            # a call that takes several launches of the kernel (ring epochs: 7 full grids and a remainder) is one "launch" of the table:
+            # the last dispatch and those before it back to the previous dispatch of the SAME grid are summed (equal grids throughout: one dispatch)
+            ids = sorted(rows)
+            last = ids[-1]; span = [last]
+            for i in reversed(ids[:-1]):
+                if rows[i]["_grid"] == rows[last]["_grid"]: break
+                span.append(i)
+            if len(span) == len(ids): span = [last]              # (no earlier dispatch of that grid: not a pattern)
+            for k in rows[last]:
+                if k.startswith("_"): best[k] = rows[last][k] if k != "_ns" else sum(rows[i]["_ns"] for i in span)
+                else: best[k] = sum(rows[i].get(k, 0.0) for i in span)
+            best["_dispatches"] = len(span)
     return best
 
 
