@@ -104,6 +104,35 @@ void mfma_prepare_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
     }
 }
 
+// the flagged slots of every period of a launch <- their input samples (see artfir_pass_fixup_wanted)
+__global__ __launch_bounds__ (256)
+void pass_fixup_kernel (ArtFirArgs a, MfmaGeom g)
+{
+    __shared__ int s_slots [1024];
+    __shared__ int s_count;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_count = 0;
+    __syncthreads ();
+    for (int s = tid; s < g.P; s += 256)
+        if (((unsigned int) g.tile_w0 [3 * (s >> 5) + 1] >> (s & 31)) & 1u) { const int at = atomicAdd (&s_count, 1); if (at < 1024) s_slots [at] = s; }
+    __syncthreads ();
+    const int nflag = min (s_count, 1024);
+    if (nflag == 0) return;
+    const unsigned int total = a.n_end - a.n_begin;
+    const unsigned int periods = (total + (unsigned int) g.P - 1u) / (unsigned int) g.P;
+    const unsigned long long items = (unsigned long long) periods * nflag * a.C;
+    for (unsigned long long e = (unsigned long long) blockIdx.x * 256 + tid; e < items; e += (unsigned long long) gridDim.x * 256) {
+        const int c = (int)(e % a.C);
+        const unsigned long long r = e / a.C;
+        const int f = (int)(r % nflag);
+        const unsigned int j = (unsigned int)(r / nflag);
+        const int slot = s_slots [f];
+        const unsigned int n = a.n_begin + j * (unsigned int) g.P + (unsigned int) slot;
+        if (n < a.n_end)
+            a.out [(size_t) n * a.C + c] = load_frame (a, INT_MIN, g.canon_ip [slot] + g.canon_fi [slot] / a.F + (int) j * g.Q, c);
+    }
+}
+
 // CG > 0: the stream has exactly CG channels (compile-time index math, vector loads);  CG == 0: any count.
 // WS (wave specialisation, needs CG > 0): the workgroup has 8 waves.  Waves 4-7 are LOADERS — they prefetch
 // chunk c+2 from global memory into registers and commit chunk c+1 (lerp folded in) to the other LDS buffer;
@@ -787,6 +816,26 @@ static bool mfma_launch_is_regular (const ArtFirArgs *a, const ArtSegTable *segs
 
 // does this call take the matrix-core path (arthip_fir), or the general kernel?  One rule, also asked by the batched entry
 // point, which only gathers calls the general kernel would have run anyway.
+static size_t pass_fixup_min ()
+{
+    static const size_t v = [] { const char *e = getenv ("ARTAMD_PASS_FIXUP_MIN"); return e && *e ? (size_t) strtoull (e, nullptr, 10) : (size_t) 1 << 20; } ();
+    return v;                                                 // (samples of a launch; 0: every launch, a huge number: never — A/B runs, the bit-identity test)
+}
+bool artfir_pass_fixup_wanted (const ArtFirArgs *a)
+{
+    return !a->interpolate && !a->lowpass && a->out_pitch == 0 && a->in_pitch == 0 && (size_t)(a->n_end - a->n_begin) * a->C >= pass_fixup_min ();
+}
+void artfir_pass_fixup (const ArtFirArgs *a, const MfmaGeom &g, hipStream_t st)
+{
+    if (g.P > 1024 * 32) return;                              // (cannot be: P <= filters x period multiple)
+    const unsigned int total = a->n_end - a->n_begin;
+    const unsigned long long items = (unsigned long long)((total + g.P - 1) / g.P) * a->C;       // (per flagged slot)
+    unsigned int blocks = (unsigned int)((items + 255) / 256);
+    if (blocks > 2048u) blocks = 2048u;
+    if (blocks == 0u) blocks = 1u;
+    hipLaunchKernelGGL (pass_fixup_kernel, dim3 (blocks), dim3 (256), 0, st, *a, g);
+}
+
 bool artfir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref)
 {
     if (a->n_end <= a->n_begin || (a->mode & 3) == ART_MODE_STRICT) return false;
@@ -1000,8 +1049,9 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
                 return hipGetLastError () == hipSuccess ? (ART_KERNEL_MFMA | (a->roll_dst ? ART_FIR_ROLLED : 0)) : -1;
             }
             const dim3 sgrid ((unsigned int)(8 * wgs_per_xcd) + roll_blocks);
+            const bool fixup = artfir_pass_fixup_wanted (a);
 #define MS_GO_(I, CGT, PS) hipLaunchKernelGGL ((fir_mfma_stream_kernel<I, CGT, PS>), sgrid, dim3 (2 * MF_THREADS), 0, st, *a, g, wgs_per_xcd)
-#define MS_GO(I, CGT) do { if (!I && !a->lowpass) MS_GO_ (false, CGT, true); else MS_GO_ (I, CGT, false); } while (0)
+#define MS_GO(I, CGT) do { if (!I && !a->lowpass && !fixup) MS_GO_ (false, CGT, true); else MS_GO_ (I, CGT, false); } while (0)
             if (a->interpolate) switch (cgt) { case 32: MS_GO (true, 32); break; case 16: MS_GO (true, 16); break; case 8: MS_GO (true, 8); break;
                                                 case 4: MS_GO (true, 4); break; case 2: MS_GO (true, 2); break; default: MS_GO (true, 1); }
             else                switch (cgt) { case 32: MS_GO (false, 32); break; case 16: MS_GO (false, 16); break; case 8: MS_GO (false, 8); break;
@@ -1009,6 +1059,7 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
 #undef MS_GO
 #undef MS_GO_
             if (a->ev_stop) arthip_event_record (a->ev_stop, stream);
+            if (fixup) artfir_pass_fixup (a, g, st);
             return hipGetLastError () == hipSuccess ? (ART_KERNEL_MFMA | (a->roll_dst ? ART_FIR_ROLLED : 0)) : -1;
         }
 #define MF_GO(I, CGT) do { if (ws && CGT) hipLaunchKernelGGL ((fir_mfma_kernel<I, CGT, (CGT != 0), 1>), grid, dim3 (2 * MF_THREADS), 0, st, *a, *segs, g); \

@@ -1466,7 +1466,9 @@ int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGe
     const int resident = 62;
     int wgs_per_xcd = tiles_per_xcd < resident ? tiles_per_xcd : resident;
     { static const int k_env = [] { const char *e = getenv ("ARTAMD_I8_WGS"); return e && *e ? atoi (e) : 0; } (); if (k_env > 0 && k_env < tiles_per_xcd) wgs_per_xcd = k_env; }
-    const bool pass = !a->interpolate && !a->lowpass;
+    // (big launches of the nearest-filter mode: the plain instantiation and the pass-through pass behind it, artfir_pass_fixup_wanted)
+    const bool fixup = artfir_pass_fixup_wanted (a);
+    const bool pass = !a->interpolate && !a->lowpass && !fixup;
     if (q.tr == 64) {
         // slabs: one eight-wave workgroup per CU (all of its LDS), which also rolls the history and carries the stand-by
         I8Slab sl;
@@ -1498,6 +1500,7 @@ int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGe
         switch (cgt) { case 32: I8_SLAB (32); break; case 16: I8_SLAB (16); break; case 8: I8_SLAB (8); break; default: I8_SLAB (4); }
 #undef I8_SLAB
         if (a->ev_stop) arthip_event_record (a->ev_stop, (void *) st);
+        if (fixup) artfir_pass_fixup (a, g, st);
 #ifdef I8_SLAB_TRACE
         {
             static int n_launch = 0;
@@ -1531,6 +1534,7 @@ int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGe
 #undef I8_DMA
 #undef I8_GO
     if (a->ev_stop) arthip_event_record (a->ev_stop, (void *) st);
+    if (fixup) artfir_pass_fixup (a, g, st);
     return 1;
 }
 
