@@ -34,8 +34,8 @@ int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGe
 
 // Nearest-filter mode without a low-pass: the outputs whose position falls exactly on an input sample are copies of that sample
 // (reference resampler.c:1141-1142).  The matrix kernels' PASS instantiations substitute them in their epilogues — and pay for the extra
-// live state with 20-40 spilt registers in the tile loop.  A launch of at least artfir_pass_fixup_min () samples runs the plain
-// instantiation and this pass behind it on the same stream: the flagged slots (tile_w0 [3 st + 1], 32-row slot tiles) of every period
+// live state with 20-40 spilt registers in the tile loop.  The streaming kernels' launches (ARTAMD_PASS_FIXUP_MIN: from that many samples
+// on; default all of them) run the plain instantiation and this pass behind it on the same stream: the flagged slots (tile_w0 [3 st + 1], 32-row slot tiles) of every period
 // are overwritten with their samples — the same values the PASS epilogues store.  Returns true if the launch is to run that way.
 bool artfir_pass_fixup_wanted (const ArtFirArgs *a);
 void artfir_pass_fixup (const ArtFirArgs *a, const MfmaGeom &g, hipStream_t st);
