@@ -1029,6 +1029,7 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
             int wgs_per_xcd = tiles_per_xcd < resident ? tiles_per_xcd : resident;
             { static const int k_env = [] { const char *e = getenv ("ARTAMD_TILES_PER_WG"); return e && *e ? atoi (e) : 0; } (); if (k_env > 0) wgs_per_xcd = (tiles_per_xcd + k_env - 1) / k_env; }
             // launches of few tiles: a tile's K range as several work items (fir_mfma_split_kernel)
+            const bool fixup = artfir_pass_fixup_wanted (a);
             const int ks = a->split ? matrix_split_parts (a, g, a->n_end - a->n_begin, kernel_pref) : 1;
             if (ks > 1 && (size_t) 8 * tiles_per_xcd * 16 <= ART_SPLIT_HEAD_BYTES &&
                 ART_SPLIT_HEAD_BYTES + (size_t) 8 * tiles_per_xcd * ks * 16 * MF_THREADS * sizeof (double) <= a->split_bytes) {
@@ -1038,7 +1039,7 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
                 unsigned int *arrivals = (unsigned int *) a->split;
                 double *partials = (double *)((char *) a->split + ART_SPLIT_HEAD_BYTES);
 #define MK_GO_(I, CGT, PS) hipLaunchKernelGGL ((fir_mfma_split_kernel<I, CGT, PS>), kgrid, dim3 (2 * MF_THREADS), 0, st, *a, g, wgs, ks, partials, arrivals)
-#define MK_GO(I, CGT) do { if (!I && !a->lowpass) MK_GO_ (false, CGT, true); else MK_GO_ (I, CGT, false); } while (0)
+#define MK_GO(I, CGT) do { if (!I && !a->lowpass && !fixup) MK_GO_ (false, CGT, true); else MK_GO_ (I, CGT, false); } while (0)
                 if (a->interpolate) switch (cgt) { case 32: MK_GO (true, 32); break; case 16: MK_GO (true, 16); break; case 8: MK_GO (true, 8); break;
                                                     case 4: MK_GO (true, 4); break; case 2: MK_GO (true, 2); break; default: MK_GO (true, 1); }
                 else                switch (cgt) { case 32: MK_GO (false, 32); break; case 16: MK_GO (false, 16); break; case 8: MK_GO (false, 8); break;
@@ -1046,10 +1047,10 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
 #undef MK_GO
 #undef MK_GO_
                 if (a->ev_stop) arthip_event_record (a->ev_stop, stream);
+                if (fixup) artfir_pass_fixup (a, g, st);
                 return hipGetLastError () == hipSuccess ? (ART_KERNEL_MFMA | (a->roll_dst ? ART_FIR_ROLLED : 0)) : -1;
             }
             const dim3 sgrid ((unsigned int)(8 * wgs_per_xcd) + roll_blocks);
-            const bool fixup = artfir_pass_fixup_wanted (a);
 #define MS_GO_(I, CGT, PS) hipLaunchKernelGGL ((fir_mfma_stream_kernel<I, CGT, PS>), sgrid, dim3 (2 * MF_THREADS), 0, st, *a, g, wgs_per_xcd)
 #define MS_GO(I, CGT) do { if (!I && !a->lowpass && !fixup) MS_GO_ (false, CGT, true); else MS_GO_ (I, CGT, false); } while (0)
             if (a->interpolate) switch (cgt) { case 32: MS_GO (true, 32); break; case 16: MS_GO (true, 16); break; case 8: MS_GO (true, 8); break;

@@ -18,6 +18,7 @@ SESSIONS = [
     (1, 156, 160, 44100, 48000, 0, (700000, 20000)),                 # mono
     (16, 512, 147, 96000, 44100, 0, (200000, 50000)),                # down-sampling, 147 phases
     (8, 988, 2, 44100, 88200, 0, (200000,)),                         # 2 outputs per period: every other output is a copy
+    (8, 988, 160, 44100, 48000, 8, (30000, 20000)),                  # the K-split kernel forced (few tiles)
 ]
 
 
