@@ -108,18 +108,43 @@ void mfma_prepare_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
 __global__ __launch_bounds__ (256)
 void pass_fixup_kernel (ArtFirArgs a, MfmaGeom g)
 {
+    // the flagged slots in ascending order — the SAME list in every workgroup: the items below are shared out by list index
+    // (built with atomics the order differed from workgroup to workgroup and a slot's copy could be made twice here, never there)
     __shared__ int s_slots [1024];
-    __shared__ int s_count;
+    __shared__ int s_off [1025];
     const int tid = threadIdx.x;
-    if (tid == 0) s_count = 0;
+    const int tiles = (g.P + 31) >> 5;                        // (<= 1024: artfir_pass_fixup)
+    auto word = [&] (int st) -> unsigned int {
+        const int valid = min (32, g.P - st * 32);
+        return (unsigned int) g.tile_w0 [3 * st + 1] & (valid >= 32 ? 0xffffffffu : (1u << valid) - 1u);
+    };
+    for (int st = tid; st < tiles; st += 256) s_off [st + 1] = __popc (word (st));
     __syncthreads ();
-    for (int s = tid; s < g.P; s += 256)
-        if (((unsigned int) g.tile_w0 [3 * (s >> 5) + 1] >> (s & 31)) & 1u) { const int at = atomicAdd (&s_count, 1); if (at < 1024) s_slots [at] = s; }
+    if (tid == 0) { s_off [0] = 0; for (int st = 0; st < tiles; ++st) s_off [st + 1] += s_off [st]; }
     __syncthreads ();
-    const int nflag = min (s_count, 1024);
-    if (nflag == 0) return;
+    for (int st = tid; st < tiles; st += 256) {
+        unsigned int w = word (st); int o = s_off [st];
+        while (w) { const int b = __ffs ((int) w) - 1; if (o < 1024) s_slots [o] = st * 32 + b; ++o; w &= w - 1u; }
+    }
+    __syncthreads ();
+    if (s_off [tiles] == 0) return;
     const unsigned int total = a.n_end - a.n_begin;
     const unsigned int periods = (total + (unsigned int) g.P - 1u) / (unsigned int) g.P;
+    if (s_off [tiles] > 1024) {
+        // (more flagged slots than the list holds — a period of thousands of slots with few filters: every slot of every period is looked at)
+        const unsigned long long all = (unsigned long long) periods * (unsigned int) g.P * a.C;
+        for (unsigned long long e = (unsigned long long) blockIdx.x * 256 + tid; e < all; e += (unsigned long long) gridDim.x * 256) {
+            const int c = (int)(e % a.C);
+            const unsigned long long r = e / a.C;
+            const int slot = (int)(r % (unsigned int) g.P);
+            const unsigned int j = (unsigned int)(r / (unsigned int) g.P);
+            const unsigned int n = a.n_begin + j * (unsigned int) g.P + (unsigned int) slot;
+            if (((word (slot >> 5) >> (slot & 31)) & 1u) && n < a.n_end)
+                a.out [(size_t) n * a.C + c] = load_frame (a, INT_MIN, g.canon_ip [slot] + g.canon_fi [slot] / a.F + (int) j * g.Q, c);
+        }
+        return;
+    }
+    const int nflag = s_off [tiles];
     const unsigned long long items = (unsigned long long) periods * nflag * a.C;
     for (unsigned long long e = (unsigned long long) blockIdx.x * 256 + tid; e < items; e += (unsigned long long) gridDim.x * 256) {
         const int c = (int)(e % a.C);

@@ -19,6 +19,8 @@ SESSIONS = [
     (16, 512, 147, 96000, 44100, 0, (200000, 50000)),                # down-sampling, 147 phases
     (8, 988, 2, 44100, 88200, 0, (200000,)),                         # 2 outputs per period: every other output is a copy
     (8, 988, 160, 44100, 48000, 8, (30000, 20000)),                  # the K-split kernel forced (few tiles)
+    (4, 380, 32, 44100, 48000, 7, (250000, 120000)),                 # fixed point, three pass-through slots per period
+    (2, 64, 1, 44100, 48000, 0, (300000,)),                          # ONE filter: every slot whose nearest filter is a whole sample — most of them
 ]
 
 

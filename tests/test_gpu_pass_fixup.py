@@ -17,6 +17,8 @@ def _sessions(**env):
 def test_pass_through_slots_by_epilogue_or_by_their_own_pass_are_the_same_bits():
     never, always, default = _sessions(ARTAMD_PASS_FIXUP_MIN="1000000000000"), _sessions(ARTAMD_PASS_FIXUP_MIN="0"), _sessions()
     assert len(never) == len(always) == len(default) >= 7
+    for again in (_sessions(ARTAMD_PASS_FIXUP_MIN="0"), _sessions(ARTAMD_PASS_FIXUP_MIN="0", ARTAMD_I8_SLAB_MIN="1")):     # (the pass shares its work out by list index: every workgroup must build the same list — it did not at first, and one run in two showed it)
+        assert [s["sha256"] for s in again] == [s["sha256"] for s in never]
     for a, b, c in zip(never, always, default):
         assert a["frames"] == b["frames"] == c["frames"] > 0
         assert a["kernels"] == b["kernels"] == c["kernels"], (a, b)
