@@ -79,6 +79,10 @@ typedef struct {
     /* device memory for the K-split streaming kernel of launches with few tiles (arthip_fir_split_bytes; NULL: unsplit): the first
      * ART_SPLIT_HEAD_BYTES are arrival counters, zero whenever no launch is in flight (zeroed by the owner when allocated) */
     void *split; size_t split_bytes;
+    /* device memory for launches of a channel count the matrix kernels are not compiled for (anything but 1, 2, 4, 8, 16, 32): the
+     * launch runs in groups of up to 32 channels, each copied into a buffer of the next compiled width (arthip_fir_pad_bytes; NULL: the
+     * generic matrix kernel runs such a stream, several times slower) */
+    void *pad; size_t pad_bytes;
     /* host, optional, 4 ints filled when the fixed-point kernel is enqueued: the launch's flag value (the first word of
      * `planes` equals it afterwards iff the kernel stood down), mask words behind the header (at planes + ART_I8_HEAD_BYTES),
      * chunks per tile, the kernel's form (1 register-staged, 2 LDS-DMA, 3 slabs) */
@@ -137,6 +141,7 @@ size_t arthip_fir_split_bytes (const ArtFirArgs *a, unsigned int outputs, int ke
 size_t arthip_fir_batch_item_bytes (void);
 int arthip_fir_batch_max_segments (void);                /* ring-epoch segments a batched call may have */
 int arthip_fir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref);   /* what arthip_fir would do */
+size_t arthip_fir_pad_bytes (const ArtFirArgs *a, unsigned int outputs);      /* bytes a->pad wants for a call of this shape making `outputs` frames (0: none) */
 /* May a call of more segments than a table holds be ONE launch (n_begin .. n_end = the whole call, segs = its first ART_MAX_SEGS
  * segments)?  Yes where the launch runs on a streaming matrix-core kernel: those take their positions from the lattice of the
  * launch's first period, not from the table (short filters: a ring epoch is a few hundred frames, a 1M-frame call eight tables) */

@@ -14,6 +14,79 @@ size_t arthip_fir_split_bytes (const ArtFirArgs *a, unsigned int outputs, int ke
 
 size_t arthip_fir_planes_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref) { return artfir_planes_bytes (a, outputs, kernel_pref); }
 
+// ---------------------------------------------------------------------------------------------------
+// Channel counts the matrix-core kernels are not compiled for.  Their tile loops index a stream of exactly 1, 2, 4, 8, 16 or 32 channels
+// (compile-time pitch, 16-byte vectors); a 6- or 12- or 64-channel stream used to take the generic instantiation, 5-8 x slower per
+// sample (6 ch x 988 taps, 262,144 frames: 7.0 Gsamples/s where 8 channels make 39).  Such a launch now runs in GROUPS of up to 32
+// channels: a group's history and input are copied into a buffer of the next compiled width (the extra channels zero), the
+// ordinary launch runs on that, and its outputs are copied back into the caller's frames.  A channel's arithmetic does not depend on
+// its group's width or on its neighbours: the same bits as the same channel in any other context (a shard, a wider stream).
+// ---------------------------------------------------------------------------------------------------
+static inline bool channels_irregular (int C) { return C > 32 || (C & (C - 1)) != 0; }
+static inline int padded_width (int w) { int p = 1; while (p < w) p <<= 1; return p; }
+
+__global__ void group_in_kernel (art_s *dst, const art_s *hist, const art_s *in, int H, int in_frames, int C, int c0, int w, int wp)
+{
+    const size_t total = (size_t)(H + in_frames) * wp, stride = (size_t) gridDim.x * blockDim.x;
+    for (size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const size_t f = e / wp; const int c = (int)(e - f * wp);
+        art_s v = 0;
+        if (c < w) v = f < (size_t) H ? hist [f * C + c0 + c] : in [(f - H) * C + c0 + c];
+        dst [e] = v;                                          // ([history frames][wp] then [input frames][wp]: one array)
+    }
+}
+
+__global__ void group_out_kernel (art_s *out, const art_s *src, unsigned int n_begin, unsigned int n_end, int C, int c0, int w, int wp)
+{
+    const size_t total = (size_t)(n_end - n_begin) * w, stride = (size_t) gridDim.x * blockDim.x;
+    for (size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const size_t r = e / w; const int c = (int)(e - r * w);
+        out [((size_t) n_begin + r) * C + c0 + c] = src [r * wp + c];
+    }
+}
+
+size_t arthip_fir_pad_bytes (const ArtFirArgs *a, unsigned int outputs)
+{
+    if (!channels_irregular (a->C) || a->in_pitch || a->out_pitch || (a->mode & 3) != ART_MODE_FAST) return 0;
+    const size_t wp = a->C > 32 ? 32 : (size_t) padded_width (a->C);
+    return (((size_t)(a->H + a->in_frames) * wp * sizeof (art_s) + 255) & ~(size_t) 255) + (size_t) outputs * wp * sizeof (art_s) + 256;
+}
+
+// 0: not for this launch (the caller goes on as before); else artfir_matrix's return value for the whole launch
+static int fir_in_groups (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, hipStream_t st)
+{
+    static const bool off = [] { const char *e = getenv ("ARTAMD_NO_GROUPS"); return e && *e && *e != '0'; } ();      // (A/B runs: the generic matrix kernel as before)
+    if (off || !a->pad || !channels_irregular (a->C) || a->in_pitch || a->out_pitch || (a->mode & 3) != ART_MODE_FAST || (!a->in && a->in_frames > 0)) return 0;
+    if (!artfir_takes_matrix_path (a, segs, kernel_pref)) return 0;
+    const unsigned int outs = a->n_end - a->n_begin;
+    if (arthip_fir_pad_bytes (a, outs) > a->pad_bytes) return 0;
+    const size_t wp_max = a->C > 32 ? 32 : (size_t) padded_width (a->C);
+    art_s *p_in = (art_s *) a->pad;
+    art_s *p_out = (art_s *)((char *) a->pad + (((size_t)(a->H + a->in_frames) * wp_max * sizeof (art_s) + 255) & ~(size_t) 255));
+    int rc = 0;
+    for (int c0 = 0; c0 < a->C; c0 += 32) {
+        const int w = a->C - c0 < 32 ? a->C - c0 : 32, wp = padded_width (w);
+        const size_t in_elems = (size_t)(a->H + a->in_frames) * wp;
+        hipLaunchKernelGGL (group_in_kernel, dim3 ((unsigned int)((in_elems + 255) / 256 < 4096 ? (in_elems + 255) / 256 : 4096)), dim3 (256), 0, st,
+                            p_in, a->hist, a->in, a->H, a->in_frames, a->C, c0, w, wp);
+        ArtFirArgs b = *a;
+        b.C = wp; b.hist = p_in; b.in = p_in + (size_t) a->H * wp;
+        b.out = p_out - (size_t) a->n_begin * wp;             // (the kernels index outputs from the call's first)
+        b.roll_dst = nullptr; b.roll_appended = 0;            // (the history is rolled once, below, in the stream's own layout)
+        b.stream_C = a->stream_C > a->C ? a->stream_C : a->C; b.stream_plain = 0;
+        b.pad = nullptr; b.pad_bytes = 0;
+        const int r = artfir_matrix (&b, segs, kernel_pref, (void *) st);
+        if (r <= 0) { if (c0 == 0 && r == 0) return 0; return -1; }      // (declined before anything ran: the caller's other paths; later: cannot be, same decisions)
+        rc = r;
+        const size_t out_elems = (size_t) outs * w;
+        hipLaunchKernelGGL (group_out_kernel, dim3 ((unsigned int)((out_elems + 255) / 256 < 4096 ? (out_elems + 255) / 256 : 4096)), dim3 (256), 0, st,
+                            a->out, p_out, a->n_begin, a->n_end, a->C, c0, w, wp);
+    }
+    if (a->roll_dst && arthip_roll_history (a->roll_dst, a->hist, a->in, 0, a->roll_appended, a->H, a->C, (void *) st)) return -1;
+    if (hipGetLastError () != hipSuccess) return -1;
+    return (rc & ~ART_FIR_ROLLED) | (a->roll_dst ? ART_FIR_ROLLED : 0);
+}
+
 int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, void *stream)
 {
     hipStream_t st = (hipStream_t) stream;
@@ -30,6 +103,7 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
 
     // matrix cores: exact rational ratio, default numeric mode, interleaved buffers, no history floor — and enough work to beat
     // the general kernel (fir_matrix.hip / fir_matrix64.hip)
+    { const int grouped = fir_in_groups (a, segs, kernel_pref, st); if (grouped) return grouped; }
     const int matrix = artfir_matrix (a, segs, kernel_pref, stream);
     if (matrix) return matrix;
     if (a->segs_truncated) return -2;                        // (nothing enqueued: the matrix path declines before its first launch)

@@ -883,8 +883,11 @@ bool artfir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int
         const double need = (floor_ns - 5000.0) / k_mid < 40000.0 ? (floor_ns - 5000.0) / k_mid : (floor_ns - 5000.0) / k_base;
         enough = (double) total >= need;
     }
-    else
+    else {
+        // (not a compiled width: the launch runs in groups of compiled widths behind two copies, fir_dispatch.hip — when it has the
+        // buffer for them; the old rule stays: such streams are rare, and below it the general kernel is at home)
         enough = (double) total * C * a->T >= 1.2e8;
+    }
     return a->mode == ART_MODE_FAST && a->period_out > 0 && a->fix_list && a->scratch && a->in_pitch == 0 && a->out_pitch == 0 &&
                          segs->lin_floor == INT_MIN && kernel_pref != ART_KERNEL_GENERAL &&
                          (enough || kernel_pref >= ART_KERNEL_MFMA) && total >= (unsigned int) a->period_out;
@@ -929,6 +932,19 @@ static int matrix_geometry (const ArtFirArgs *a, MfmaGeom &g)
 // 147 frames apart: a quarter of the K range still spans 3/4 of the tile's input), so more than two parts lose; two parts win
 // where half the CUs would otherwise idle through a whole K walk (50-110 tiles: the 32,768-frame call of 8 ch x 988 taps,
 // 21.7 -> 16.2 us) and nowhere else.  Kernel preference 8 forces 2 / 4 / 8 parts (tests, experiments: ARTAMD_SPLIT_KS).
+// a launch of a channel count the kernels are not compiled for runs in groups of a compiled width (fir_dispatch.hip, fir_in_groups): what
+// its buffers are sized for is the widest group
+static ArtFirArgs widest_group (const ArtFirArgs *a)
+{
+    ArtFirArgs b = *a;
+    if (a->C > 32 || (a->C & (a->C - 1))) {
+        int wp = 1; while (wp < (a->C > 32 ? 32 : a->C)) wp <<= 1;
+        b.stream_C = a->stream_C > a->C ? a->stream_C : a->C;
+        b.C = wp; b.in = nullptr; b.hist = nullptr; b.stream_plain = 0;        // (the groups' own buffers are 256-byte aligned)
+    }
+    return b;
+}
+
 static int matrix_split_parts (const ArtFirArgs *a, const MfmaGeom &g, unsigned int outputs, int kernel_pref)
 {
     if (kernel_pref == 5 || kernel_pref == 6 || kernel_pref == 7 || a->stream_plain) return 1;
@@ -949,8 +965,9 @@ static int matrix_split_parts (const ArtFirArgs *a, const MfmaGeom &g, unsigned 
     return ks;
 }
 
-size_t artfir_split_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref)
+size_t artfir_split_bytes (const ArtFirArgs *a_, unsigned int outputs, int kernel_pref)
 {
+    const ArtFirArgs wg_ = widest_group (a_), *a = &wg_;
     if (!a->period_out || a->mode != ART_MODE_FAST) return 0;
     ArtFirArgs b = *a;
     b.n_begin = 0; b.n_end = outputs + (unsigned int) a->period_out * 64u;       // (any launch of the call: at most this many outputs)
@@ -971,8 +988,9 @@ bool artfir_matrix_spans_segments (const ArtFirArgs *a, const ArtSegTable *segs,
 }
 
 // bytes of digit planes the fixed-point kernel wants for a call of this shape (the host sizes a->planes with it before the launch)
-size_t artfir_planes_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref)
+size_t artfir_planes_bytes (const ArtFirArgs *a_, unsigned int outputs, int kernel_pref)
 {
+    const ArtFirArgs wg_ = widest_group (a_), *a = &wg_;
     if (!a->period_out || a->mode != ART_MODE_FAST || kernel_pref == 5 || kernel_pref == 6 || kernel_pref == 8 || a->stream_plain) return 0;
     // Where it pays (MI355X, tools/bench_shapes.py with and without ARTAMD_NO_FIXED, profiles/r2_fixed_point_shapes.txt): the
     // integer kernel gains in proportion to outputs x channels x taps, its staging pass costs in proportion to the input

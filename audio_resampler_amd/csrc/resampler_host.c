@@ -67,6 +67,7 @@ struct artamd_resampler {
     int timing; void **ev; int ev_count, ev_cap; double prep_ms;
     art_s *d_patch; size_t patch_cap;        /* end-point extrapolation: samples computed on the host */
     void *d_scratch; size_t scratch_cap;     /* MFMA path: effective rows + canonical positions of one launch */
+    void *d_pad; size_t pad_cap;             /* matrix path of a channel count the kernels are not compiled for: the groups' padded buffers (arthip_fir_pad_bytes) */
     void *d_planes; size_t planes_cap;       /* fixed-point matrix kernel: digit planes of one launch (flag word first) */
     void *d_split; size_t split_cap;         /* K-split streaming kernel: arrival counters (zero at rest) + partial sums of one launch */
     int last_fixed [4];                      /* its last launch of the last call: flag value (0: none), mask words, chunks per tile, kernel form (art_hip.h) */
@@ -554,7 +555,8 @@ static Resample *init_sharded (int numChannels, int numTaps, int numFilters, dou
         hip->ev_shard [s] = arthip_order_event_create ();
         hip->nshards = s + 1;
         ok = hip->shards [s] && hip->ev_shard [s];
-        if (ok) { hip->shards [s]->hip->stream_channels = numChannels; hip->shards [s]->hip->stream_irregular = irregular; }
+        (void) irregular;                                /* (every width runs the compiled kernels now: a shard of 3 channels in a group of 4 — fir_dispatch.hip, fir_in_groups) */
+        if (ok) { hip->shards [s]->hip->stream_channels = numChannels; hip->shards [s]->hip->stream_irregular = 0; }
     }
     if (prev >= 0) arthip_set_device (prev);
 
@@ -686,7 +688,7 @@ void resampleFree (Resample *cxt)
         arthip_event_destroy (hip->ev_parent);
         free (hip->shards); free (hip->shard_first); free (hip->ev_shard);
         bank_release (hip->bank); arthip_free (hip->d_hist [0]); arthip_free (hip->d_hist [1]);
-        arthip_free (hip->d_in); arthip_free (hip->d_out); arthip_free (hip->d_tmp); arthip_free (hip->d_fix); arthip_free (hip->d_scratch); arthip_free (hip->d_planes); arthip_free (hip->d_split); arthip_free (hip->d_patch); arthip_free (hip->d_batch);
+        arthip_free (hip->d_in); arthip_free (hip->d_out); arthip_free (hip->d_tmp); arthip_free (hip->d_fix); arthip_free (hip->d_scratch); arthip_free (hip->d_pad); arthip_free (hip->d_planes); arthip_free (hip->d_split); arthip_free (hip->d_patch); arthip_free (hip->d_batch);
         arthip_host_free (hip->h_in); arthip_host_free (hip->h_out);
         for (int i = 0; i < hip->ev_cap; ++i) arthip_event_destroy (hip->ev [i]);
         if (hip->own_stream) arthip_stream_destroy (hip->stream);
@@ -1251,6 +1253,10 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
             }
             a.split = split_want ? hip->d_split : NULL; a.split_bytes = hip->d_split ? hip->split_cap : 0;
             a.fixed_out = hip->last_fixed;
+            /* a channel count the matrix kernels are not compiled for: room for its groups' padded copies */
+            const size_t pad_want = arthip_fir_pad_bytes (&a, res.output_generated);
+            if (pad_want > hip->pad_cap) hip->d_pad = grow (hip->d_pad, &hip->pad_cap, pad_want);
+            a.pad = pad_want ? hip->d_pad : NULL; a.pad_bytes = hip->d_pad ? hip->pad_cap : 0;
         }
 
         /* A call of more ring epochs than a table holds (short filters: an epoch is a few hundred frames) is cut into launches of

@@ -1,0 +1,58 @@
+"""Channel counts the matrix-core kernels are not compiled for (3, 5, 6, 7, 12, 24, 33, 64 ...) run their matrix-path launches in groups of a
+compiled width (fir_dispatch.hip, fir_in_groups): against the oracle like every other stream, and — a channel's arithmetic depending neither
+on its group's width nor on its neighbours — bit for bit what the same channel gives inside a stream of a compiled width."""
+import numpy as np
+import pytest
+
+import audio_resampler_amd as A
+from _hip import HipResampler, tolerance_ok
+from _oracle import noise, OracleResampler, BH, INTERP, PRECISE
+
+pytestmark = pytest.mark.gpu
+R = 48000 / 44100
+
+
+def _run(r, x, sizes, ratio=R):
+    outs = []; pos = 0; kinds = []
+    for n in sizes:
+        u, g, y = r.process(x[pos:pos + n], int(n * ratio) + 4000, ratio)
+        assert u == n
+        outs.append(np.array(y).copy()); pos += n; kinds.append((int(r.last_kernel()), int(r.fixed_point()[0])))
+    return np.concatenate(outs), kinds
+
+
+@pytest.mark.parametrize("ch,wide,T", [(6, 8, 988), (3, 4, 988), (12, 16, 512), (5, 8, 380), (33, 64, 988), (24, 32, 156)])
+def test_a_channel_is_the_same_in_a_group_and_in_a_stream_of_a_compiled_width(ch, wide, T):
+    sizes = [150000, 3000, 60000] if ch < 33 else [40000, 3000, 20000]
+    x, _ = noise(sum(sizes) * wide, state=ch * 77 + 1); x = x.reshape(-1, wide)
+    if wide > 32:                                               # (a 64-channel stream is two groups of 32 itself: compare with a 32-channel one)
+        narrow = HipResampler(ch, T, T, 0.0, BH | INTERP, kernel=2); narrow.advance(T / 2)
+        ref = HipResampler(32, T, T, 0.0, BH | INTERP, kernel=2); ref.advance(T / 2)
+        ya, ka = _run(narrow, np.ascontiguousarray(x[:, :ch]), sizes)
+        yb, kb = _run(ref, np.ascontiguousarray(x[:, :32]), sizes)
+        assert np.array_equal(ya[:, :32].view(np.uint32), yb.view(np.uint32)), (ka, kb)
+        assert all(k[0] == 2 for k in ka)
+        return
+    narrow = HipResampler(ch, T, T, 0.0, BH | INTERP, kernel=7 if T >= 512 else 2); narrow.advance(T / 2)
+    ref = HipResampler(wide, T, T, 0.0, BH | INTERP, kernel=7 if T >= 512 else 2); ref.advance(T / 2)
+    ya, ka = _run(narrow, np.ascontiguousarray(x[:, :ch]), sizes)
+    yb, kb = _run(ref, x, sizes)
+    assert ka == kb and all(k[0] == 2 for k in ka), (ka, kb)     # (the matrix path, the same kernel family, in both)
+    assert np.array_equal(ya.view(np.uint32), yb[:, :ch].view(np.uint32)), (ch, ka)
+
+
+@pytest.mark.parametrize("ch", [3, 6, 7, 12, 40])
+def test_grouped_launches_against_the_oracle(ch):
+    T = 380
+    big = int(3.5e8 / (ch * T))                                 # (frames from which such a stream's calls take the matrix path, with room)
+    sizes = [big, 2500, big // 2]
+    x, _ = noise(sum(sizes) * ch, state=ch * 13 + 5); x = x.reshape(-1, ch)
+    r = HipResampler(ch, T, T, 0.0, BH | INTERP); r.advance(T / 2)
+    o = OracleResampler(ch, T, T, 0.0, BH | INTERP | PRECISE); o.advance(T / 2)
+    y, kinds = _run(r, x, sizes)
+    assert (2, 0) in kinds or (2, 1) in kinds, kinds             # (the big calls took the matrix path)
+    yo = []; pos = 0
+    for n in sizes:
+        u, g, yy = o.process(x[pos:pos + n], int(n * R) + 4000, R); yo.append(np.array(yy).copy()); pos += n
+    ok, worst, rms = tolerance_ok(y, np.concatenate(yo))
+    assert ok, (ch, worst, rms)

@@ -331,8 +331,9 @@ def test_slices_are_widths_the_matrix_kernels_are_compiled_for(monkeypatch):
             assert a [:2] == b [:2] and ka == kb, (ch, n, ka, kb)
             assert np.array_equal(np.array(a [2]).view(np.uint32), np.array(b [2]).view(np.uint32)), (ch, n, ka, kb)
             kinds.append(kb)
-        # 16 channels over 3 shards = 8 4 4: the big call runs in fixed point on every shard; the other two streams never do
-        assert ((2, 1) in kinds) == (ch == 16), (ch, kinds)
+        # the big call runs in fixed point on every shard of every one of the three streams — 12 channels as 4 2 2 2 2, 7 as 4 3 (the
+        # 3-channel shard in a group of 4: fir_in_groups), 16 as 8 4 4 — and on the ordinary context (12 in a group of 16, 7 in 8)
+        assert (2, 1) in kinds, (ch, kinds)
 
 
 # ---- the other two stages spread the same way: DECIMATE_MULTITHREADED (reference decimator.c:92-93, 119-136) and a multi-device biquad bank ----
