@@ -886,7 +886,9 @@ bool artfir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int
     else {
         // (not a compiled width: the launch runs in groups of compiled widths behind two copies, fir_dispatch.hip — when it has the
         // buffer for them; the old rule stays: such streams are rare, and below it the general kernel is at home)
-        enough = (double) total * C * a->T >= 1.2e8;
+        // (measured with the groups in place, tools/bench_crossover2.py 6x988 6x380 3x988 12x988 64x988 24x156: the rule sits on the
+        // crossover for one group; a stream of several groups pays the matrix path's floor once per group)
+        enough = (double) total * C * a->T >= 1.2e8 * ((C + 31) / 32);
     }
     return a->mode == ART_MODE_FAST && a->period_out > 0 && a->fix_list && a->scratch && a->in_pitch == 0 && a->out_pitch == 0 &&
                          segs->lin_floor == INT_MIN && kernel_pref != ART_KERNEL_GENERAL &&
