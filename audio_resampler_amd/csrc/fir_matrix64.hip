@@ -285,14 +285,17 @@ bool artfir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int
 {
     if (a->n_end <= a->n_begin || (a->mode & 3) == ART_MODE_STRICT) return false;
     const unsigned int total = a->n_end - a->n_begin;
-    const double k_ns = ((0.2 + 0.05 * a->C) + 0.00021 * a->C * a->T) * (general_group (a->T) == 16 ? 0.55 : a->T <= 512 ? 0.85 : 0.95);
-    const double floor_ns = 15000.0 + 4100.0 * ((a->T + 63) / 32);
+    const int Cs = a->stream_C > a->C ? a->stream_C : a->C;     // (a group of a wider stream decides as the stream does)
+    const double k_ns = ((0.2 + 0.05 * Cs) + 0.00021 * Cs * a->T) * (general_group (a->T) == 16 ? 0.55 : a->T <= 512 ? 0.85 : 0.95);
+    const double floor_ns = (15000.0 + 4100.0 * ((a->T + 63) / 32)) * ((Cs + 31) / 32);
     const bool enough = total * k_ns >= floor_ns - 5000.0;
     const bool small = (size_t) a->in_frames * a->C * 8 < 0x7fff0000ull && (size_t) a->H * a->C * 8 < 0x7fff0000ull &&
                        ((uintptr_t) a->in % 16) == 0 && ((uintptr_t) a->hist % 16) == 0;
     const int cgt = (small && (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32)) ? a->C : 0;
+    // (a channel count the kernel is not compiled for: in groups of a compiled width, where the launch has the buffer for them — fir_dispatch.hip)
+    const bool grouped = a->pad != nullptr && (a->C > 32 || (a->C & (a->C - 1)) != 0);
     return a->mode == ART_MODE_FAST && a->period_out > 0 && a->fix_list && a->scratch && a->in_pitch == 0 && a->out_pitch == 0 &&
-                    segs->lin_floor == INT_MIN && kernel_pref != ART_KERNEL_GENERAL && cgt != 0 &&
+                    segs->lin_floor == INT_MIN && kernel_pref != ART_KERNEL_GENERAL && (cgt != 0 || grouped) &&
                     (enough || kernel_pref >= ART_KERNEL_MFMA) && total >= (unsigned int) a->period_out;
 }
 
@@ -314,7 +317,7 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
         const bool small = (size_t) a->in_frames * a->C * 8 < 0x7fff0000ull && (size_t) a->H * a->C * 8 < 0x7fff0000ull &&
                            ((uintptr_t) a->in % 16) == 0 && ((uintptr_t) a->hist % 16) == 0;
         const int cgt = (small && (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32)) ? a->C : 0;
-        const bool ok = artfir_takes_matrix_path (a, segs, kernel_pref);
+        const bool ok = cgt != 0 && artfir_takes_matrix_path (a, segs, kernel_pref);     // (cgt == 0 here: the groups could not run — no buffer — and the general kernel takes the call)
         if (ok) {
             WideGeom g;
             {   // (short or badly fitting periods: several at a time, fir_common.hip.h)

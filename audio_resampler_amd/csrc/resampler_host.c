@@ -1222,10 +1222,10 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
         if (a.period_out && a.mode == ART_MODE_FAST && hip->kernel_pref != ART_KERNEL_GENERAL && !is_flush) {
             ArtSegTable probe;
             probe.count = 1; probe.lin_floor = lin_floor;
-            a.fix_count = a.fix_list = (unsigned int *) hip; a.scratch = hip; a.scratch_bytes = (size_t) 8 << 20;
+            a.fix_count = a.fix_list = (unsigned int *) hip; a.scratch = hip; a.scratch_bytes = (size_t) 8 << 20; a.pad = hip;
             a.n_begin = 0; a.n_end = res.output_generated;
             matrix_sized = arthip_fir_takes_matrix_path (&a, &probe, hip->kernel_pref);
-            a.fix_count = a.fix_list = NULL; a.scratch = NULL; a.scratch_bytes = 0; a.n_begin = a.n_end = 0;
+            a.fix_count = a.fix_list = NULL; a.scratch = NULL; a.scratch_bytes = 0; a.n_begin = a.n_end = 0; a.pad = NULL;
         }
         if (matrix_sized) {
             /* [0] per-launch count, [1] running total of outputs the matrix kernels evaluated off their canonical pattern

@@ -56,3 +56,27 @@ def test_grouped_launches_against_the_oracle(ch):
         u, g, yy = o.process(x[pos:pos + n], int(n * R) + 4000, R); yo.append(np.array(yy).copy()); pos += n
     ok, worst, rms = tolerance_ok(y, np.concatenate(yo))
     assert ok, (ch, worst, rms)
+
+
+def test_channel_groups_in_the_8_byte_build():
+    """libartamd64: a 6-channel stream's big calls on the fp64 matrix kernel in a group of 8 — the same bits per channel as in an 8-channel stream, and the oracle's bar"""
+    W = A.wide()
+    import _oracle
+    Wo = _oracle.wide()
+    T, sizes = 380, [200000, 3000, 60000]
+    x, _ = noise(sum(sizes) * 8, state=4242); x = x.reshape(-1, 8).astype(np.float64)
+    a = W.Resampler(6, T, T, 0.0, BH | INTERP); a.advance(T / 2)
+    b = W.Resampler(8, T, T, 0.0, BH | INTERP); b.advance(T / 2)
+    o = Wo.OracleResampler(6, T, T, 0.0, BH | INTERP); o.advance(T / 2)
+    pos = 0
+    for n in sizes:
+        cap = int(n * R) + 4000
+        ua, ga, ya = a.process(np.ascontiguousarray(x[pos:pos + n, :6]), cap, R)
+        ub, gb, yb = b.process(x[pos:pos + n], cap, R)
+        uo, go, yo = o.process(np.ascontiguousarray(x[pos:pos + n, :6]), cap, R)
+        pos += n
+        assert (ua, ga) == (ub, gb) == (uo, go)
+        if a.last_kernel() == b.last_kernel():
+            assert np.array_equal(np.array(ya).view(np.uint64), np.array(yb)[:, :6].view(np.uint64)), n
+        assert np.abs(np.array(ya) - np.array(yo)).max() <= 2.0 ** -44, n
+    assert a.last_kernel() in (1, 2)
