@@ -94,7 +94,9 @@ ResampleResult resampleProcessAndFlushInterleavedDevice (Resample *cxt, const ar
 int resampleProcessBatchInterleavedDevice (Resample *const *cxts, int n, const artsample_t *const *d_inputs, const int *numInputFrames,
                                            artsample_t *const *d_outputs, const int *numOutputFrames, const double *ratios,
                                            ResampleResult *results);
-/* planar device buffers: channel c at d_input + c*inputPitch (in samples), likewise output */
+/* planar device buffers: channel c at d_input + c*inputPitch (in samples), likewise output; a pitch of 0 on either side means that side
+ * is interleaved.  Big calls are transposed through the context's interleaved staging on the device (the matrix-core kernels read
+ * interleaved frames): the same samples as the interleaved entry point's, bit for bit */
 ResampleResult resampleProcessPlanarDevice (Resample *cxt, const artsample_t *d_input, long inputPitch, int numInputFrames,
                                             artsample_t *d_output, long outputPitch, int numOutputFrames, double ratio);
 
