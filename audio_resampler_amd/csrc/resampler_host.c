@@ -1655,7 +1655,9 @@ static ResampleResult enqueue_call_layouts (Resample *cxt, const art_s *d_in, lo
             in_i = hip->d_in;
         }
         if (ok && out_pitch) {
-            hip->d_out = grow (hip->d_out, &hip->out_cap, sizeof (art_s) * (size_t) cap * C);
+            /* (room for the frames the call will make, not for the caller's whole capacity) */
+            const ResampleResult pk = peek_call (cxt, nIn, cap, ratio);
+            hip->d_out = grow (hip->d_out, &hip->out_cap, sizeof (art_s) * ((size_t) pk.output_generated + 16) * C);
             ok = hip->d_out != NULL;
             out_i = hip->d_out;
         }
