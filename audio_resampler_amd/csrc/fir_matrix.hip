@@ -999,7 +999,9 @@ size_t artfir_planes_bytes (const ArtFirArgs *a_, unsigned int outputs, int kern
     // and its extra launch ~4 us: long filters and big calls win (8 ch x 988 taps: from ~90k frames per call, +27 % at 1M;
     // 4 and 32 channels alike), 380-tap and shorter filters lose at every size (13 chunks per tile: the f32 kernel is not
     // matrix-bound there).  kernel_pref 7 takes the fixed-point kernel wherever it can run.
-    if (kernel_pref != 7 && (a->T < 512 || (double) outputs * (a->stream_C > a->C ? a->stream_C : a->C) * a->T < 8.5e8)) return 0;
+    // (one- and two-channel streams: the register-staged integer kernel plus its staging passes lose to the f32 kernel at every size —
+    // 2 ch x 988 taps, 1M frames: 28.4 against 30.9 Gsamples/s, mono 16.8 / 17.5; re-measured at the end of round 4)
+    if (kernel_pref != 7 && (a->T < 512 || (a->stream_C > a->C ? a->stream_C : a->C) <= 2 || (double) outputs * (a->stream_C > a->C ? a->stream_C : a->C) * a->T < 8.5e8)) return 0;
     static const bool off = [] { const char *e = getenv ("ARTAMD_NO_FIXED"); return e && *e && *e != '0'; } ();
     if (off) return 0;
     MfmaGeom g;
