@@ -1001,7 +1001,14 @@ size_t artfir_planes_bytes (const ArtFirArgs *a_, unsigned int outputs, int kern
     // matrix-bound there).  kernel_pref 7 takes the fixed-point kernel wherever it can run.
     // (one- and two-channel streams: the register-staged integer kernel plus its staging passes lose to the f32 kernel at every size —
     // 2 ch x 988 taps, 1M frames: 28.4 against 30.9 Gsamples/s, mono 16.8 / 17.5; re-measured at the end of round 4)
-    if (kernel_pref != 7 && (a->T < 512 || (a->stream_C > a->C ? a->stream_C : a->C) <= 2 || (double) outputs * (a->stream_C > a->C ? a->stream_C : a->C) * a->T < 8.5e8)) return 0;
+    // (medium filters, 256-511 taps: only calls of ~1M frames of an 8-channel stream win — 8 ch x 380 taps 101.7 -> 109.0 Gsamples/s, 8 ch x 448
+    // 86.2 -> 98.3, 8 ch x 256 +2 %; 16 ch x 380 loses 4 %, 32 ch x 256 9 %, 4 ch x 380 7 %, and 8 ch x 380 at 524k frames 4 %)
+    {
+        const int Cs = a->stream_C > a->C ? a->stream_C : a->C;
+        const bool long_rows = a->T >= 512 && (double) outputs * Cs * a->T >= 8.5e8;
+        const bool medium_rows = a->T >= 256 && a->T < 512 && Cs >= 8 && Cs < 16 && outputs >= 900000u;
+        if (kernel_pref != 7 && (Cs <= 2 || !(long_rows || medium_rows))) return 0;
+    }
     static const bool off = [] { const char *e = getenv ("ARTAMD_NO_FIXED"); return e && *e && *e != '0'; } ();
     if (off) return 0;
     MfmaGeom g;
