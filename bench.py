@@ -139,6 +139,9 @@ def main():
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
+            # gloo picks its interface by resolving the box's hostname, which a fresh container may not be able to do: one node,
+            # so the loopback is the right device whatever the hostname says
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
             dist.init_process_group(backend)
 
     from audio_resampler_amd.shard import agree_and_aggregate, channel_slice
@@ -223,27 +226,53 @@ def main():
     # (reference fan-out: resampler.c:442-470, one worker per channel of one context).  Its own context and buffers, W warmup + K
     # timed steps between barriers like the headline; never `value`.
     config_d = None
+    config_d_error = None
+    dev = "cuda" if backend == "nccl" else "cpu"
+
+    def all_ranks_ok(ok):
+        """every rank enters the barriers of the config_d leg or none does: one rank's failure must not hang the others"""
+        if dist is None:
+            return ok
+        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item() == 1.0)
+
     if args.scaling == "weak" and not args.kernel and args.total_channels >= world:
-        lo_d, hi_d = channel_slice(args.total_channels, world, rank)
-        Cd = hi_d - lo_d
-        d_in_d = torch.from_numpy(stream_slice(block, lo_d, hi_d)).cuda()
-        d_out_d = torch.empty(cap, Cd, device="cuda", dtype=torch.float32)
-        rs_d = A.Resampler(Cd, TAPS, FILTERS, 0.0, A.BLACKMAN_HARRIS | A.SUBSAMPLE_INTERPOLATE)
-        rs_d.advance(TAPS / 2.0)
-        rs_d.set_stream(torch.cuda.current_stream().cuda_stream)
-        for _ in range(args.warmup):
-            rs_d.process_device(d_in_d, block, d_out_d, cap, ratio)
-        barrier()
-        rs_d.set_timing(True)
-        frames_d = 0
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            frames_d += rs_d.process_device(d_in_d, block, d_out_d, cap, ratio)[1]
-        barrier()
-        dt_d = time.perf_counter() - t0
-        k_ms_d, launches_d = rs_d.read_timing()
-        rs_d.set_timing(False)
-        config_d = (dt_d, frames_d, Cd, k_ms_d, launches_d, rs_d.fixed_point_kernel() or {1: "general", 2: "mfma (f32)"}.get(rs_d.last_kernel()))
+        rs_d = d_in_d = d_out_d = None
+        Cd = 0
+        try:
+            lo_d, hi_d = channel_slice(args.total_channels, world, rank)
+            Cd = hi_d - lo_d
+            d_in_d = torch.from_numpy(stream_slice(block, lo_d, hi_d)).cuda()
+            d_out_d = torch.empty(cap, Cd, device="cuda", dtype=torch.float32)
+            rs_d = A.Resampler(Cd, TAPS, FILTERS, 0.0, A.BLACKMAN_HARRIS | A.SUBSAMPLE_INTERPOLATE)
+            rs_d.advance(TAPS / 2.0)
+            rs_d.set_stream(torch.cuda.current_stream().cuda_stream)
+            for _ in range(args.warmup):
+                used, made = rs_d.process_device(d_in_d, block, d_out_d, cap, ratio)
+                assert used == block and 0 < made < cap, (used, made)
+            torch.cuda.synchronize()
+            ok = True
+        except Exception as e:                       # reported in the line ("config_d_error"), never fatal to `value`
+            config_d_error = f"rank {rank}: {type(e).__name__}: {e}"
+            print(f"bench.py: config_d leg skipped: {config_d_error}", file=sys.stderr, flush=True)
+            ok = False
+        if all_ranks_ok(ok):
+            barrier()
+            rs_d.set_timing(True)
+            frames_d = 0
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                used, made = rs_d.process_device(d_in_d, block, d_out_d, cap, ratio)
+                assert used == block and 0 < made < cap, (used, made)
+                frames_d += made
+            barrier()
+            dt_d = time.perf_counter() - t0
+            k_ms_d, launches_d = rs_d.read_timing()
+            rs_d.set_timing(False)
+            config_d = (dt_d, frames_d, Cd, k_ms_d, launches_d, rs_d.fixed_point_kernel() or {1: "general", 2: "mfma (f32)"}.get(rs_d.last_kernel()))
+        elif config_d_error is None:
+            config_d_error = "another rank could not set the leg up"
         del rs_d, d_in_d, d_out_d
 
     dev = "cuda" if backend == "nccl" else "cpu"
@@ -369,6 +398,8 @@ def main():
                                 "workload": f"BASELINE.json configs[3]: ONE {args.total_channels}-channel 44.1k->48k preset -4 stream, its channels shared among "
                                             f"the {world} rank(s) ({config_d[2]} per GPU here; 4 per GPU at N = 8), {block} input frames per call, same W + K steps "
                                             "between barriers as the headline; the strong-scaling figure (total work fixed as N grows), never `value`"}
+        if config_d_error:
+            line["config_d_error"] = config_d_error
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(Cn)
         print(json.dumps(line), flush=True)
@@ -379,4 +410,15 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException as e:
+        if isinstance(e, SystemExit) and e.code in (0, None):
+            raise
+        # a rank that dies under torch.distributed.run leaves only the launcher's summary behind unless it says why itself: the
+        # traceback goes to BOTH streams, tagged with the rank, so that whoever captured either can read the cause
+        import traceback
+        text = f"bench.py: rank {os.environ.get('RANK', '0')} of {os.environ.get('WORLD_SIZE', '1')} FAILED\n" + traceback.format_exc()
+        for stream in (sys.stderr, sys.stdout):
+            print("\n".join("bench.py[FAILED] " + l for l in text.splitlines()), file=stream, flush=True)
+        raise

@@ -19,9 +19,31 @@ def pytest_configure(config):
         build()
 
 
+# Order of a run (the driver's `pytest -m gpu -x -q` stops at the first failure): arithmetic first, infrastructure last, so that no
+# environment-level failure of a child process (torch.distributed.run, bench.py, the reference's binaries) can stand in front of
+# a parity test.  0 = the parity tests proper (every BASELINE config's golden, full sizes, fuzz, the 64-bit build, the stretcher),
+# 1 = the other kernel-level parity tests, 2 = tests that run sessions / the reference's tools in child processes,
+# 3 = bench.py and multi-rank launches.  Within a class the usual (alphabetical, definition) order stays.
+_FIRST = ("test_gpu_parity", "test_gpu_fullsize", "test_gpu_fixed_point", "test_gpu_fuzz", "test_wide", "test_stretch",
+          "test_oracle_golden", "test_oracle_vs_ref", "test_host_logic")
+_CHILD = ("test_gpu_general_pipe", "test_gpu_pass_fixup", "test_gpu_slab_kernel", "test_gpu_dropin")
+_WIDE_CHILD = ("test_reference_artest64_binary_on_the_hip_library_matches_reference_checksums", "test_art64_cli_on_hip_library_writes_the_same_file_as_reference_art64")
+_LAUNCH = ("test_gpu_bench_ranks", "test_shard_gloo")
+
+
+def _run_class(item):
+    name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+    if name in _LAUNCH or "bench" in item.name:
+        return 3
+    if name in _CHILD or (name == "test_wide" and getattr(item, "originalname", item.name) in _WIDE_CHILD):
+        return 2
+    return 0 if name in _FIRST else 1
+
+
 def pytest_collection_modifyitems(config, items):
     from _oracle import have_ref
     skip_ref = pytest.mark.skip(reason="oracle/_ref not built here (/root/reference absent)")
     for item in items:
         if "ref" in item.keywords and not have_ref("strict"):
             item.add_marker(skip_ref)
+    items.sort(key=_run_class)                       # stable

@@ -3,31 +3,19 @@
 few scalars of the reduction travelling over gloo (ARTAMD_BENCH_BACKEND=gloo, bench.py) — rendezvous, channel slices of ONE
 stream, barrier + max-over-ranks timing, frame-count agreement and the JSON line are what is under test, not the numbers."""
 import json
-import os
-import socket
-import subprocess
-import sys
 
 import pytest
 
+from _spawn import run_ranks
+
 pytestmark = pytest.mark.gpu
-
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def _free_port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname() [1]; s.close()
-    return p
 
 
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
 def test_bench_runs_with_two_ranks(scaling):
-    env = dict(os.environ, ARTAMD_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
-           "--block-frames", "262144", "--preroll-ms", "20", "--scaling", scaling, "--no-cpu-baseline"]
-    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr [-2000:]
+    out, failed = run_ranks(2, ["--gpus", "2", "--steps", "4", "--warmup", "1", "--block-frames", "262144", "--preroll-ms", "20",
+                                "--scaling", scaling, "--no-cpu-baseline"], ARTAMD_BENCH_BACKEND="gloo")
+    assert out.returncode == 0, "\n=====\n".join(failed)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout [-2000:]                # rank 0 alone prints
     line = json.loads(lines [0])

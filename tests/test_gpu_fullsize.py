@@ -85,11 +85,10 @@ def test_bench_line_keeps_its_contract():
     """bench.py prints ONE JSON line with the fields the driver reads (metric / value / unit / n_gpus / steps / warmup /
     ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload) plus `roofline` and — unless
     switched off — `cpu_baseline`; the workload is BASELINE.json's, the kernel the matrix-core one, value = samples / time."""
-    import json, os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2", "--preroll-ms", "20", "--no-cpu-baseline"],
-                         capture_output=True, text=True, timeout=600, cwd=root)
-    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    from _spawn import run_bench, report
+    out = run_bench(["--steps", "5", "--warmup", "2", "--preroll-ms", "20", "--no-cpu-baseline"])
+    assert out.returncode == 0, report(out)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
@@ -118,12 +117,10 @@ def test_bench_line_keeps_its_contract():
 
 def test_bench_strong_mode_is_one_32_channel_stream():
     """--scaling strong: ONE 32-channel stream (BASELINE.json configs[3]) cut 32/N per GPU; on one GPU the rank owns all 32"""
-    import json, os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--scaling", "strong", "--steps", "3", "--warmup", "1",
-                          "--preroll-ms", "0", "--block-frames", "262144", "--no-cpu-baseline"],
-                         capture_output=True, text=True, timeout=600, cwd=root)
-    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    from _spawn import run_bench, report
+    out = run_bench(["--scaling", "strong", "--steps", "3", "--warmup", "1", "--preroll-ms", "0", "--block-frames", "262144", "--no-cpu-baseline"])
+    assert out.returncode == 0, report(out)
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["scaling"] == "strong" and d["config"]["stream_channels"] == 32 and d["config"]["channels_per_gpu"] == 32
     assert "STRONG" in d["config"]["workload"] and d["config"]["fir_kernel"] == "mfma-i8 (fixed point)" and d["roofline"]["frac"] <= 1.0

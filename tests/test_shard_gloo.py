@@ -35,7 +35,7 @@ def _worker(rank, world, port, q, hip=False):
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
     from _oracle import OracleResampler, noise, BH, INTERP
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     total_ch, T = 6, 48
     x, _ = noise(total_ch * 3000)
