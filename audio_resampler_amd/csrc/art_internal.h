@@ -56,8 +56,6 @@ typedef struct {
     int stream_C;                        /* channels of the whole stream when this context is a shard of a multi-device context (0: = C): the
                                           * kernel choice is made for the stream, so that a shard and an ordinary context of the same stream
                                           * run the same kernels and produce the same bits */
-    int stream_plain;                    /* a shard of a stream whose channel slices are not all 1, 2, 4, 8, 16 or 32 wide: the matrix path keeps to
-                                          * the generic f32 instantiation an ordinary context of such a stream runs: no channel of the stream gets other arithmetic */
     int interpolate, lowpass;            /* SUBSAMPLE_INTERPOLATE / INCLUDE_LOWPASS in effect */
     int mode;                            /* ART_MODE_* */
     double ratio;
@@ -123,6 +121,7 @@ int   arthip_d2d (void *dst, const void *src, size_t bytes, void *stream);
 int   arthip_zero (void *dst, size_t bytes, void *stream);
 int   arthip_sync (void *stream);
 const char *arthip_last_error (void);
+void arthip_set_last_error (const char *text);
 void *arthip_event_create (void);
 void  arthip_event_destroy (void *ev);
 int   arthip_event_record (void *ev, void *stream);

@@ -29,6 +29,8 @@ static int fail (hipError_t e, const char *what)
 extern "C" {
 
 const char *arthip_last_error (void) { return g_err; }
+// (the error string is per thread; a worker thread's is handed to the thread that reports it)
+void arthip_set_last_error (const char *text) { snprintf (g_err, sizeof (g_err), "%s", text ? text : "no error"); }
 const char *artamdVersion (void) { return ART_WIDE ? "artamd 0.1 (gfx950, 64-bit samples)" : "artamd 0.1 (gfx950)"; }
 
 int arthip_device_count (void)

@@ -23,16 +23,25 @@ size_t arthip_fir_planes_bytes (const ArtFirArgs *a, unsigned int outputs, int k
 // its group's width or on its neighbours: the same bits as the same channel in any other context (a shard, a wider stream).
 // ---------------------------------------------------------------------------------------------------
 static inline bool channels_irregular (int C) { return C > 32 || (C & (C - 1)) != 0; }
-static inline int padded_width (int w) { int p = 1; while (p < w) p <<= 1; return p; }
+// (never narrower than 4: the last group of a 33- or 34-channel stream runs the kernels every other group of the stream runs — the
+// 16-byte-vector forms, fixed point where the stream's size asks for it — not the 1- and 2-channel streams' own choice)
+static inline int padded_width (int w) { int p = 4; while (p < w) p <<= 1; return p; }
+static inline size_t align256 (size_t b) { return (b + 255) & ~(size_t) 255; }
+// a group's buffer: [history][input][outputs], each on a 256-byte boundary (the matrix kernels take 16-byte vectors from the input and
+// look at its alignment when they choose their instantiation: directly behind a history of 1.5 T frames a 1-wide group's input sat on
+// an 8-byte boundary and ran the generic instantiation — other bits than the same channel has anywhere else)
+static inline size_t group_hist_bytes (const ArtFirArgs *a, size_t wp) { return align256 ((size_t) a->H * wp * sizeof (art_s)); }
+static inline size_t group_in_bytes (const ArtFirArgs *a, size_t wp) { return align256 ((size_t) a->in_frames * wp * sizeof (art_s)); }
 
-__global__ void group_in_kernel (art_s *dst, const art_s *hist, const art_s *in, int H, int in_frames, int C, int c0, int w, int wp)
+__global__ void group_in_kernel (art_s *dst, art_s *dst_in, const art_s *hist, const art_s *in, int H, int in_frames, int C, int c0, int w, int wp)
 {
     const size_t total = (size_t)(H + in_frames) * wp, stride = (size_t) gridDim.x * blockDim.x;
     for (size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
         const size_t f = e / wp; const int c = (int)(e - f * wp);
         art_s v = 0;
         if (c < w) v = f < (size_t) H ? hist [f * C + c0 + c] : in [(f - H) * C + c0 + c];
-        dst [e] = v;                                          // ([history frames][wp] then [input frames][wp]: one array)
+        // ([history frames][wp], then — on a 256-byte boundary of its own, as a caller's buffer would be — [input frames][wp])
+        if (f < (size_t) H) dst [e] = v; else dst_in [e - (size_t) H * wp] = v;
     }
 }
 
@@ -49,7 +58,7 @@ size_t arthip_fir_pad_bytes (const ArtFirArgs *a, unsigned int outputs)
 {
     if (!channels_irregular (a->C) || a->in_pitch || a->out_pitch || (a->mode & 3) != ART_MODE_FAST) return 0;
     const size_t wp = a->C > 32 ? 32 : (size_t) padded_width (a->C);
-    return (((size_t)(a->H + a->in_frames) * wp * sizeof (art_s) + 255) & ~(size_t) 255) + (size_t) outputs * wp * sizeof (art_s) + 256;
+    return group_hist_bytes (a, wp) + group_in_bytes (a, wp) + (size_t) outputs * wp * sizeof (art_s) + 256;
 }
 
 // 0: not for this launch (the caller goes on as before); else artfir_matrix's return value for the whole launch
@@ -61,19 +70,23 @@ static int fir_in_groups (const ArtFirArgs *a, const ArtSegTable *segs, int kern
     const unsigned int outs = a->n_end - a->n_begin;
     if (arthip_fir_pad_bytes (a, outs) > a->pad_bytes) return 0;
     const size_t wp_max = a->C > 32 ? 32 : (size_t) padded_width (a->C);
-    art_s *p_in = (art_s *) a->pad;
-    art_s *p_out = (art_s *)((char *) a->pad + (((size_t)(a->H + a->in_frames) * wp_max * sizeof (art_s) + 255) & ~(size_t) 255));
+    art_s *p_hist = (art_s *) a->pad;
+    art_s *p_in = (art_s *)((char *) a->pad + group_hist_bytes (a, wp_max));
+    art_s *p_out = (art_s *)((char *) p_in + group_in_bytes (a, wp_max));
     int rc = 0;
+    // (timing: ONE pair of events around all the groups — their copies and staging passes are this launch's time)
+    if (a->ev_start) arthip_event_record (a->ev_start, (void *) st);
     for (int c0 = 0; c0 < a->C; c0 += 32) {
         const int w = a->C - c0 < 32 ? a->C - c0 : 32, wp = padded_width (w);
         const size_t in_elems = (size_t)(a->H + a->in_frames) * wp;
         hipLaunchKernelGGL (group_in_kernel, dim3 ((unsigned int)((in_elems + 255) / 256 < 4096 ? (in_elems + 255) / 256 : 4096)), dim3 (256), 0, st,
-                            p_in, a->hist, a->in, a->H, a->in_frames, a->C, c0, w, wp);
+                            p_hist, p_in, a->hist, a->in, a->H, a->in_frames, a->C, c0, w, wp);
         ArtFirArgs b = *a;
-        b.C = wp; b.hist = p_in; b.in = p_in + (size_t) a->H * wp;
+        b.C = wp; b.hist = p_hist; b.in = p_in;
+        b.ev_start = b.ev_stop = nullptr;
         b.out = p_out - (size_t) a->n_begin * wp;             // (the kernels index outputs from the call's first)
         b.roll_dst = nullptr; b.roll_appended = 0;            // (the history is rolled once, below, in the stream's own layout)
-        b.stream_C = a->stream_C > a->C ? a->stream_C : a->C; b.stream_plain = 0;
+        b.stream_C = a->stream_C > a->C ? a->stream_C : a->C;
         b.pad = nullptr; b.pad_bytes = 0;
         const int r = artfir_matrix (&b, segs, kernel_pref, (void *) st);
         if (r <= 0) { if (c0 == 0 && r == 0) return 0; return -1; }      // (declined before anything ran: the caller's other paths; later: cannot be, same decisions)
@@ -82,6 +95,7 @@ static int fir_in_groups (const ArtFirArgs *a, const ArtSegTable *segs, int kern
         hipLaunchKernelGGL (group_out_kernel, dim3 ((unsigned int)((out_elems + 255) / 256 < 4096 ? (out_elems + 255) / 256 : 4096)), dim3 (256), 0, st,
                             a->out, p_out, a->n_begin, a->n_end, a->C, c0, w, wp);
     }
+    if (a->ev_stop) arthip_event_record (a->ev_stop, (void *) st);
     if (a->roll_dst && arthip_roll_history (a->roll_dst, a->hist, a->in, 0, a->roll_appended, a->H, a->C, (void *) st)) return -1;
     if (hipGetLastError () != hipSuccess) return -1;
     return (rc & ~ART_FIR_ROLLED) | (a->roll_dst ? ART_FIR_ROLLED : 0);

@@ -848,11 +848,14 @@ static size_t pass_fixup_min ()
 }
 bool artfir_pass_fixup_wanted (const ArtFirArgs *a)
 {
-    return !a->interpolate && !a->lowpass && a->out_pitch == 0 && a->in_pitch == 0 && (size_t)(a->n_end - a->n_begin) * a->C >= pass_fixup_min ();
+    // (the pass's slot list holds 1024 x 32 slots of a period: a longer period — the period multiple included — keeps the kernels' own
+    // PASS epilogues, decided HERE, before the instantiation is chosen, so that no launch can end up with neither)
+    const long period = (long) a->period_out * (a->period_out > 0 ? artfir_period_multiple (a->period_out, 32) : 1);
+    return !a->interpolate && !a->lowpass && a->out_pitch == 0 && a->in_pitch == 0 && period > 0 && period <= 8192 && (size_t)(a->n_end - a->n_begin) * a->C >= pass_fixup_min ();
 }
 void artfir_pass_fixup (const ArtFirArgs *a, const MfmaGeom &g, hipStream_t st)
 {
-    if (g.P > 1024 * 32) return;                              // (cannot be: P <= filters x period multiple)
+    if (g.P > 1024 * 32) { fprintf (stderr, "artamd: pass-through pass: a period of %d slots (cannot be: artfir_pass_fixup_wanted)\n", g.P); abort (); }
     const unsigned int total = a->n_end - a->n_begin;
     const unsigned long long items = (unsigned long long)((total + g.P - 1) / g.P) * a->C;       // (per flagged slot)
     unsigned int blocks = (unsigned int)((items + 255) / 256);
@@ -908,9 +911,7 @@ static int matrix_geometry (const ArtFirArgs *a, MfmaGeom &g)
     }
     // compile-time channel count where the whole stream is one column group and the buffers allow vector loads
     const bool small = (size_t) a->in_frames * a->C * 4 < 0xffff0000ull && ((uintptr_t) a->in % 16) == 0 && ((uintptr_t) a->hist % 16) == 0;
-    // (a shard of a stream that an ordinary context would run on the generic instantiation — channel count or slices not of the
-    // compiled widths — runs the generic instantiation too: the wave-specialised kernels round differently in 1 sample of 30)
-    const int cgt = (small && !a->stream_plain && (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32)) ? a->C : 0;
+    const int cgt = (small && (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32)) ? a->C : 0;
     g.tile_rows = 32;
     g.slot_tiles = (g.P + g.tile_rows - 1) / g.tile_rows;
     g.cg = a->C < 32 ? a->C : 32;
@@ -942,14 +943,14 @@ static ArtFirArgs widest_group (const ArtFirArgs *a)
     if (a->C > 32 || (a->C & (a->C - 1))) {
         int wp = 1; while (wp < (a->C > 32 ? 32 : a->C)) wp <<= 1;
         b.stream_C = a->stream_C > a->C ? a->stream_C : a->C;
-        b.C = wp; b.in = nullptr; b.hist = nullptr; b.stream_plain = 0;        // (the groups' own buffers are 256-byte aligned)
+        b.C = wp; b.in = nullptr; b.hist = nullptr;        // (the groups' own buffers are 256-byte aligned)
     }
     return b;
 }
 
 static int matrix_split_parts (const ArtFirArgs *a, const MfmaGeom &g, unsigned int outputs, int kernel_pref)
 {
-    if (kernel_pref == 5 || kernel_pref == 6 || kernel_pref == 7 || a->stream_plain) return 1;
+    if (kernel_pref == 5 || kernel_pref == 6 || kernel_pref == 7) return 1;
     static const bool off = [] { const char *e = getenv ("ARTAMD_NO_SPLIT"); return e && *e && *e != '0'; } ();
     if (off) return 1;
     const int C = a->stream_C > a->C ? a->stream_C : a->C;
@@ -993,7 +994,7 @@ bool artfir_matrix_spans_segments (const ArtFirArgs *a, const ArtSegTable *segs,
 size_t artfir_planes_bytes (const ArtFirArgs *a_, unsigned int outputs, int kernel_pref)
 {
     const ArtFirArgs wg_ = widest_group (a_), *a = &wg_;
-    if (!a->period_out || a->mode != ART_MODE_FAST || kernel_pref == 5 || kernel_pref == 6 || kernel_pref == 8 || a->stream_plain) return 0;
+    if (!a->period_out || a->mode != ART_MODE_FAST || kernel_pref == 5 || kernel_pref == 6 || kernel_pref == 8) return 0;
     // Where it pays (MI355X, tools/bench_shapes.py with and without ARTAMD_NO_FIXED, profiles/r2_fixed_point_shapes.txt): the
     // integer kernel gains in proportion to outputs x channels x taps, its staging pass costs in proportion to the input
     // and its extra launch ~4 us: long filters and big calls win (8 ch x 988 taps: from ~90k frames per call, +27 % at 1M;

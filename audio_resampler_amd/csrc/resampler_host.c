@@ -60,7 +60,6 @@ struct artamd_resampler {
     int floor_active;                       /* ring index 0 is a hard history floor (after a flush-time rewind) */
     int kernel_pref, last_kernel;
     int stream_channels;                     /* a shard: channels of the whole stream (kernel choice); 0 otherwise */
-    int stream_irregular;                    /* a shard of a stream whose slices are not all 1/2/4/8/16/32 wide: f32 matrix kernels only */
     /* cached rational structure of the current ratio */
     double period_ratio; int period_out, period_in;
     /* optional HIP-event timing of FIR launches */
@@ -518,12 +517,10 @@ static Resample *init_sharded (int numChannels, int numTaps, int numFilters, dou
      * kernels are compiled for 1, 2, 4, 8, 16 and 32 channels: with every slice one of those widths all shards of a stream run the
      * same kernels — the ordinary context's bits.  So the channels are written as a sum of `count` such widths where that is possible
      * (binary digits of the channel count, the largest part halved until there are enough: 12 over 5 = 4 2 2 2 2, 8 over 3 = 4 2 2);
-     * where it is not (7 channels on 2 devices) the slices are balanced and the stream is marked irregular: every shard then keeps to
-     * the generic f32 matrix kernel an ordinary context of such a stream runs (no fixed point, no K split, no wave-specialised
-     * form: channels of one stream never get different arithmetic). */
-    /* (a stream whose own channel count is not one of those widths runs the generic f32 matrix kernel as an ordinary context: its
-     * shards keep to f32 too) */
-    int widths [MAX_DEVICES], parts = 0, irregular = numChannels > 32 || (numChannels & (numChannels - 1));
+     * where it is not (7 channels on 2 devices) the slices are balanced.  A slice — or a stream — of any other width runs its matrix-path
+     * launches in groups of a compiled width (fir_dispatch.hip, fir_in_groups): a channel's arithmetic depends neither on its group's
+     * width nor on its neighbours, so channels of one stream never get different arithmetic whatever the slices are. */
+    int widths [MAX_DEVICES], parts = 0;
     {
         int left = numChannels;
         while (left > 0 && parts < count) {              /* the channel count's binary digits, 32 at most per part */
@@ -545,7 +542,6 @@ static Resample *init_sharded (int numChannels, int numTaps, int numFilters, dou
     if (parts != count) {
         const int base = numChannels / count, extra = numChannels % count;
         for (int s = 0; s < count; ++s) widths [s] = base + (s < extra ? 1 : 0);
-        for (int s = 0; s < count; ++s) if (widths [s] > 32 || (widths [s] & (widths [s] - 1))) irregular = 1;
     }
     for (int s = 0; ok && s < count; ++s) {
         const int width = widths [s];
@@ -555,8 +551,7 @@ static Resample *init_sharded (int numChannels, int numTaps, int numFilters, dou
         hip->ev_shard [s] = arthip_order_event_create ();
         hip->nshards = s + 1;
         ok = hip->shards [s] && hip->ev_shard [s];
-        (void) irregular;                                /* (every width runs the compiled kernels now: a shard of 3 channels in a group of 4 — fir_dispatch.hip, fir_in_groups) */
-        if (ok) { hip->shards [s]->hip->stream_channels = numChannels; hip->shards [s]->hip->stream_irregular = 0; }
+        if (ok) hip->shards [s]->hip->stream_channels = numChannels;
     }
     if (prev >= 0) arthip_set_device (prev);
 
@@ -1205,7 +1200,7 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
         a.in_frames = is_flush ? (flush_in ? T / 2 : 0) : (int) res.input_used;
         a.out = d_out; a.out_pitch = out_pitch;
         a.C = C; a.T = T; a.F = cxt->numFilters; a.H = H;
-        a.stream_C = hip->stream_channels; a.stream_plain = hip->stream_irregular;
+        a.stream_C = hip->stream_channels;
         a.interpolate = (cxt->flags & SUBSAMPLE_INTERPOLATE) != 0;
         a.lowpass = (cxt->flags & INCLUDE_LOWPASS) != 0;
         /* the double-precision build has one arithmetic: EXTEND_CONVOLUTION_MATH only matters for 4-byte samples
@@ -1365,7 +1360,7 @@ static int batch_plan (Resample *cxt, const art_s *d_in, int nIn, art_s *d_out, 
     a->in = d_in; a->in_pitch = 0; a->in_frames = (int) res->input_used;
     a->out = d_out; a->out_pitch = 0;
     a->C = C; a->T = T; a->F = cxt->numFilters; a->H = H;
-    a->stream_C = hip->stream_channels; a->stream_plain = hip->stream_irregular;
+    a->stream_C = hip->stream_channels;
     a->interpolate = (cxt->flags & SUBSAMPLE_INTERPOLATE) != 0;
     a->lowpass = (cxt->flags & INCLUDE_LOWPASS) != 0;
     a->mode = (!ART_WIDE && (cxt->flags & EXTEND_CONVOLUTION_MATH)) ? ART_MODE_PRECISE : ART_MODE_FAST;
@@ -1504,9 +1499,28 @@ static ResampleResult shard_part (Resample *cxt, int k, const struct shard_job *
 
     arthip_set_device (sp->device);
     arthip_stream_wait_event (sp->stream, hip->ev_parent);
-    if (j->in_pitch || j->out_pitch)
+    if (j->in_pitch && j->out_pitch)
         res = enqueue_call_layouts (sh, j->d_in ? j->d_in + (size_t) first * j->in_pitch : NULL, j->in_pitch, j->nIn,
                                     j->d_out + (size_t) first * j->out_pitch, j->out_pitch, j->cap, j->ratio);
+    else if (j->in_pitch || j->out_pitch) {
+        /* one side planar, the other interleaved (a pitch of 0): the planar side is the shard's own run of planes; the interleaved side
+         * is a strided slice of the caller's stream-wide frames and goes through the shard's slice staging, as in the branch below */
+        const int wpw = (int)(sizeof (art_s) / 4);
+        if (j->out_pitch) {                                     /* interleaved in, planar out */
+            sp->d_in = grow (sp->d_in, &sp->in_cap, sizeof (art_s) * (size_t) j->peek.input_used * width);
+            if (j->peek.input_used && !sp->d_in) { *failed = 1; arthip_event_record (hip->ev_shard [k], sp->stream); return res; }
+            if (j->peek.input_used && j->d_in)
+                arthip_slice_copy (sp->d_in, (size_t) width * wpw, j->d_in + first, (size_t) C * wpw, width * wpw, j->peek.input_used, sp->stream);
+            res = enqueue_call_layouts (sh, j->d_in ? sp->d_in : NULL, 0, j->nIn, j->d_out + (size_t) first * j->out_pitch, j->out_pitch, j->cap, j->ratio);
+        }
+        else {                                                  /* planar in, interleaved out */
+            sp->d_out = grow (sp->d_out, &sp->out_cap, sizeof (art_s) * ((size_t) j->peek.output_generated + 16) * width);
+            if (j->peek.output_generated && !sp->d_out) { *failed = 1; arthip_event_record (hip->ev_shard [k], sp->stream); return res; }
+            res = enqueue_call_layouts (sh, j->d_in ? j->d_in + (size_t) first * j->in_pitch : NULL, j->in_pitch, j->nIn, sp->d_out, 0, j->cap, j->ratio);
+            if (res.output_generated)
+                arthip_slice_copy (j->d_out + first, (size_t) C * wpw, sp->d_out, (size_t) width * wpw, width * wpw, res.output_generated, sp->stream);
+        }
+    }
     else {
         sp->d_in = grow (sp->d_in, &sp->in_cap, sizeof (art_s) * (size_t) j->peek.input_used * width);
         sp->d_out = grow (sp->d_out, &sp->out_cap, sizeof (art_s) * (size_t) j->peek.output_generated * width);
@@ -1529,6 +1543,7 @@ struct shard_pool {
     struct shard_job job;
     ResampleResult res [MAX_DEVICES];
     int failed [MAX_DEVICES];
+    char err [MAX_DEVICES] [256];            /* a worker's own error text (arthip_last_error is per thread) for the caller to report */
     pthread_t thread [MAX_DEVICES];
     int started;
     pthread_mutex_t lock;
@@ -1551,7 +1566,9 @@ static void *shard_worker (void *p)
         seen = pool->call;
         pthread_mutex_unlock (&pool->lock);
         pool->failed [k] = 0;
+        arthip_set_last_error (NULL);
         pool->res [k] = shard_part (pool->cxt, k, &pool->job, &pool->failed [k]);
+        snprintf (pool->err [k], sizeof (pool->err [k]), "%s", arthip_last_error ());
         pthread_mutex_lock (&pool->lock);
         if (--pool->pending == 0) pthread_cond_signal (&pool->done);
     }
@@ -1619,7 +1636,11 @@ static ResampleResult sharded_device_call (Resample *cxt, const art_s *d_in, lon
         pthread_cond_broadcast (&pool->go);
         while (pool->pending) pthread_cond_wait (&pool->done, &pool->lock);
         pthread_mutex_unlock (&pool->lock);
-        for (int k = 0; k < hip->nshards; ++k) { per_shard [k] = pool->res [k]; failed |= pool->failed [k]; }
+        for (int k = 0; k < hip->nshards; ++k) {
+            per_shard [k] = pool->res [k]; failed |= pool->failed [k];
+            /* (a worker that failed, or whose launch made nothing where shard 0's made something: its thread's error text becomes this thread's) */
+            if (pool->failed [k] || per_shard [k].output_generated != pool->res [0].output_generated) arthip_set_last_error (pool->err [k]);
+        }
     }
     else
         for (int k = 0; k < hip->nshards; ++k) { int f = 0; per_shard [k] = shard_part (cxt, k, &job, &f); failed |= f; }

@@ -64,7 +64,7 @@ void resampleHipSetKernel (Resample *cxt, int which);
 int  resampleHipLastKernel (Resample *cxt);          /* which kernel produced the bulk of the last call */
 /* the matrix-core path's fixed-point kernel (regular launches, 4-byte samples): 0 = the last call did not use it, 1 = it ran,
  * 2 = it was enqueued and stood down for the f32 kernel behind it (a sample outside (-1.98, 1.98) or not finite).
- * *pairsPerChunk (may be NULL): digit-pair products issued per 32-tap chunk, 9 .. 13.  Synchronises. */
+ * *pairsPerChunk (may be NULL): digit-pair products issued per 32-tap chunk, 5 .. 13 (5 where both upper digit planes of the rows are zero, + 4 for each that is not).  Synchronises. */
 int  resampleHipLastFixedPoint (Resample *cxt, double *pairsPerChunk);
 /* the form of the fixed-point kernel the last call's last launch was given to: 0 none, 1 fir_i8_stream_kernel (register-staged: 1 and 2
  * channels, ARTAMD_I8_DMA=0), 2 fir_i8_dma_kernel (LDS-DMA staging, 32-slot tiles), 3 fir_i8_slab_kernel (64 x 256 tiles, big launches).

@@ -32,6 +32,12 @@ def test_a_channel_is_the_same_in_a_group_and_in_a_stream_of_a_compiled_width(ch
         yb, kb = _run(ref, np.ascontiguousarray(x[:, :32]), sizes)
         assert np.array_equal(ya[:, :32].view(np.uint32), yb.view(np.uint32)), (ka, kb)
         assert all(k[0] == 2 for k in ka)
+        # the channels of the LAST group (one channel wide here, copied into a 4-wide buffer): what the same channels give in the
+        # second group of a 64-channel stream (the kernel family follows the STREAM's size, so a stream of a similar size is the reference)
+        full = HipResampler(wide, T, T, 0.0, BH | INTERP, kernel=2); full.advance(T / 2)
+        yc, kc = _run(full, x, sizes)
+        assert ka == kc, (ka, kc)
+        assert np.array_equal(ya[:, 32:ch].view(np.uint32), yc[:, 32:ch].view(np.uint32)), (ka, kc)
         return
     narrow = HipResampler(ch, T, T, 0.0, BH | INTERP, kernel=7 if T >= 512 else 2); narrow.advance(T / 2)
     ref = HipResampler(wide, T, T, 0.0, BH | INTERP, kernel=7 if T >= 512 else 2); ref.advance(T / 2)
