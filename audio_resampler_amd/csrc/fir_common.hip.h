@@ -118,6 +118,40 @@ __device__ __forceinline__ art_s direct_sample (const ArtFirArgs &a, int lin_flo
 // (Levels are unrolled at compile time — with a run-time count of live values the register array is indexed
 // dynamically and every exchange turns into a chain of compares and selects over the whole array: 1,400 VALU
 // instructions per output for 16 values instead of ~80.)
+// lane L <- the value of lane L ^ M, through the data-parallel paths of the vector unit instead of the LDS crossbar (__shfl_xor =
+// ds_bpermute_b32: an LDS round trip of ~100+ cycles per 32-bit half, and the five dependent levels of a reduction were close to half
+// of a pass of the any-ratio kernels): quad permutes (M = 1, 2), row shifts picked by the lane's bit (4), a row rotation (8), the
+// gfx950 row / half swaps (16, 32).  The same pairs exchange the same values: bit-neutral.
+template <int M>
+__device__ __forceinline__ unsigned int xor_lane_b32 (unsigned int v, int lane)
+{
+    if constexpr (M == 1) return (unsigned int) __builtin_amdgcn_mov_dpp ((int) v, 0xB1, 0xf, 0xf, true);        // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return (unsigned int) __builtin_amdgcn_mov_dpp ((int) v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    else if constexpr (M == 4) {
+        const unsigned int up = (unsigned int) __builtin_amdgcn_mov_dpp ((int) v, 0x104, 0xf, 0xf, true);        // row_shl:4 — lane L reads lane L + 4
+        const unsigned int dn = (unsigned int) __builtin_amdgcn_mov_dpp ((int) v, 0x114, 0xf, 0xf, true);        // row_shr:4 — lane L reads lane L - 4
+        return (lane & 4) ? dn : up;
+    }
+    else if constexpr (M == 8) return (unsigned int) __builtin_amdgcn_mov_dpp ((int) v, 0x128, 0xf, 0xf, true);  // row_ror:8 (rows of 16: L <-> L ^ 8)
+    else if constexpr (M == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap (v, v, false, false);      // r[0] = rows {0,0,2,2}, r[1] = rows {1,1,3,3} of v
+        return (lane & 16) ? r [0] : r [1];
+    }
+    else if constexpr (M >= 64) return v;                     // (no such lane: instantiated only in branches that are never taken)
+    else {
+        static_assert (M == 32, "lane masks 1 .. 32");
+        const auto r = __builtin_amdgcn_permlane32_swap (v, v, false, false);      // r[0] = halves {lo,lo}, r[1] = halves {hi,hi} of v
+        return (lane & 32) ? r [0] : r [1];
+    }
+}
+template <int M>
+__device__ __forceinline__ double xor_lane (double v, int lane)
+{
+    const unsigned long long b = (unsigned long long) __double_as_longlong (v);
+    const unsigned int lo = xor_lane_b32<M> ((unsigned int) b, lane), hi = xor_lane_b32<M> ((unsigned int)(b >> 32), lane);
+    return __longlong_as_double ((long long)(((unsigned long long) hi << 32) | lo));
+}
+
 template <int N, int M>                            // N live values, lane mask M
 __device__ __forceinline__ void reduce_level (double *v, int lane)
 {
@@ -128,12 +162,12 @@ __device__ __forceinline__ void reduce_level (double *v, int lane)
             for (int j = 0; j < N / 2; ++j) {
                 const double keep = upper ? v [j + N / 2] : v [j];
                 const double send = upper ? v [j] : v [j + N / 2];
-                v [j] = keep + __shfl_xor (send, M);
+                v [j] = keep + xor_lane<M> (send, lane);
             }
             reduce_level<N / 2, M / 2> (v, lane);
         }
         else {
-            v [0] = v [0] + __shfl_xor (v [0], M);
+            v [0] = v [0] + xor_lane<M> (v [0], lane);
             reduce_level<1, M / 2> (v, lane);
         }
     }

@@ -18,7 +18,7 @@ constexpr int GEN_MAX_TILE = 32;
 // reduction and the per-output bookkeeping are then paid once per FOUR outputs, which is most of the cost when taps x
 // channels is small).  G depends on the tap count only, never on the tile, so a frame's value does not depend on how a
 // call is cut up.
-template <int CG, bool INTERP, bool PRECISE, int G, bool PIPE = false>
+template <int CG, bool INTERP, bool PRECISE, int G, bool PIPE = false, bool LEAN = false>
 __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const ArtSegTable &segs, int tile, unsigned int bx, unsigned int by)
 {
     constexpr int SUBS = 64 / G;
@@ -130,10 +130,10 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
         const art_s *x = xs + (size_t)(ip - half + 1 - lin_lo) * CG;
         art_s result [CG];
 
-        if (!INTERP && !a.lowpass && (fi % a.F) == 0) {
+        if (!INTERP && !a.lowpass && (fi == 0 || fi == a.F)) {      // (fi % F == 0 with fi in [0, F]: no integer division in every pass)
             // exact sample hit in nearest-filter mode: the reference copies the sample through
 #pragma unroll
-            for (int c = 0; c < CG; ++c) result [c] = x [(size_t)(half - 1 + fi / a.F) * CG + c];
+            for (int c = 0; c < CG; ++c) result [c] = x [(size_t)(half - 1 + (fi == a.F ? 1 : 0)) * CG + c];
             if constexpr (PIPE) { if (i0 + (GEN_THREADS / 64) * SUBS < cnt) fetch (index_of (i0 + (GEN_THREADS / 64) * SUBS), 0); }     // (these lanes' next output)
         }
         else {
@@ -177,6 +177,58 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
                 }
                 if (i0 + STRIDE < cnt) fetch (index_of (i0 + STRIDE), 0);      // (the next output's first round travels under this one's reduction)
             }
+            else if constexpr (LEAN) {
+                // The plain loop below, instruction for instruction leaner (the kernel is bound by vector-instruction ISSUE — ~210 wave
+                // instructions per pass of two outputs for its 12 packed multiply-adds at 380 taps, tools/attic/fir_cell_kernel_r5.txt —
+                // not by the trips its loads make): R steps at a time, their coefficient loads (buffer loads: one address per lane and
+                // side, the step in the instruction's offset) and LDS reads (likewise) all issued before the first multiply-add, no loop
+                // control or address arithmetic between them.  A lane takes the same taps in the same order: the same bits.
+                constexpr int R = CG >= 2 ? 3 : 6;        // (steps in flight: their samples and coefficients are registers — occupancy — of every wave)
+                constexpr unsigned int SZ = sizeof (art_s);
+                const int steps = (half + G - 1) / G;                // (uniform)
+                const int le = l < half ? l : 0;                     // (lanes past the row's half — short filters — read lane 0's taps and drop them)
+                const unsigned int row = (unsigned int) fi * (unsigned int) a.T;
+                unsigned int lo = (row + (unsigned int) le) * SZ, hi = (row + (unsigned int)(a.T - 1 - le)) * SZ;
+                const art_s *xl = x + (size_t) le * CG, *xh = x + (size_t)(a.T - 1 - le) * CG;
+                const unsigned int next_row = INTERP ? (unsigned int) a.T * SZ : 0u;
+                for (int r0 = 0; r0 < steps; r0 += R) {
+                    art_s c0v [R] [2], c1v [R] [2], xv [R] [2] [CG];
+#pragma unroll
+                    for (int u = 0; u < R; ++u)
+                        if (r0 + u < steps) {
+                            // (the last step of a row may lie past its half for the upper lanes: what they read — taps of the row's other half, inside
+                            // the row and the window — is dropped below)
+                            c0v [u] [0] = tap (lo + (unsigned int)(u * G) * SZ, 0u);
+                            c0v [u] [1] = tap (hi - (unsigned int)(u * G) * SZ, 0u);
+                            if (INTERP) { c1v [u] [0] = tap (lo + (unsigned int)(u * G) * SZ, next_row); c1v [u] [1] = tap (hi - (unsigned int)(u * G) * SZ, next_row); }
+#pragma unroll
+                            for (int c = 0; c < CG; ++c) { xv [u] [0] [c] = xl [(size_t)(u * G) * CG + c]; xv [u] [1] [c] = (xh - (size_t)(u * G) * CG) [c]; }
+                        }
+#pragma unroll
+                    for (int u = 0; u < R; ++u)
+                        if (r0 + u < steps && l + (r0 + u) * G < half) {
+#pragma unroll
+                            for (int side = 0; side < 2; ++side) {
+                                const art_s c0 = c0v [u] [side];
+                                const art_s c1 = INTERP ? c1v [u] [side] : 0.0f;
+#pragma unroll
+                                for (int c = 0; c < CG; ++c) {
+                                    const art_s v = xv [u] [side] [c];
+                                    if (PRECISE) {
+                                        acc0 [c] = acc0 [c] + (Acc) c0 * (Acc) v;
+                                        if (INTERP) acc1 [c] = acc1 [c] + (Acc) c1 * (Acc) v;
+                                    }
+                                    else {
+                                        acc0 [c] = fused ((Acc) c0, (Acc) v, acc0 [c]);
+                                        if (INTERP) acc1 [c] = fused ((Acc) c1, (Acc) v, acc1 [c]);
+                                    }
+                                }
+                            }
+                        }
+                    lo += (unsigned int)(R * G) * SZ; hi -= (unsigned int)(R * G) * SZ;
+                    xl += (size_t)(R * G) * CG; xh -= (size_t)(R * G) * CG;
+                }
+            }
             else
             for (int p = l; p < half; p += G) {
 #pragma unroll
@@ -216,7 +268,7 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
             art_s y;
             if (INTERP) {
                 // the lane group of row fi fetches row fi+1 from the neighbouring group; fp64 lerp, un-fused
-                const double s1 = __shfl_xor (mine, GROUP);
+                const double s1 = xor_lane<GROUP> (mine, lane);
                 const double left = mine * (1.0 - frac);
                 const double right = s1 * frac;
                 y = (art_s)(left + right);
@@ -245,11 +297,11 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
   }
 }
 
-template <int CG, bool INTERP, bool PRECISE, int G, bool PIPE>
+template <int CG, bool INTERP, bool PRECISE, int G, bool PIPE, bool LEAN>
 __global__ __launch_bounds__ (GEN_THREADS)
 void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile)
 {
-    fir_general_body<CG, INTERP, PRECISE, G, PIPE> (a, segs, tile, blockIdx.x, blockIdx.y);
+    fir_general_body<CG, INTERP, PRECISE, G, PIPE, LEAN> (a, segs, tile, blockIdx.x, blockIdx.y);
 }
 
 
@@ -397,8 +449,9 @@ int launch_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st
     static const bool pipe_on = [] { const char *e = getenv ("ARTAMD_GENERAL_PIPE"); return !(e && *e == '0'); } ();      // (A/B runs and the bit-identity test)
 
 #define GO(I, P) do { const int gg = general_group (a.T); if (gg == 16) GO_ (I, P, 16); else if (gg == 32) GO_ (I, P, 32); else GO_ (I, P, 64); } while (0)
-#define GO_(I, P, GG) do { if (CG >= 4 && a.T >= 512 && pipe_on) GO__ (I, P, GG, (CG >= 4)); else GO__ (I, P, GG, false); } while (0)
-#define GO__(I, P, GG, PP) do { auto k = fir_general_kernel<CG, I, P, GG, PP>; \
+    static const bool lean_on = [] { const char *e = getenv ("ARTAMD_GENERAL_LEAN"); return !(e && *e == '0'); } ();      // (likewise: =0 pins the plain loop)
+#define GO_(I, P, GG) do { if (CG >= 4 && a.T >= 512 && pipe_on) GO__ (I, P, GG, (CG >= 4), false); else if (lean_on && CG <= 2) GO__ (I, P, GG, false, (CG <= 2)); else GO__ (I, P, GG, false, false); } while (0)
+#define GO__(I, P, GG, PP, LL) do { auto k = fir_general_kernel<CG, I, P, GG, PP, LL>; \
         if (lds > 48 * 1024) (void) hipFuncSetAttribute ((const void *) k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
         hipLaunchKernelGGL (k, grid, dim3 (GEN_THREADS), lds, st, a, segs, tile); } while (0)
     if (a.interpolate) { if (precise) GO (true, true); else GO (true, false); }

@@ -898,6 +898,7 @@ constexpr size_t SL_PART_BYTES = (size_t) 8 * 16 * 64 * 16;      // one part of 
 
 struct I8Slab {
     int wgs_per_xcd;                      // W
+    int tail;                             // 0: the run behind the whole rounds is W + (L mod W) tiles (each tile cut in two at most); 1: L mod W tiles, cut into W pieces
     int live [8];                         // tiles of each XCD's list that hold outputs (they are a prefix of the list)
     unsigned char *parts;                 // [xcd][rank][2] parts of SL_PART_BYTES
     unsigned int *arrivals;               // [xcd][SL_MAX_SK][8 waves], zero between launches
@@ -947,7 +948,7 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
     int D, S;
     {
         const int R = L / W, rem = L - R * W;
-        D = rem ? (R > 0 ? R - 1 : 0) : R;
+        D = rem && !sl.tail ? (R > 0 ? R - 1 : 0) : R;
         S = L - D * W;
     }
     const int Ct = S * nch, Weff = S ? (W < Ct ? W : Ct) : 1;
@@ -1473,6 +1474,7 @@ int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGe
         // slabs: one eight-wave workgroup per CU (all of its LDS), which also rolls the history and carries the stand-by
         I8Slab sl;
         sl.wgs_per_xcd = SL_WGS;
+        { static const int tail_env = [] { const char *e = getenv ("ARTAMD_I8_SLAB_TAIL"); return e && *e ? atoi (e) : 0; } (); sl.tail = tail_env; }
         sl.parts = q.parts;
         sl.arrivals = (unsigned int *)((char *) a->planes + ART_I8_FLAG_BYTES);
         {   // tiles of each XCD's list that hold outputs: a prefix of the list (a tile holds outputs iff its first column's period does)

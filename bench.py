@@ -98,6 +98,147 @@ def stream_slice(block, lo, hi):
     return np.ascontiguousarray(np.stack(cols, axis=1))
 
 
+def other_configs(A, torch, steps, warmup):
+    """BASELINE.json configs[1], [2] and [4] beside the headline, in the same run (N = 1 only; never `value`): each W warmup + K timed
+    steps of device-resident calls between synchronisations, with the FIR kernel's own time from HIP events and the fraction of the
+    peak that bounds it.  Config C is timed END TO END (2 x biquad low-pass pre-filter, FIR, 16-bit HP-TPDF + ATH-shaped decimation:
+    the shaped decimator is a serial recurrence per channel — art.c:1011-1067 / decimator.c:255-283 — and the floor of that pipeline)
+    and stage by stage."""
+    from audio_resampler_amd.synth import noise
+    stream = torch.cuda.current_stream().cuda_stream
+    BH, IN, LP = A.BLACKMAN_HARRIS, A.SUBSAMPLE_INTERPOLATE, A.INCLUDE_LOWPASS
+    out = {}
+
+    def run(fn, k):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 0
+        for _ in range(k):
+            n += fn()
+        torch.cuda.synchronize()
+        return n, time.perf_counter() - t0
+
+    def fir_leg(ch, taps, filters, src, dst, flags, fixed, block, k, ratio_fn=None):
+        rs = A.Resampler(ch, taps, filters, 0.0, flags, fixed=(src, dst, 0) if fixed else None)
+        rs.advance(taps / 2.0)
+        rs.set_stream(stream)
+        x, _ = noise(block * ch)
+        d_in = torch.from_numpy(x.reshape(block, ch)).cuda()
+        ratio = dst / src
+        cap = int(math.floor((block + taps // 2) * ratio * 1.001 + 10))
+        d_out = torch.empty(cap, ch, device="cuda", dtype=torch.float32)
+        calls = [0]
+
+        def step():
+            r = ratio_fn(calls[0]) if ratio_fn else ratio
+            calls[0] += 1
+            used, made = rs.process_device(d_in, block, d_out, cap, 0.0 if fixed else r)
+            assert used == block and 0 < made < cap, (used, made)
+            return made * ch
+        rs.set_timing(True)
+        rs.read_timing()
+        for _ in range(warmup):
+            step()
+        rs.read_timing()                                   # (drops the warmup's events)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 0
+        for _ in range(k):
+            n += step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ms, launches = rs.read_timing()
+        rs.set_timing(False)
+        kernel = rs.last_kernel()
+        fixed_state, pairs = rs.fixed_point()
+        interp = bool(rs.L.resampleInterpolationUsed(rs.p))
+        g = math.gcd(src, dst)
+        kpad = ((taps + int(31.0 * (src // g) / (dst // g)) + 2 + 3 + 31) // 32) * 32
+        rate = n / (ms * 1e-3) if ms > 0 else 0.0
+        if kernel == 2 and fixed_state == 1:
+            name, ops, peak, unit = rs.fixed_point_kernel() or "fir_i8", 2 * kpad * pairs, PEAK_I8_TOPS, "TOP/s"
+        elif kernel == 2:
+            name, ops, peak, unit = "fir_mfma_stream_kernel (f32 matrix cores)", 2 * kpad, PEAK_FP32_TFLOPS, "TFLOP/s"
+        else:
+            name, ops, peak, unit = "fir_general_kernel", ((4 * taps + 3) if interp else 2 * taps), PEAK_FP32_TFLOPS, "TFLOP/s (algorithmic flop, vector units)"
+        return {"value": round(n / dt / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt / k * 1e3, 4), "steps": k, "block_frames": block,
+                "channels": ch, "fir_kernel": name, "avg_kernel_ms": round(ms / max(launches, 1), 4), "launches": launches,
+                "roofline": {"bound": "mfma" if kernel == 2 else "valu", "achieved": round(rate * ops / 1e12, 3), "peak": peak, "unit": unit,
+                             "frac": round(rate * ops / 1e12 / peak, 4)}}, rs, d_out, cap
+
+    # ---- configs[1]: stereo 44.1k -> 48k, preset -3 (380 x 380), Blackman-Harris, interpolating, 1M-frame calls
+    leg, rs_b, _, _ = fir_leg(2, 380, 380, SRC, DST, BH | IN, False, 1 << 20, steps)
+    leg["workload"] = "BASELINE.json configs[1]: stereo 44.1k->48k preset -3 = 380 filters x 380 taps Blackman-Harris interpolating, 1,048,576 input frames per call, device-resident"
+    out["config_b"] = leg
+    del rs_b
+
+    # ---- configs[4]: stereo ASRC, ratio 48000/44100 x (1 +- 100 ppm) updated every block, preset -3, nearest filter (no lerp), 65,536-frame blocks
+    leg, rs_e, _, _ = fir_leg(2, 380, 380, SRC, DST, BH, False, 65536, max(steps, 32),
+                              ratio_fn=lambda i: DST / SRC * (1.0 + 100e-6 * math.sin(2.0 * math.pi * i / 64.0)))
+    leg["workload"] = ("BASELINE.json configs[4]: stereo ASRC, ratio 48000/44100 x (1 +- 100 ppm) changed on every call, preset -3 = 380 x 380 nearest filter "
+                       "(no interpolation), 65,536 input frames per call, device-resident")
+    out["config_e"] = leg
+    del rs_e
+
+    # ---- configs[2]: 8 ch 96k -> 44.1k, preset -4 fixed ratio (-l implicit low-pass: 147 filters x 988 taps, nearest filter), -p biquad
+    # cascade (2 low-pass sections per channel in front), 16-bit output with HP-TPDF dither + ATH noise shaping
+    ch, taps, src, dst, block = 8, 988, 96000, 44100, 1 << 20
+    k = max(2, min(steps, 5))
+    leg, rs_c, d_out, cap = fir_leg(ch, taps, taps, src, dst, BH | IN | LP, True, block, k)
+    L = A.lib()
+    co = A.BiquadCoefficients()
+    L.biquad_lowpass(C.byref(co), dst * 0.45 / src)
+    secs = (A.Biquad * (ch * 2))()
+    for i in range(ch * 2):
+        L.biquad_init(C.byref(secs[i]), C.byref(co), 1.0)
+    bank = A.BiquadBank(secs, ch, 2)
+    bank.set_stream(stream)
+    dec = A.Decimator(ch, 16, 2, 1.0, dst, A.DITHER_HIGHPASS | A.SHAPING_ATH_CURVE)
+    dec.set_stream(stream)
+    x, _ = noise(block * ch)
+    d_src = torch.from_numpy(x.reshape(block, ch)).cuda()
+    d_in = torch.empty_like(d_src)
+    d_pcm = torch.empty(cap * ch * 2, dtype=torch.uint8, device="cuda")
+    made_c = [0]
+
+    def pre():
+        d_in.copy_(d_src)
+        bank.apply_device(d_in, block)
+        return block * ch
+
+    def fir():
+        used, made = rs_c.process_device(d_in, block, d_out, cap, 0.0)
+        assert used == block and 0 < made < cap, (used, made)
+        made_c[0] = made
+        return made * ch
+
+    def post():
+        dec.process_device(d_out, made_c[0], d_pcm)
+        return made_c[0] * ch
+
+    def whole():
+        pre()
+        n = fir()
+        post()
+        return n
+    n_all, dt_all = run(whole, k)
+    stage_ms = {}
+    for name, fn in (("biquad_prefilter", pre), ("fir", fir), ("decimate", post)):
+        _, dts = run(fn, k)
+        stage_ms[name] = round(dts / k * 1e3, 4)
+    tot = sum(stage_ms.values())
+    out["config_c"] = {"value": round(n_all / dt_all / 1e6, 2), "unit": "Msamples/s (out)", "ms_per_step": round(dt_all / k * 1e3, 4), "steps": k, "block_frames": block,
+                       "channels": ch, "stage_ms": stage_ms, "stage_share": {kk: round(v / tot, 4) for kk, v in stage_ms.items()},
+                       "fir": {kk: leg[kk] for kk in ("value", "fir_kernel", "avg_kernel_ms", "roofline")},
+                       "floor": "decimate_pipe_kernel: the ATH-shaped 16-bit decimator is a serial error-feedback recurrence per channel (one lane per channel, "
+                                "8 lanes here): it bounds this pipeline whatever the FIR stage does; without noise shaping the decimator is fully parallel",
+                       "workload": "BASELINE.json configs[2]: 8 ch 96k->44.1k, preset -4 fixed ratio with -l (147 filters x 988 taps, nearest filter, implicit low-pass), "
+                                   "-p biquad cascade (2 low-pass sections per channel), 16-bit HP-TPDF + ATH-shaped decimation; END TO END per 1,048,576-frame block, device-resident"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,6 +253,7 @@ def main():
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 general, 2 matrix path, 5 f32 tile kernel, 6 f32 streaming kernel, 7 fixed point wherever possible")
     ap.add_argument("--preroll-ms", type=float, default=200.0, help="untimed device pre-roll before the warmup steps (clock ramp); 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the config_b / config_c / config_e legs (BASELINE.json configs[1], [2], [4]) behind the headline")
     ap.add_argument("--pmc-json", default=None, help="traffic file written by tools/roofline_report.py from the rocprofv3 --pmc passes of the same lease (tools/refresh_evidence.sh; else the committed profiles/ figure is reported, labelled as such)")
     args = ap.parse_args()
 
@@ -400,6 +542,11 @@ def main():
                                             "between barriers as the headline; the strong-scaling figure (total work fixed as N grows), never `value`"}
         if config_d_error:
             line["config_d_error"] = config_d_error
+        if world == 1 and not args.kernel and not args.no_other_configs:
+            try:
+                line.update(other_configs(A, torch, args.steps, args.warmup))
+            except Exception as e:                           # (never fatal to the headline; the reason rides in the line)
+                line["other_configs_error"] = f"{type(e).__name__}: {e}"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(Cn)
         print(json.dumps(line), flush=True)

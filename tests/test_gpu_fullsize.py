@@ -113,6 +113,15 @@ def test_bench_line_keeps_its_contract():
     # value is whole-job samples over the timed region: consistent with ms_per_step and the workload's size
     per_step = d["value"] * 1e6 * d["ms_per_step"] * 1e-3
     assert abs(per_step - (1 << 20) * 8 * 48000 / 44100) / per_step < 0.01
+    # every other BASELINE.json config rides in the same line (N = 1): B (stereo -3), C (8 ch 96k -> 44.1k -4 + biquads + 16-bit ATH decimation,
+    # end to end, the decimator's share stated), E (stereo ASRC, nearest filter, the ratio changed on every call) — each with its kernel and fraction
+    assert "other_configs_error" not in d, d.get("other_configs_error")
+    b, c, e = d["config_b"], d["config_c"], d["config_e"]
+    assert b["channels"] == 2 and b["block_frames"] == 1 << 20 and b["value"] > 0 and 0 < b["roofline"]["frac"] <= 1.0 and b["roofline"]["bound"] == "mfma"
+    assert abs(b["value"] * 1e6 * b["ms_per_step"] * 1e-3 - (1 << 20) * 2 * 48000 / 44100) / ((1 << 20) * 2.2) < 0.01
+    assert e["channels"] == 2 and e["block_frames"] == 65536 and e["value"] > 0 and e["fir_kernel"] and 0 < e["roofline"]["frac"] <= 1.0
+    assert c["channels"] == 8 and c["value"] > 0 and set(c["stage_ms"]) == {"biquad_prefilter", "fir", "decimate"} and abs(sum(c["stage_share"].values()) - 1.0) < 1e-3
+    assert abs(c["value"] * 1e6 * c["ms_per_step"] * 1e-3 - (1 << 20) * 8 * 44100 / 96000) / ((1 << 20) * 3.7) < 0.01 and "floor" in c and c["fir"]["roofline"]["frac"] <= 1.0
 
 
 def test_bench_strong_mode_is_one_32_channel_stream():
