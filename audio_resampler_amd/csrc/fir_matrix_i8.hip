@@ -82,6 +82,7 @@ struct I8Geom {
     int *flag; int epoch;                 // *flag == epoch: this launch cannot run in fixed point (set by the staging pass)
     int *shifts;                          // [ebs][C]: the block's samples of channel c are quantised as rint (x * 2^shift)
     unsigned char *parts;                 // slabs: parts of tiles cut between workgroups (fir_i8_slab_kernel), behind the planes
+    int rows_cached;                      // the rows' planes, masks and tables are in place (no row workgroups in the peak launch)
 };
 
 // binary exponent for a channel whose peak magnitude has these float bits: peak * 2^shift in [2^29, 2^31 - 2^24) — as large as the
@@ -248,7 +249,7 @@ void i8_stage_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g, I8Geom q)
     // (PEAK launch: the row workgroups come first in the grid — latency chains, they finish under the X workgroups' traffic)
     // (the residue-0 row workgroups write the f32 tables too — 320 workgroups fewer, 1.1 us of the peak pass)
     const unsigned int t_wgs = 0u;
-    const unsigned int a_wgs = PEAK ? t_wgs + (unsigned int)(q.tiles * q.g * q.tr) : 0u;
+    const unsigned int a_wgs = PEAK && !q.rows_cached ? t_wgs + (unsigned int)(q.tiles * q.g * q.tr) : 0u;
     // what mfma_prepare_kernel leaves for the f32 streaming kernels (that kernel is not launched at all then), for row `row` of the
     // 32-row slot tile `st`: the effective row in float, the canonical position, the tile's origin and pass-through rows
     auto write_tables = [&] (int st, int row) {
@@ -1447,7 +1448,8 @@ int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGe
         q.b0 = (la > 0 ? la : 0) >> 2;
     }
     const unsigned int x_wgs = (unsigned int)(q.ebs * (a->C / q.cgrp) * q.slices);
-    const dim3 pgrid (x_wgs + (unsigned int)(q.tiles * q.g * q.tr)), xgrid (x_wgs + (unsigned int)((q.tiles * q.g * (q.tr / 32) + I8_STAGE_THREADS - 1) / I8_STAGE_THREADS));
+    q.rows_cached = 0;
+    const dim3 pgrid (x_wgs + (q.rows_cached ? 0u : (unsigned int)(q.tiles * q.g * q.tr))), xgrid (x_wgs + (unsigned int)((q.tiles * q.g * (q.tr / 32) + I8_STAGE_THREADS - 1) / I8_STAGE_THREADS));
     if (a->interpolate) {
         hipLaunchKernelGGL ((i8_stage_kernel<true, true>), pgrid, dim3 (I8_STAGE_THREADS), 0, st, *a, *segs, g, q);
         hipLaunchKernelGGL ((i8_stage_kernel<true, false>), xgrid, dim3 (I8_STAGE_THREADS), 0, st, *a, *segs, g, q);

@@ -137,11 +137,8 @@ def other_configs(A, torch, steps, warmup):
             used, made = rs.process_device(d_in, block, d_out, cap, 0.0 if fixed else r)
             assert used == block and 0 < made < cap, (used, made)
             return made * ch
-        rs.set_timing(True)
-        rs.read_timing()
         for _ in range(warmup):
             step()
-        rs.read_timing()                                   # (drops the warmup's events)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         n = 0
@@ -149,6 +146,11 @@ def other_configs(A, torch, steps, warmup):
             n += step()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        rs.set_timing(True)                                # (the kernel's own time: the same steps again, with events — see timed_region)
+        n_ev = 0
+        for _ in range(k):
+            n_ev += step()
+        torch.cuda.synchronize()
         ms, launches = rs.read_timing()
         rs.set_timing(False)
         kernel = rs.last_kernel()
@@ -156,7 +158,7 @@ def other_configs(A, torch, steps, warmup):
         interp = bool(rs.L.resampleInterpolationUsed(rs.p))
         g = math.gcd(src, dst)
         kpad = ((taps + int(31.0 * (src // g) / (dst // g)) + 2 + 3 + 31) // 32) * 32
-        rate = n / (ms * 1e-3) if ms > 0 else 0.0
+        rate = n_ev / (ms * 1e-3) if ms > 0 else 0.0
         if kernel == 2 and fixed_state == 1:
             name, ops, peak, unit = rs.fixed_point_kernel() or "fir_i8", 2 * kpad * pairs, PEAK_I8_TOPS, "TOP/s"
         elif kernel == 2:
@@ -313,7 +315,12 @@ def main():
         torch.cuda.synchronize()
 
     def timed_region(blk=None, steps=None):
-        """W untimed warmup steps, then EXACTLY K steps between barrier + synchronize on both sides"""
+        """W untimed warmup steps, then EXACTLY K steps between barrier + synchronize on both sides: the clean region `value` is taken
+        from — no event is recorded inside it.  Behind it, between barriers of its own, the same K steps once more with HIP events around
+        every launch's dominant kernel (on the kernel's own stream): the roofline's per-launch duration.  Events are not free — each is a
+        packet in the queue between two kernels, three per launch: measured (tools/micro/host_rate.py) 117.5 against 123.1 us per headline
+        call, 27.1 against 32.9 at 65,536 frames — which is why the two regions are separate; the instrumented region's own rate rides in
+        the line as ms_per_step_instrumented."""
         blk = block if blk is None else blk
         steps = args.steps if steps is None else steps
         cap_b = int(math.floor((blk + TAPS // 2) * ratio + 10))
@@ -321,7 +328,6 @@ def main():
             used, made = rs.process_device(d_in, blk, d_out, cap_b, ratio)
             assert used == blk and made < cap_b
         barrier()
-        rs.set_timing(True)
         frames = 0
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -329,9 +335,16 @@ def main():
             frames += made
         barrier()
         dt = time.perf_counter() - t0
+        rs.set_timing(True)
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            rs.process_device(d_in, blk, d_out, cap_b, ratio)
+        barrier()
+        dt_events = time.perf_counter() - t1
         kernel_ms, launches = rs.read_timing()
         prep_ms = rs.read_prep_timing()
         rs.set_timing(False)
+        timed_region.instrumented_ms_per_step = dt_events / steps * 1e3
         return dt, frames, kernel_ms, launches, prep_ms
 
     # From cold first (reported as value_cold): MI355X raises its clocks over the first tens of milliseconds of sustained load —
@@ -347,6 +360,7 @@ def main():
                 rs.process_device(d_in, block, d_out, cap, ratio)
             torch.cuda.synchronize()
     dt, out_frames, kernel_ms, launches, prep_ms = timed_region()
+    ms_instrumented = timed_region.instrumented_ms_per_step
     kernel_used = rs.last_kernel()
     fixed_state, fixed_pairs = rs.fixed_point()           # 1: the matrix path ran in fixed point on the integer matrix cores
     fixed_kernel_name = rs.fixed_point_kernel()           # which form of the fixed-point kernel (asked of the library, not inferred)
@@ -401,7 +415,6 @@ def main():
             ok = False
         if all_ranks_ok(ok):
             barrier()
-            rs_d.set_timing(True)
             frames_d = 0
             t0 = time.perf_counter()
             for _ in range(args.steps):
@@ -410,6 +423,10 @@ def main():
                 frames_d += made
             barrier()
             dt_d = time.perf_counter() - t0
+            rs_d.set_timing(True)                        # (the kernel's own time: the same steps again, with events — see timed_region)
+            for _ in range(args.steps):
+                rs_d.process_device(d_in_d, block, d_out_d, cap, ratio)
+            barrier()
             k_ms_d, launches_d = rs_d.read_timing()
             rs_d.set_timing(False)
             config_d = (dt_d, frames_d, Cd, k_ms_d, launches_d, rs_d.fixed_point_kernel() or {1: "general", 2: "mfma (f32)"}.get(rs_d.last_kernel()))
@@ -469,6 +486,10 @@ def main():
             "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 4),
+            "ms_per_step_instrumented": round(ms_instrumented, 4),
+            "instrumentation_note": "value / ms_per_step: K steps with NO event recorded inside the timed region; roofline.avg_kernel_ms / avg_prep_ms: the same K steps "
+                                    "run again right behind it with HIP events around every launch's dominant kernel (three event packets per launch cost the queue "
+                                    "4-6 us per call), at ms_per_step_instrumented",
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "preroll_ms": args.preroll_ms,
             "value_cold": round(agg_cold["samples_total"] / agg_cold["seconds_max"] / 1e6, 2),
             "value_cold_note": "the same W warmup + K timed steps run first, from cold clocks, before the untimed pre-roll",
