@@ -60,6 +60,8 @@ typedef struct {
     int mode;                            /* ART_MODE_* */
     double ratio;
     unsigned int n_begin, n_end;         /* call-relative output frames to produce */
+    int n_skip;                          /* matrix kernels on cached rows (below): the launch's tiles start at the cached period's first slot, n_skip
+                                          * slots before the launch's first output — those slots of the first period are computed and not stored */
     int segs_truncated;                  /* the launch reaches beyond the segments of its table (a call of more than ART_MAX_SEGS ring epochs
                                           * handed over whole, arthip_fir_spans_segments): only a kernel that follows the lattice from the
                                           * launch's first period may run it — arthip_fir returns -2, nothing enqueued, otherwise */
@@ -74,6 +76,11 @@ typedef struct {
     void *scratch; size_t scratch_bytes;
     /* device memory for the fixed-point matrix kernel's digit planes of one launch (arthip_fir_planes_bytes; NULL: f32 kernels) */
     void *planes; size_t planes_bytes;
+    /* the fixed-point kernel's filter rows ACROSS calls (digit planes, masks, the f32 tables of its stand-by): device memory of
+     * arthip_fir_rows_bytes () bytes and a zeroed host block of arthip_fir_rows_cache_bytes () bytes that describes what it holds, both owned
+     * by the context (NULL: the rows are rebuilt by every launch, as before round 5).  rows_masks_out (host, optional): where the used
+     * set's row masks live on the device (resampleHipLastFixedPoint reads them) */
+    void *rows; size_t rows_bytes; void *rows_cache; void **rows_masks_out;
     /* device memory for the K-split streaming kernel of launches with few tiles (arthip_fir_split_bytes; NULL: unsplit): the first
      * ART_SPLIT_HEAD_BYTES are arrival counters, zero whenever no launch is in flight (zeroed by the owner when allocated) */
     void *split; size_t split_bytes;
@@ -133,6 +140,13 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
 /* bytes a->planes must hold for the fixed-point matrix kernel to run a call of this shape (C, T, H, in_frames, period) making
  * `outputs` frames; 0: the call is not for it (shape, size, kernel preference) */
 size_t arthip_fir_planes_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref);
+/* the fixed-point kernel's rows across the calls of a context (ArtFirArgs.rows / rows_cache): device bytes a call of this shape wants (0: none),
+ * size of the host block that describes the device buffer (zeroed by the owner), forgetting what the buffer held (it was replaced), releasing
+ * what the host block owns */
+size_t arthip_fir_rows_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref);
+size_t arthip_fir_rows_cache_bytes (void);
+void   arthip_fir_rows_cache_reset (void *cache);
+void   arthip_fir_rows_cache_free (void *cache);
 /* bytes a->split must hold for a call of this shape making `outputs` frames to run on the K-split kernel; 0: the call is not for it */
 size_t arthip_fir_split_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref);
 /* n independent general-kernel calls (default / precise mode) in one launch per kernel variant; d_table = device scratch of

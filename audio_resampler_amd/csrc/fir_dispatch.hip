@@ -14,6 +14,8 @@ size_t arthip_fir_split_bytes (const ArtFirArgs *a, unsigned int outputs, int ke
 
 size_t arthip_fir_planes_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref) { return artfir_planes_bytes (a, outputs, kernel_pref); }
 
+size_t arthip_fir_rows_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref) { return artfir_rows_bytes (a, outputs, kernel_pref); }
+
 // ---------------------------------------------------------------------------------------------------
 // Channel counts the matrix-core kernels are not compiled for.  Their tile loops index a stream of exactly 1, 2, 4, 8, 16 or 32 channels
 // (compile-time pitch, 16-byte vectors); a 6- or 12- or 64-channel stream used to take the generic instantiation, 5-8 x slower per

@@ -139,8 +139,8 @@ void pass_fixup_kernel (ArtFirArgs a, MfmaGeom g)
             const int slot = (int)(r % (unsigned int) g.P);
             const unsigned int j = (unsigned int)(r / (unsigned int) g.P);
             const unsigned int n = a.n_begin + j * (unsigned int) g.P + (unsigned int) slot;
-            if (((word (slot >> 5) >> (slot & 31)) & 1u) && n < a.n_end)
-                a.out [(size_t) n * a.C + c] = load_frame (a, INT_MIN, g.canon_ip [slot] + g.canon_fi [slot] / a.F + (int) j * g.Q, c);
+            if (((word (slot >> 5) >> (slot & 31)) & 1u) && n < a.n_end && (j || slot >= a.n_skip))
+                a.out [(size_t) n * a.C + c] = load_frame (a, INT_MIN, g.canon_ip [slot] + g.w_shift + g.canon_fi [slot] / a.F + (int) j * g.Q, c);
         }
         return;
     }
@@ -153,8 +153,8 @@ void pass_fixup_kernel (ArtFirArgs a, MfmaGeom g)
         const unsigned int j = (unsigned int)(r / nflag);
         const int slot = s_slots [f];
         const unsigned int n = a.n_begin + j * (unsigned int) g.P + (unsigned int) slot;
-        if (n < a.n_end)
-            a.out [(size_t) n * a.C + c] = load_frame (a, INT_MIN, g.canon_ip [slot] + g.canon_fi [slot] / a.F + (int) j * g.Q, c);
+        if (n < a.n_end && (j || slot >= a.n_skip))
+            a.out [(size_t) n * a.C + c] = load_frame (a, INT_MIN, g.canon_ip [slot] + g.w_shift + g.canon_fi [slot] / a.F + (int) j * g.Q, c);
     }
 }
 
@@ -925,7 +925,7 @@ static int matrix_geometry (const ArtFirArgs *a, MfmaGeom &g)
     const unsigned int periods = (total + g.P - 1) / g.P;
     g.period_groups = (int)((periods + g.ppw - 1) / g.ppw);
     g.groups_per_xcd = (g.period_groups + 7) / 8;
-    g.eff = nullptr; g.canon_ip = g.canon_fi = nullptr; g.canon_frac = nullptr; g.head = nullptr; g.head_frames = 0; g.tile_w0 = nullptr;
+    g.eff = nullptr; g.canon_ip = g.canon_fi = nullptr; g.canon_frac = nullptr; g.head = nullptr; g.head_frames = 0; g.tile_w0 = nullptr; g.w_shift = 0;
     return cgt;
 }
 
@@ -1015,6 +1015,16 @@ size_t artfir_planes_bytes (const ArtFirArgs *a_, unsigned int outputs, int kern
     MfmaGeom g;
     const int cgt = matrix_geometry (a, g);
     return cgt ? artfir_i8_bytes (a, g, cgt, outputs) : 0;
+}
+
+// device bytes of the rows the fixed-point kernel keeps across the calls of a context (0: this call is not for that kernel)
+size_t artfir_rows_bytes (const ArtFirArgs *a_, unsigned int outputs, int kernel_pref)
+{
+    if (!artfir_planes_bytes (a_, outputs, kernel_pref)) return 0;
+    const ArtFirArgs wg_ = widest_group (a_), *a = &wg_;
+    MfmaGeom g;
+    const int cgt = matrix_geometry (a, g);
+    return cgt ? artfir_i8_rows_bytes (a, g, cgt, outputs) : 0;
 }
 
 // Launch the matrix-core path for this call if it applies: returns ART_KERNEL_MFMA (| ART_FIR_ROLLED), -1 on a launch failure,

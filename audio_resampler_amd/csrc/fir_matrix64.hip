@@ -302,6 +302,12 @@ bool artfir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int
 // Launch the fp64 matrix-core path for this call if it applies: ART_KERNEL_MFMA (| ART_FIR_ROLLED), -1 on a launch failure,
 // 0 when the call is for the general kernel.
 size_t artfir_planes_bytes (const ArtFirArgs *, unsigned int, int) { return 0; }
+size_t artfir_rows_bytes (const ArtFirArgs *, unsigned int, int) { return 0; }
+extern "C" {      // (the fixed-point kernel's rows across calls: 4-byte samples only)
+size_t arthip_fir_rows_cache_bytes (void) { return 0; }
+void arthip_fir_rows_cache_reset (void *) { }
+void arthip_fir_rows_cache_free (void *) { }
+}
 size_t artfir_split_bytes (const ArtFirArgs *, unsigned int, int) { return 0; }
 bool artfir_matrix_spans_segments (const ArtFirArgs *, const ArtSegTable *, int) { return false; }    // (the fp64 kernel checks every output's position against the table)        // (the fixed-point kernel is a 4-byte-sample path)
 

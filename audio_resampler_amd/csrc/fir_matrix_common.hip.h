@@ -24,10 +24,14 @@ struct MfmaGeom {
     // filter mode without a low-pass: the slots whose rounded filter index is a whole input sample, which the reference copies),
     // one bit per row — such a row's sample in period 0 is canon_ip + canon_fi / F; [2] unused (streaming kernels)
     int *tile_w0;
+    // rows kept across calls (fir_matrix_i8.hip): canon_ip and tile_w0 [3 st] are the BUILDING launch's linear indices; this launch's are
+    // w_shift frames further on (0: the tables were written by this launch)
+    int w_shift;
 };
 
 // fir_matrix_i8.hip: the fixed-point kernel of regular launches
-size_t artfir_i8_bytes (const ArtFirArgs *a, const MfmaGeom &g, int cgt, unsigned int outputs);   // device bytes of the digit planes of a call making `outputs` frames (0: not for it)
+size_t artfir_i8_bytes (const ArtFirArgs *a, const MfmaGeom &g, int cgt, unsigned int outputs);
+size_t artfir_i8_rows_bytes (const ArtFirArgs *a, const MfmaGeom &g, int cgt, unsigned int outputs);   // device bytes of the rows kept ACROSS calls (0: none)   // device bytes of the digit planes of a call making `outputs` frames (0: not for it)
 bool artfir_i8_slab_enabled ();           // 64-slot tiles of the slab kernel (periods are taken so as to fill those); ARTAMD_I8_SLAB=0: off
 // stage + main kernel of one launch (1), or 0: not for this path (no planes, shape)
 int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGeom &g, int cgt, unsigned int roll_blocks, hipStream_t st);

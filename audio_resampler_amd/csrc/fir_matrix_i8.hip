@@ -83,6 +83,11 @@ struct I8Geom {
     int *shifts;                          // [ebs][C]: the block's samples of channel c are quantised as rint (x * 2^shift)
     unsigned char *parts;                 // slabs: parts of tiles cut between workgroups (fir_i8_slab_kernel), behind the planes
     int rows_cached;                      // the rows' planes, masks and tables are in place (no row workgroups in the peak launch)
+    int rows_table;                       // the row workgroups build the rows of the CANONICAL period (rows kept across calls): slot k sits where the reference's
+    double tb_base; int tb_lin, tb_w;     // arithmetic puts output tb_n0 + k of an epoch of offset tb_base and ring-to-linear shift tb_lin, tb_w frames further on
+    unsigned int tb_n0;
+    int jr_rot;                           // ... built by a launch whose windows started jr_rot residues further on: period residue jr of this launch
+                                          // stages the rows of residue (jr + jr_rot) mod g
 };
 
 // binary exponent for a channel whose peak magnitude has these float bits: peak * 2^shift in [2^29, 2^31 - 2^24) — as large as the
@@ -249,13 +254,31 @@ void i8_stage_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g, I8Geom q)
     // (PEAK launch: the row workgroups come first in the grid — latency chains, they finish under the X workgroups' traffic)
     // (the residue-0 row workgroups write the f32 tables too — 320 workgroups fewer, 1.1 us of the peak pass)
     const unsigned int t_wgs = 0u;
+    // slot k of the launch's first period: its position by the reference's arithmetic — or, for rows kept across calls, from the canonical
+    // period's constants (artfir_i8_launch), which makes the rows a function of those alone
+    auto slot_pos = [&] (int k) -> Pos {
+        if (q.rows_table) {                                   // (locate () on the canonical period's own constants: what the host evaluated, to the bit)
+            const unsigned int n = q.tb_n0 + (unsigned int) k;
+            const double step = n ? (double) n / a.ratio : 0.0;
+            const double off = q.tb_base + step;
+            const double whole = floor (off);
+            Pos t;
+            double fr = off - whole;
+            fr = fr * (double) a.F;
+            if (INTERP) { t.fi = (int) floor (fr); t.frac = fr - (double) t.fi; }
+            else { t.fi = (int) floor (fr + 0.5); t.frac = 0.0; }
+            t.ip = (int) whole + q.tb_lin + q.tb_w;
+            return t;
+        }
+        return locate<INTERP> (a, segs, a.n_begin + (unsigned int) k);
+    };
     const unsigned int a_wgs = PEAK && !q.rows_cached ? t_wgs + (unsigned int)(q.tiles * q.g * q.tr) : 0u;
     // what mfma_prepare_kernel leaves for the f32 streaming kernels (that kernel is not launched at all then), for row `row` of the
     // 32-row slot tile `st`: the effective row in float, the canonical position, the tile's origin and pass-through rows
     auto write_tables = [&] (int st, int row) {
         const int rows_valid = min (32, g.P - st * 32);
-        const Pos p0 = locate<INTERP> (a, segs, a.n_begin + st * 32);
-        const Pos p = locate<INTERP> (a, segs, a.n_begin + st * 32 + min (row, rows_valid - 1));
+        const Pos p0 = slot_pos (st * 32);
+        const Pos p = slot_pos (st * 32 + min (row, rows_valid - 1));
         const float *h0 = a.bank + (size_t) p.fi * a.T;
         __shared__ unsigned int s_pass;
         if (row == 0) {
@@ -268,7 +291,7 @@ void i8_stage_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g, I8Geom q)
             // nearest-filter mode without a low-pass: the slots whose position falls exactly on an input sample (one bit per row;
             // their sample index is the row's canonical ip + fi / F)
             if (!INTERP && !a.lowpass && tid < rows_valid) {
-                const Pos pq = locate<INTERP> (a, segs, a.n_begin + st * 32 + tid);
+                const Pos pq = slot_pos (st * 32 + tid);
                 if ((pq.fi % a.F) == 0) atomicOr (&s_pass, 1u << tid);
             }
             __syncthreads ();
@@ -302,8 +325,8 @@ void i8_stage_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g, I8Geom q)
         const int st = variant / q.g, jr = variant - st * q.g;
         if (jr == 0 && (q.tr == 32 ? st : 2 * st + (row >> 5)) < g.slot_tiles) write_tables (q.tr == 32 ? st : 2 * st + (row >> 5), row & 31);
         const int rows_valid = min (q.tr, g.P - st * q.tr);
-        const Pos p0 = locate<INTERP> (a, segs, a.n_begin + st * q.tr);
-        const Pos p = locate<INTERP> (a, segs, a.n_begin + st * q.tr + min (row, rows_valid - 1));
+        const Pos p0 = slot_pos (st * q.tr);
+        const Pos p = slot_pos (st * q.tr + min (row, rows_valid - 1));
         const float *h0 = a.bank + (size_t) p.fi * a.T;
         // K column 0 of this tile family sits r frames before the first slot's window (the start of its 4-frame block)
         const int r = max (p0.ip - a.T / 2 + 1 + jr * g.Q + I8_PADF, 0) & 3;
@@ -490,7 +513,7 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
             if (!f_live) return;
             // (readfirstlane: the table entry arrives in a vector register, and a resource built from it would make every load a
             // waterfall loop; the value is the same in all lanes)
-            const int la = max (__builtin_amdgcn_readfirstlane (g.tile_w0 [3 * st]) + j0 * g.Q + I8_PADF, 0);
+            const int la = max (__builtin_amdgcn_readfirstlane (g.tile_w0 [3 * st]) + g.w_shift + j0 * g.Q + I8_PADF, 0);
             // the tile's exponent block and its first 4-frame block inside that block's own planes
             const int eb = j0 / q.eb_periods;
             unsigned int skip = (unsigned int) max ((la >> 2) - q.b0 - eb * q.eb_step, 0) * (unsigned int)(CG * 4);
@@ -500,7 +523,7 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
 #pragma unroll
             for (int u = 0; u < NB; ++u) bdel [u] = (unsigned int)((j0 + bper [u]) / q.eb_periods - eb) * eb_hop;
             fa_bytes = (unsigned int) nchunks * 4096u;
-            fa_base = q.a_planes + (size_t)(st * q.g + j0 % q.g) * fa_bytes;
+            fa_base = q.a_planes + (size_t)(st * q.g + (j0 + q.jr_rot) % q.g) * fa_bytes;
         };
         auto fetch_next = [&] (auto set_tag) {
             constexpr int SET = decltype (set_tag)::value;
@@ -582,7 +605,7 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
         // chunks in which some row of this tile has a non-zero most significant digit (the few around the rows' centres: taps
         // fall off as 1 / distance): everywhere else the four products with that digit plane are exactly zero and not issued
         // (and likewise the second digit plane — zero in the window's tails, where the taps are below 2^-15: its four products too)
-        unsigned long long top = q.a_masks [(st * q.g + j0 % q.g) * 32 + (lane & 31)], sec = q.a_masks [q.mask_words + (st * q.g + j0 % q.g) * 32 + (lane & 31)];
+        unsigned long long top = q.a_masks [(st * q.g + (j0 + q.jr_rot) % q.g) * 32 + (lane & 31)], sec = q.a_masks [q.mask_words + (st * q.g + (j0 + q.jr_rot) % q.g) * 32 + (lane & 31)];
 #pragma unroll
         for (int off = 1; off < 32; off <<= 1) { top |= __shfl_xor (top, off); sec |= __shfl_xor (sec, off); }
         const unsigned int top_lo = __builtin_amdgcn_readfirstlane ((unsigned int) top), top_hi = __builtin_amdgcn_readfirstlane ((unsigned int)(top >> 32));
@@ -623,6 +646,10 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
         const size_t left = (size_t)(a.n_end - n_tile) * CG * 4;
         const __amdgpu_buffer_rsrc_t rs_out = make_rsrc (a.out + (size_t) n_tile * CG, left > 0xffffff00ull ? 0xffffff00u : (unsigned int) left);
         const unsigned int pass_rows = PASS ? (unsigned int) g.tile_w0 [3 * st + 1] : 0u;
+        // (a launch on rows kept across calls starts mid-period: the slots of its first period in front of its first output are not stored.
+        // They sit in the first CG columns of the first matrix wave of the launch's first period group: a scalar bound — 0 everywhere else —
+        // and a test on the lane's own number, nothing kept live through the tile loop)
+        const int lo = a.n_skip != 0 && j0 == 0 && wave == 0 ? a.n_skip - st * 32 : 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i_const = (r & 3) + 8 * (r >> 2);      // compile-time part of the slot
@@ -633,9 +660,9 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
             if constexpr (PASS) {
                 // nearest-filter mode, the position falls exactly on an input sample: the reference copies it (resampler.c:1141-1142)
                 if ((pass_rows >> i) & 1u)
-                    y = load_frame (a, INT_MIN, g.canon_ip [st * 32 + i] + g.canon_fi [st * 32 + i] / a.F + (j0 + jl * q.g) * g.Q, c);
+                    y = load_frame (a, INT_MIN, g.canon_ip [st * 32 + i] + g.w_shift + g.canon_fi [st * 32 + i] / a.F + (j0 + jl * q.g) * g.Q, c);
             }
-            if (col_live && i < rows_valid)                  // (frames at or past n_end: out of the resource's range, dropped)
+            if (col_live && i < rows_valid && (i >= lo || (lane & 31) >= CG))      // (frames at or past n_end: out of the resource's range, dropped)
                 __builtin_amdgcn_raw_buffer_store_b32 (__float_as_uint (y), rs_out, (int)(out_off + (unsigned int)(i_const * CG) * 4u), 0, 0);
         }
     }
@@ -737,7 +764,7 @@ void fir_i8_dma_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
             for (f_within += wgs_per_xcd; f_within < tiles_per_xcd; f_within += wgs_per_xcd)
                 if (tile_at (f_within, st, j0)) { f_live = true; break; }
             if (!f_live) return;
-            const int la = max (tile_w0 [3 * st] + j0 * g.Q + I8_PADF, 0);
+            const int la = max (tile_w0 [3 * st] + g.w_shift + j0 * g.Q + I8_PADF, 0);
             const int eb = j0 / q.eb_periods;
             unsigned int skip = (unsigned int) max ((la >> 2) - q.b0 - eb * q.eb_step, 0) * (unsigned int)(CG * 4);
             if (skip > q.eb_plane_bytes) skip = q.eb_plane_bytes;
@@ -745,7 +772,7 @@ void fir_i8_dma_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
             fb_base = q.x_planes + from; fb_bytes = (unsigned int) min (q.x_bytes - from, (size_t) 0xfffffff0u);
             bdel = (unsigned int)((j0 + m * q.g) / q.eb_periods - eb) * eb_hop;
             fa_bytes = (unsigned int) nchunks * 4096u;
-            fa_base = q.a_planes + (size_t)(st * q.g + j0 % q.g) * fa_bytes;
+            fa_base = q.a_planes + (size_t)(st * q.g + (j0 + q.jr_rot) % q.g) * fa_bytes;
         };
         // the next chunk of the workgroup's stream -> LDS buffer `buf`: 5 DMA instructions of this wave, or none past the end
         auto issue = [&] (int buf) -> bool {
@@ -811,7 +838,7 @@ void fir_i8_dma_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
         // chunks in which some row of this tile has a non-zero most significant digit (the few around the rows' centres: taps
         // fall off as 1 / distance): everywhere else the four products with that digit plane are exactly zero and not issued
         // (and likewise the second digit plane — zero in the window's tails, where the taps are below 2^-15: its four products too)
-        unsigned long long top = q.a_masks [(st * q.g + j0 % q.g) * 32 + (lane & 31)], sec = q.a_masks [q.mask_words + (st * q.g + j0 % q.g) * 32 + (lane & 31)];
+        unsigned long long top = q.a_masks [(st * q.g + (j0 + q.jr_rot) % q.g) * 32 + (lane & 31)], sec = q.a_masks [q.mask_words + (st * q.g + (j0 + q.jr_rot) % q.g) * 32 + (lane & 31)];
 #pragma unroll
         for (int off = 1; off < 32; off <<= 1) { top |= __shfl_xor (top, off); sec |= __shfl_xor (sec, off); }
         const unsigned int top_lo = __builtin_amdgcn_readfirstlane ((unsigned int) top), top_hi = __builtin_amdgcn_readfirstlane ((unsigned int)(top >> 32));
@@ -854,6 +881,10 @@ void fir_i8_dma_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
         const size_t left = (size_t)(a.n_end - n_tile) * CG * 4;
         const __amdgpu_buffer_rsrc_t rs_out = make_rsrc (a.out + (size_t) n_tile * CG, left > 0xffffff00ull ? 0xffffff00u : (unsigned int) left);
         const unsigned int pass_rows = PASS ? (unsigned int) g.tile_w0 [3 * st + 1] : 0u;
+        // (a launch on rows kept across calls starts mid-period: the slots of its first period in front of its first output are not stored.
+        // They sit in the first CG columns of the first matrix wave of the launch's first period group: a scalar bound — 0 everywhere else —
+        // and a test on the lane's own number, nothing kept live through the tile loop)
+        const int lo = a.n_skip != 0 && j0 == 0 && wave == 0 ? a.n_skip - st * 32 : 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i_const = (r & 3) + 8 * (r >> 2);      // compile-time part of the slot
@@ -861,9 +892,9 @@ void fir_i8_dma_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
             const int i = i_const + 4 * (lane >> 5);
             if constexpr (PASS) {
                 if ((pass_rows >> i) & 1u)
-                    y = load_frame (a, INT_MIN, g.canon_ip [st * 32 + i] + g.canon_fi [st * 32 + i] / a.F + (j0 + jl * q.g) * g.Q, c);
+                    y = load_frame (a, INT_MIN, g.canon_ip [st * 32 + i] + g.w_shift + g.canon_fi [st * 32 + i] / a.F + (j0 + jl * q.g) * g.Q, c);
             }
-            if (i < rows_valid)                              // (frames at or past n_end: out of the resource's range, dropped)
+            if (i < rows_valid && (i >= lo || (lane & 31) >= CG))                  // (frames at or past n_end: out of the resource's range, dropped)
                 __builtin_amdgcn_raw_buffer_store_b32 (__float_as_uint (y), rs_out, (int)(out_off + (unsigned int)(i_const * CG) * 4u), 0, 0);
         }
     }
@@ -997,16 +1028,16 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
         ++f_seg;
         segment (f_seg, within, c0, f_c1);
         tile_of (within, st, j0);
-        const int la = max (tile_w0 [3 * (2 * st)] + j0 * g.Q + I8_PADF, 0);     // (the origin of the pair's first 32-row slot tile)
+        const int la = max (tile_w0 [3 * (2 * st)] + g.w_shift + j0 * g.Q + I8_PADF, 0);     // (the origin of the pair's first 32-row slot tile)
         const int eb = j0 / q.eb_periods;
         unsigned int skip = (unsigned int) max ((la >> 2) - q.b0 - eb * q.eb_step, 0) * (unsigned int)(CG * 4);
         if (skip > q.eb_plane_bytes) skip = q.eb_plane_bytes;
         const size_t from = (size_t) eb * x_total + skip;
         f_rb = make_rsrc (q.x_planes + from, (unsigned int) min (q.x_bytes - from, (size_t) 0xfffffff0u));
         const unsigned int fa_bytes = (unsigned int) nsub * A_STEP;
-        f_ra = make_rsrc (q.a_planes + (size_t)(st * q.g + j0 % q.g) * fa_bytes, fa_bytes);
+        f_ra = make_rsrc (q.a_planes + (size_t)(st * q.g + (j0 + q.jr_rot) % q.g) * fa_bytes, fa_bytes);
         {
-            const __attribute__ ((address_space (4))) unsigned long long *tm = (const __attribute__ ((address_space (4))) unsigned long long *) q.tile_masks + (st * q.g + j0 % q.g) * 2;
+            const __attribute__ ((address_space (4))) unsigned long long *tm = (const __attribute__ ((address_space (4))) unsigned long long *) q.tile_masks + (st * q.g + (j0 + q.jr_rot) % q.g) * 2;
             f_live [0] = tm [0] | tm [1];
             f_live [1] = tm [q.tiles * q.g * 2] | tm [q.tiles * q.g * 2 + 1];
         }
@@ -1102,7 +1133,7 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
         // (through the scalar cache, like the tile table)
         unsigned long long top [2], sec [2];                  // (sec: the same for the second digit plane — zero in the window's tails)
         {
-            const __attribute__ ((address_space (4))) unsigned long long *tm = (const __attribute__ ((address_space (4))) unsigned long long *) q.tile_masks + (st * q.g + j0 % q.g) * 2;
+            const __attribute__ ((address_space (4))) unsigned long long *tm = (const __attribute__ ((address_space (4))) unsigned long long *) q.tile_masks + (st * q.g + (j0 + q.jr_rot) % q.g) * 2;
             top [0] = tm [0]; top [1] = tm [1];
             sec [0] = tm [q.tiles * q.g * 2]; sec [1] = tm [q.tiles * q.g * 2 + 1];
         }
@@ -1273,7 +1304,7 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
                     const int i = h * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     // nearest-filter mode, the position falls exactly on an input sample: the reference copies it (resampler.c:1141-1142)
                     if ((pass_rows >> (i & 31)) & 1u)
-                        y [h] [r] = load_frame (a, INT_MIN, g.canon_ip [st * 64 + i] + g.canon_fi [st * 64 + i] / a.F + (j0 + jl * q.g) * g.Q, c);
+                        y [h] [r] = load_frame (a, INT_MIN, g.canon_ip [st * 64 + i] + g.w_shift + g.canon_fi [st * 64 + i] / a.F + (j0 + jl * q.g) * g.Q, c);
                 }
             }
         }
@@ -1286,6 +1317,9 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
         TR (11);
         {
             const int qm = lane & 3;                          // this lane's place in its quad = the slot it ends up with
+            // (a launch on rows kept across calls starts mid-period: the slots of its first period in front of its first output are not stored —
+            // the first CG columns of the first wave of the launch's first period group: a scalar bound and a test on the lane's own number)
+            const int lo = a.n_skip != 0 && j0 == 0 && wave == 0 ? a.n_skip - st * 64 : 0;
             const unsigned int q_off = (unsigned int)((jl * q.g * g.P + 4 * (lane >> 5) + qm) * CG + (c & ~3)) * 4u;
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -1311,7 +1345,7 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
                     const int i_const = h * 32 + 8 * rb;      // compile-time part of the slot
                     const int i = i_const + 4 * (lane >> 5) + qm;
                     // (a slot past the period goes out of the resource's range, as frames at or past n_end do, and is dropped)
-                    const unsigned int off = i < rows_valid ? q_off + (unsigned int)(i_const * CG) * 4u : 0xfffffff0u;
+                    const unsigned int off = i < rows_valid && (i >= lo || (lane & 31) >= CG) ? q_off + (unsigned int)(i_const * CG) * 4u : 0xfffffff0u;
                     __builtin_amdgcn_raw_buffer_store_b128 (v, rs_out, (int) off, 0, 0);
                 }
         }
@@ -1353,7 +1387,7 @@ static size_t i8_layout (const ArtFirArgs *a, const MfmaGeom &g, int cgt, I8Geom
     // (outputs != 0: sizing a call's buffer before its launches are cut — any launch of the call has at most this many periods)
     const unsigned int total = outputs ? outputs + (unsigned int) g.P : a->n_end - a->n_begin, periods = (total + g.P - 1) / g.P;
     const int gg = (g.Q % 4 == 0) ? 1 : (g.Q % 2 == 0) ? 2 : 4;
-    q.tr = 32; q.cols = I8_COLS;
+    q.tr = 32; q.cols = I8_COLS; q.rows_cached = 0; q.jr_rot = 0; q.rows_table = 0; q.tb_base = 0.0; q.tb_lin = q.tb_w = 0; q.tb_n0 = 0u;
     if (artfir_i8_slab_enabled () && cgt >= 4) {
         // slabs where the launch has enough of them (decided from this context's own columns: every fixed-point kernel leaves the
         // same bits, so a shard need not decide as its stream would)
@@ -1425,31 +1459,242 @@ size_t artfir_i8_bytes (const ArtFirArgs *a, const MfmaGeom &g, int cgt, unsigne
     return i8_layout (a, g, cgt, q, nullptr, outputs ? outputs : 1u);
 }
 
-int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGeom &g, int cgt, unsigned int roll_blocks, hipStream_t st)
+// ---------------------------------------------------------------------------------------------------
+// The rows across calls.  A launch's filter rows — digit planes, masks, the stand-by's f32 tables — depend on the stream's ratio and on
+// where in its period the launch starts, not on its samples: until round 5 every launch rebuilt them (640 workgroups of a latency
+// chain — two position evaluations, the bank's rows, the blend: 11.5 us in front of every call's main kernel, the long pole of the peak
+// pass at every call size).  A context now keeps them (ArtFirArgs.rows on the device, an ArtRowsCache on the host):
+//   * the CANONICAL PERIOD: the slot positions (window index, filter index, phase) of the first period of the stream's first fixed-point
+//     launch, evaluated on the host with the reference's position arithmetic (host_locate = locate ()).  Every later launch looks its
+//     first output up among them: it is slot s of that period, a whole number of frames w further on.  Rows are only ever built FOR THE
+//     CANONICAL PERIOD, from this table (uploaded; the row workgroups read it instead of evaluating positions): they are a function of the
+//     table alone, whichever launch builds them, whatever its tile height — so the kernel forms still leave the same bits;
+//   * a launch runs as if it started s outputs earlier, on the canonical period's first slot: tiles anchored there, the s slots in front of
+//     its first output computed and not stored (ArtFirArgs.n_skip), output indices carried one period higher so that the virtual start is not
+//     negative, and w added to the table's linear indices (MfmaGeom.w_shift);
+//   * the fixed-point tiles start their K columns on 4-frame blocks, the offset inside the block absorbed by the rows (one variant per
+//     period residue): a SET of rows built at shift w_b serves the launches whose w - w_b is a multiple of 4 / g frames — residue jr of the
+//     launch then stages the variant (jr + rot) mod g, rot Q = w - w_b (mod 4) (I8Geom.jr_rot) — and there are at most 4 / g sets;
+//   * interpolating streams accept a first output whose phase is within 1e-6 filter steps of its canonical slot's (the blend moves by
+//     < 4e-9 relative; the streaming kernels already share a row between periods 2e-6 apart); nearest-filter streams must round to the
+//     canonical filter index in every slot; a stream that left the lattice (advance, reset to another phase, another ratio) starts a new
+//     canonical period.  ARTAMD_ROWS_CACHE=0: off — every launch builds its rows from its own positions, as before.
+// ---------------------------------------------------------------------------------------------------
+struct ArtRowsCache {
+    // the canonical period
+    const void *bank; int T, F, interp, P, Q; double ratio;
+    int canon_valid, cap;
+    double *c_ph; int *c_ip, *c_fi;       // [cap >= P]
+    // the sets built for it
+    int lowpass, tr, ktot, tiles, g, slot_tiles, ktot32; size_t set_bytes;
+    int nsets, victim, valid [4], w_build [4];
+    double c_base; int c_lin; unsigned int c_n0;              // ... as the device evaluates it: epoch offset, ring-to-linear shift, first output
+};
+
+namespace {
+
+struct HostPos { int ip, fi; double ph; };
+// locate () on the host: the reference's position arithmetic (compiled, like the device's, without contraction)
+static HostPos host_locate (const ArtFirArgs *a, const ArtSegTable *segs, unsigned int n)
+{
+    int e = 0;
+    while (e + 1 < segs->count && segs->first [e + 1] <= n) ++e;
+    const double step = n ? (double) n / a->ratio : 0.0;
+    const double off = segs->base [e] + step;
+    const double whole = floor (off);
+    double fr = off - whole;
+    fr = fr * (double) a->F;
+    HostPos p;
+    p.ph = fr;
+    p.fi = a->interpolate ? (int) floor (fr) : (int) floor (fr + 0.5);
+    p.ip = (int) whole + segs->lin_base [e];
+    return p;
+}
+
+struct RowsSetPtrs {
+    unsigned long long *a_masks, *tile_masks; unsigned char *a_planes;
+    float *eff; double *canon_frac; int *canon_ip, *canon_fi, *tile_w0;
+};
+static size_t rows_set_layout (const MfmaGeom &g, const I8Geom &q, char *base, RowsSetPtrs *out)
+{
+    size_t off = 0;
+    auto take = [&] (size_t bytes) { const size_t at = off; off = (off + bytes + 255) & ~(size_t) 255; return at; };
+    const size_t rows32 = (size_t) g.slot_tiles * 32;
+    const size_t o_masks = take (2 * (size_t) q.tiles * q.g * q.tr * 8), o_tm = take (2 * (size_t) q.tiles * q.g * (q.tr / 32) * 8);
+    const size_t o_planes = take ((size_t) q.tiles * q.g * (q.ktot / I8_KC) * (size_t)(q.tr * 128));
+    const size_t o_eff = take (rows32 * g.ktot * sizeof (float)), o_frac = take (rows32 * sizeof (double));
+    const size_t o_ip = take (rows32 * sizeof (int)), o_fi = take (rows32 * sizeof (int)), o_w0 = take ((size_t) 3 * g.slot_tiles * sizeof (int));
+    if (out && base) {
+        out->a_masks = (unsigned long long *)(base + o_masks); out->tile_masks = (unsigned long long *)(base + o_tm); out->a_planes = (unsigned char *)(base + o_planes);
+        out->eff = (float *)(base + o_eff); out->canon_frac = (double *)(base + o_frac); out->canon_ip = (int *)(base + o_ip); out->canon_fi = (int *)(base + o_fi);
+        out->tile_w0 = (int *)(base + o_w0);
+    }
+    return off;
+}
+
+static bool rows_cache_enabled ()
+{
+    static const bool on = [] { const char *e = getenv ("ARTAMD_ROWS_CACHE"); return !(e && *e == '0'); } ();
+    return on;
+}
+
+} // namespace
+
+extern "C" {
+size_t arthip_fir_rows_cache_bytes (void) { return sizeof (ArtRowsCache); }
+void arthip_fir_rows_cache_reset (void *cache)               // (the device buffer was replaced: no set in it is valid; the canonical period stays)
+{
+    ArtRowsCache *rc = (ArtRowsCache *) cache;
+    if (rc) for (int k = 0; k < 4; ++k) rc->valid [k] = 0;
+}
+void arthip_fir_rows_cache_free (void *cache)
+{
+    ArtRowsCache *rc = (ArtRowsCache *) cache;
+    if (rc) {
+        free (rc->c_ph); free (rc->c_ip); free (rc->c_fi); rc->c_ph = nullptr; rc->c_ip = rc->c_fi = nullptr; rc->cap = 0; rc->canon_valid = 0;
+    }
+}
+}
+
+// device bytes the rows of a call of this shape want across calls (all sets; 0: no cache for it)
+size_t artfir_i8_rows_bytes (const ArtFirArgs *a, const MfmaGeom &g, int cgt, unsigned int outputs)
+{
+    I8Geom q;
+    if (!rows_cache_enabled () || !i8_layout (a, g, cgt, q, nullptr, outputs ? outputs : 1u)) return 0;
+    // (4 / g sets: one per place of the windows inside their 4-frame blocks that the period residues do not cover)
+    return (size_t)(4 / q.g) * (rows_set_layout (g, q, nullptr, nullptr) + 4096);
+}
+
+int artfir_i8_launch (const ArtFirArgs *a_in, const ArtSegTable *segs, const MfmaGeom &g_in, int cgt, unsigned int roll_blocks, hipStream_t st)
 {
     static std::atomic<int> launches {0};
     I8Geom q;
-    if (!a->planes) return 0;
-    const size_t need = i8_layout (a, g, cgt, q, (char *) a->planes);
-    if (!need || need > a->planes_bytes) return 0;
+    if (!a_in->planes) return 0;
+    ArtFirArgs a_v = *a_in; const ArtFirArgs *a = &a_v;
+    MfmaGeom g = g_in;
+
+    // ---- the launch's place in the canonical period
+    ArtRowsCache *rc = rows_cache_enabled () && a_in->rows ? (ArtRowsCache *) a_in->rows_cache : nullptr;
+    const HostPos pos0 = host_locate (a_in, segs, a_in->n_begin);
+    int slot0 = 0, w = 0;
+    if (rc) {
+        const bool same = rc->canon_valid && rc->bank == (const void *) a_in->bank && rc->T == a_in->T && rc->F == a_in->F && rc->interp == a_in->interpolate &&
+                          rc->P == g.P && rc->Q == g.Q && rc->ratio == a_in->ratio;
+        if (!same) rc->canon_valid = 0;
+        if (rc->cap < g.P) {
+            free (rc->c_ph); free (rc->c_ip); free (rc->c_fi);
+            rc->cap = g.P; rc->canon_valid = 0;
+            rc->c_ph = (double *) malloc (sizeof (double) * (size_t) rc->cap); rc->c_ip = (int *) malloc (sizeof (int) * (size_t) rc->cap); rc->c_fi = (int *) malloc (sizeof (int) * (size_t) rc->cap);
+            if (!rc->c_ph || !rc->c_ip || !rc->c_fi) { arthip_fir_rows_cache_free (rc); rc = nullptr; }
+        }
+    }
+    if (rc && rc->canon_valid) {
+        const double tol = 1e-6, F = (double) a_in->F;
+        bool found = false;
+        for (int s = 0; s < g.P && !found; ++s) {
+            double d = fabs (rc->c_ph [s] - pos0.ph);
+            if (d > 0.5 * F) d = F - d;
+            if (d > tol) continue;
+            // (positions in frames: the same lattice point up to the tolerance, a whole number of frames apart)
+            const double w_exact = ((double) pos0.ip + pos0.ph / F) - ((double) rc->c_ip [s] + rc->c_ph [s] / F);
+            const int wr = (int) floor (w_exact + 0.5);
+            if (fabs (w_exact - (double) wr) > 1e-6) break;
+            found = true; slot0 = s; w = wr;
+        }
+        if (found && !a_in->interpolate)                      // nearest filter: the canonical rounded filter index in every slot, from this launch's own positions
+            for (int t = 0; t < g.P && found; ++t) {              // (its first P outputs are slots s, s + 1, ... of the canonical period, wrapping into the next)
+                const unsigned int n = a_in->n_begin + (unsigned int) t;
+                if (n >= a_in->n_end) break;
+                found = host_locate (a_in, segs, n).fi == rc->c_fi [(slot0 + t) % g.P];
+            }
+        if (!found) rc->canon_valid = 0;
+    }
+    if (rc && !rc->canon_valid) {                             // a new canonical period: this launch's first
+        {   // (the epoch of the launch's first output, carried through the whole period even where the ring rewinds inside it: the same lattice,
+            // and constants the row workgroups can evaluate themselves)
+            int e = 0;
+            while (e + 1 < segs->count && segs->first [e + 1] <= a_in->n_begin) ++e;
+            rc->c_base = segs->base [e]; rc->c_lin = segs->lin_base [e]; rc->c_n0 = a_in->n_begin;
+            ArtSegTable one; one.count = 1; one.lin_floor = segs->lin_floor; one.first [0] = 0u; one.lin_base [0] = rc->c_lin; one.base [0] = rc->c_base;
+            for (int i = 0; i < g.P; ++i) { const HostPos p = host_locate (a_in, &one, rc->c_n0 + (unsigned int) i); rc->c_ph [i] = p.ph; rc->c_ip [i] = p.ip; rc->c_fi [i] = p.fi; }
+        }
+        rc->bank = (const void *) a_in->bank; rc->T = a_in->T; rc->F = a_in->F; rc->interp = a_in->interpolate; rc->P = g.P; rc->Q = g.Q; rc->ratio = a_in->ratio;
+        rc->canon_valid = 1; slot0 = 0; w = 0;
+        for (int k = 0; k < 4; ++k) rc->valid [k] = 0;
+    }
+    // (the virtual start's window must not begin in front of the zero frames the planes hold before linear frame 0)
+    if (rc && rc->c_ip [0] + w - a_in->T / 2 + 1 + I8_PADF < 0) rc = nullptr;
+    if (rc) {
+        a_v.n_begin = a_in->n_begin + (unsigned int)(g.P - slot0); a_v.n_end = a_in->n_end + (unsigned int) g.P;
+        a_v.out = a_in->out - (size_t) g.P * a_in->C; a_v.n_skip = slot0;
+    }
+    size_t need = i8_layout (a, g, cgt, q, (char *) a_in->planes);
+    if (rc && (!need || need > a_in->planes_bytes)) {         // (the partial period in front does not fit: as before)
+        rc = nullptr; a_v = *a_in;
+        need = i8_layout (a, g, cgt, q, (char *) a_in->planes);
+    }
+    if (!need || need > a_in->planes_bytes) return 0;
+
+    // ---- the set of rows that serves it, or that it builds
+    bool build_from_table = false;
+    int set = -1;
+    if (rc) {
+        const size_t set_bytes = rows_set_layout (g, q, nullptr, nullptr);
+        const int nsets = 4 / q.g;
+        const bool same = rc->lowpass == a_in->lowpass && rc->tr == q.tr && rc->ktot == q.ktot && rc->tiles == q.tiles && rc->g == q.g && rc->slot_tiles == g.slot_tiles &&
+                          rc->ktot32 == g.ktot && rc->set_bytes == set_bytes && rc->nsets == nsets;
+        if ((size_t) nsets * (set_bytes + 4096) > a_in->rows_bytes) {          // (no room: this launch alone, in its own buffers, from its own positions)
+            rc = nullptr; a_v = *a_in;
+            need = i8_layout (a, g, cgt, q, (char *) a_in->planes);
+            if (!need || need > a_in->planes_bytes) return 0;
+        }
+        else {
+            if (!same) {
+                for (int k = 0; k < 4; ++k) rc->valid [k] = 0;
+                rc->lowpass = a_in->lowpass; rc->tr = q.tr; rc->ktot = q.ktot; rc->tiles = q.tiles; rc->g = q.g; rc->slot_tiles = g.slot_tiles; rc->ktot32 = g.ktot;
+                rc->set_bytes = set_bytes; rc->nsets = nsets; rc->victim = 0;
+            }
+            const int step = 4 / q.g;
+            for (int k = 0; k < nsets && set < 0; ++k) {
+                if (!rc->valid [k] || ((w - rc->w_build [k]) % step) != 0) continue;
+                const int dw = w - rc->w_build [k];
+                for (int r = 0; r < q.g; ++r) if ((((long long) r * g.Q - dw) & 3) == 0) { set = k; g.w_shift = dw; q.jr_rot = r; q.rows_cached = 1; break; }
+            }
+            if (set < 0) {                                    // build: an empty set, else the next victim in turn
+                for (int k = 0; k < nsets && set < 0; ++k) if (!rc->valid [k]) set = k;
+                if (set < 0) { set = rc->victim; rc->victim = (rc->victim + 1) % nsets; }
+                rc->valid [set] = 1; rc->w_build [set] = w;
+                g.w_shift = 0; q.jr_rot = 0; q.rows_cached = 0; build_from_table = true;
+            }
+            RowsSetPtrs sp;
+            rows_set_layout (g, q, (char *) a_in->rows + (size_t) set * (set_bytes + 4096), &sp);
+            q.a_masks = sp.a_masks; q.tile_masks = sp.tile_masks; q.a_planes = sp.a_planes;
+            g.eff = sp.eff; g.canon_frac = sp.canon_frac; g.canon_ip = sp.canon_ip; g.canon_fi = sp.canon_fi; g.tile_w0 = sp.tile_w0;
+        }
+    }
+    q.rows_table = build_from_table ? 1 : 0;
+    if (build_from_table) { q.tb_base = rc->c_base; q.tb_lin = rc->c_lin; q.tb_n0 = rc->c_n0; q.tb_w = w; }
+    {   static const bool trace = [] { const char *e = getenv ("ARTAMD_ROWS_TRACE"); return e && *e == '1'; } ();
+        if (trace) fprintf (stderr, "rows: launch n %u..%u  cache %s  slot0 %d  w %d  set %d  %s  w_shift %d rot %d  tr %d  ph0 %.12f ip0 %d\n", a_in->n_begin, a_in->n_end,
+                            rc ? "on" : "off", slot0, w, set, rc ? (build_from_table ? "BUILD" : "hit") : "-", g.w_shift, q.jr_rot, q.tr, pos0.ph, pos0.ip);
+    }
+    if (a_in->rows_masks_out) *a_in->rows_masks_out = (void *) q.a_masks;
+
     int ep = ++launches;
     if (ep <= 0) { launches = 1; ep = 1; }                             // (the flag word is zero when the buffer is allocated)
     q.epoch = ep;
     static const bool dma = [] { const char *e = getenv ("ARTAMD_I8_DMA"); return !(e && *e == '0'); } ();
     if (a->fixed_out) { a->fixed_out [0] = ep; a->fixed_out [1] = q.tiles * q.g * q.tr; a->fixed_out [2] = q.ktot / I8_KC; a->fixed_out [3] = q.tr == 64 ? 3 : (dma && cgt >= 4) ? 2 : 1; }
 
-    {   // block of the launch's first window start: the reference's position arithmetic for output n_begin (as locate ())
-        int e = 0;
-        while (e + 1 < segs->count && segs->first [e + 1] <= a->n_begin) ++e;
-        const double step = a->n_begin ? (double) a->n_begin / a->ratio : 0.0;
-        const double off = segs->base [e] + step;
-        const int ip = (int) floor (off) + segs->lin_base [e];
+    {   // block of the first tile's window start: the launch's first output's position (the reference's arithmetic, host_locate), or the
+        // canonical period's first slot carried to this launch
+        const int ip = rc ? rc->c_ip [0] + w : pos0.ip;
         const int la = ip - a->T / 2 + 1 + I8_PADF;
         q.b0 = (la > 0 ? la : 0) >> 2;
     }
     const unsigned int x_wgs = (unsigned int)(q.ebs * (a->C / q.cgrp) * q.slices);
-    q.rows_cached = 0;
-    const dim3 pgrid (x_wgs + (q.rows_cached ? 0u : (unsigned int)(q.tiles * q.g * q.tr))), xgrid (x_wgs + (unsigned int)((q.tiles * q.g * (q.tr / 32) + I8_STAGE_THREADS - 1) / I8_STAGE_THREADS));
+    const dim3 pgrid (x_wgs + (q.rows_cached ? 0u : (unsigned int)(q.tiles * q.g * q.tr))),
+               xgrid (x_wgs + (q.rows_cached ? 0u : (unsigned int)((q.tiles * q.g * (q.tr / 32) + I8_STAGE_THREADS - 1) / I8_STAGE_THREADS)));
     if (a->interpolate) {
         hipLaunchKernelGGL ((i8_stage_kernel<true, true>), pgrid, dim3 (I8_STAGE_THREADS), 0, st, *a, *segs, g, q);
         hipLaunchKernelGGL ((i8_stage_kernel<true, false>), xgrid, dim3 (I8_STAGE_THREADS), 0, st, *a, *segs, g, q);

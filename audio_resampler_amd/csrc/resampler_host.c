@@ -68,6 +68,7 @@ struct artamd_resampler {
     void *d_scratch; size_t scratch_cap;     /* MFMA path: effective rows + canonical positions of one launch */
     void *d_pad; size_t pad_cap;             /* matrix path of a channel count the kernels are not compiled for: the groups' padded buffers (arthip_fir_pad_bytes) */
     void *d_planes; size_t planes_cap;       /* fixed-point matrix kernel: digit planes of one launch (flag word first) */
+    void *d_rows; size_t rows_cap; void *rows_cache; void *last_masks;      /* ... its filter rows, kept across calls (art_internal.h), and where the last launch's row masks live */
     void *d_split; size_t split_cap;         /* K-split streaming kernel: arrival counters (zero at rest) + partial sums of one launch */
     int last_fixed [4];                      /* its last launch of the last call: flag value (0: none), mask words, chunks per tile, kernel form (art_hip.h) */
     unsigned int *d_fix; size_t fix_cap;    /* [0] per-launch, [1] running count of outputs the matrix kernels evaluated off-pattern */
@@ -683,7 +684,7 @@ void resampleFree (Resample *cxt)
         arthip_event_destroy (hip->ev_parent);
         free (hip->shards); free (hip->shard_first); free (hip->ev_shard);
         bank_release (hip->bank); arthip_free (hip->d_hist [0]); arthip_free (hip->d_hist [1]);
-        arthip_free (hip->d_in); arthip_free (hip->d_out); arthip_free (hip->d_tmp); arthip_free (hip->d_fix); arthip_free (hip->d_scratch); arthip_free (hip->d_pad); arthip_free (hip->d_planes); arthip_free (hip->d_split); arthip_free (hip->d_patch); arthip_free (hip->d_batch);
+        arthip_free (hip->d_in); arthip_free (hip->d_out); arthip_free (hip->d_tmp); arthip_free (hip->d_fix); arthip_free (hip->d_scratch); arthip_free (hip->d_pad); arthip_free (hip->d_planes); arthip_free (hip->d_rows); if (hip->rows_cache) { arthip_fir_rows_cache_free (hip->rows_cache); free (hip->rows_cache); } arthip_free (hip->d_split); arthip_free (hip->d_patch); arthip_free (hip->d_batch);
         arthip_host_free (hip->h_in); arthip_host_free (hip->h_out);
         for (int i = 0; i < hip->ev_cap; ++i) arthip_event_destroy (hip->ev [i]);
         if (hip->own_stream) arthip_stream_destroy (hip->stream);
@@ -912,7 +913,7 @@ int resampleHipLastFixedPoint (Resample *cxt, double *pairsPerChunk)
     /* (the rows' masks of the first two digit planes, one after the other) */
     unsigned long long *masks = malloc (sizeof (unsigned long long) * (size_t)(words > 0 ? 2 * words : 1));
     arthip_d2h (&flag, hip->d_planes, sizeof (flag), hip->stream);
-    if (masks && words > 0) arthip_d2h (masks, (char *) hip->d_planes + ART_I8_HEAD_BYTES, sizeof (unsigned long long) * (size_t)(2 * words), hip->stream);
+    if (masks && words > 0) arthip_d2h (masks, hip->last_masks ? hip->last_masks : (void *)((char *) hip->d_planes + ART_I8_HEAD_BYTES), sizeof (unsigned long long) * (size_t)(2 * words), hip->stream);
     arthip_sync (hip->stream);
     if (pairsPerChunk && masks && words > 0 && chunks > 0) {
         double full [2] = { 0.0, 0.0 };
@@ -1240,6 +1241,15 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
                 if (hip->d_planes) arthip_zero (hip->d_planes, ART_I8_HEAD_BYTES, hip->stream);
             }
             a.planes = want ? hip->d_planes : NULL; a.planes_bytes = hip->d_planes ? hip->planes_cap : 0;
+            /* ... and its filter rows, which outlive the call: built by the first launch of a stream, looked up by the others */
+            const size_t rows_want = want ? arthip_fir_rows_bytes (&a, res.output_generated, hip->kernel_pref) : 0;
+            if (rows_want && !hip->rows_cache) hip->rows_cache = calloc (1, arthip_fir_rows_cache_bytes ());
+            if (rows_want > hip->rows_cap && hip->rows_cache) {
+                hip->d_rows = grow (hip->d_rows, &hip->rows_cap, rows_want);
+                arthip_fir_rows_cache_reset (hip->rows_cache);
+            }
+            if (rows_want && hip->d_rows && hip->rows_cache) { a.rows = hip->d_rows; a.rows_bytes = hip->rows_cap; a.rows_cache = hip->rows_cache; }
+            hip->last_masks = NULL; a.rows_masks_out = &hip->last_masks;
             /* calls of few tiles: room for the K-split kernel's partial sums (a grown buffer starts with its counters zeroed; the
              * old one is released behind the launches that used it: stream order) */
             const size_t split_want = want ? 0 : arthip_fir_split_bytes (&a, res.output_generated, hip->kernel_pref);
