@@ -118,6 +118,7 @@ def _bind(width):
         "resampleHipSetStream": (None, [RP, ptr]),
         "resampleHipSynchronize": (None, [RP]),
         "resampleHipSetKernel": (None, [RP, C.c_int]),
+        "resampleHipKeepRows": (None, [RP, C.c_int]),
         "resampleHipLastKernel": (C.c_int, [RP]),
         "resampleHipLastHandedBack": (C.c_uint, [RP]),
         "resampleHipLastFixedPoint": (C.c_int, [RP, C.POINTER(C.c_double)]),
@@ -259,6 +260,9 @@ def _bind(width):
 
         def set_kernel(self, which):
             self.L.resampleHipSetKernel(self.p, which)
+
+        def keep_rows(self, on):
+            self.L.resampleHipKeepRows(self.p, 1 if on else 0)
 
         def last_kernel(self):
             return self.L.resampleHipLastKernel(self.p)

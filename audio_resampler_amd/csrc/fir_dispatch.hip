@@ -108,6 +108,7 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
     hipStream_t st = (hipStream_t) stream;
 
     if (a->n_end <= a->n_begin) return ART_KERNEL_GENERAL;
+    artfir_rows_touch (a, segs);                              // (the canonical period of the rows kept across calls: every launch looks after it)
 
     if (a->segs_truncated && ((a->mode & 3) == ART_MODE_STRICT || !artfir_matrix_spans_segments (a, segs, kernel_pref))) return -2;
 

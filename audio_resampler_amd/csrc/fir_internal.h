@@ -10,4 +10,5 @@ int  artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pre
 size_t artfir_split_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref);           // fir_matrix.hip | fir_matrix64.hip (0)
 bool artfir_matrix_spans_segments (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref);  // fir_matrix.hip | fir_matrix64.hip (never)
 size_t artfir_planes_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref);
-size_t artfir_rows_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref);        // fir_matrix.hip | fir_matrix64.hip (0)                                                      // fir_matrix.hip | fir_matrix64.hip (0)
+size_t artfir_rows_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref);
+void artfir_rows_touch (const ArtFirArgs *a, const ArtSegTable *segs);                               // fir_matrix.hip | fir_matrix64.hip (nothing)        // fir_matrix.hip | fir_matrix64.hip (0)                                                      // fir_matrix.hip | fir_matrix64.hip (0)

@@ -45,16 +45,53 @@ namespace {
 // Grid (slot tile, row): canonical (ip, fi, frac) of the slot from the first period of the launch, and its
 // effective row g_i[k - shift_i] (lerp folded in, fp64, one rounding) laid out exactly as the main kernel
 // stages it: [row][ktot], zero outside the row's T taps.
+// the call's head, gathered by a whole grid: linear frame lin = index - MF_HEAD_PAD; history below H, input above
+__device__ __forceinline__ void gather_head (const ArtFirArgs &a, const MfmaGeom &g, int blocks, int me, int tid)
+{
+    const long total = (long) g.head_frames * a.C;
+    for (long e = (long) me * 256 + tid; e < total; e += (long) blocks * 256) {
+        const int f = (int)(e / a.C), c = (int)(e - (long) f * a.C), lin = f - MF_HEAD_PAD;
+        float v = 0.0f;
+        if (lin >= 0 && lin < a.H) v = a.hist [(size_t) lin * a.C + c];
+        else if (lin >= a.H && lin - a.H < a.in_frames) v = a.in [(size_t)(lin - a.H) * a.C + c];
+        g.head [e] = v;
+    }
+}
+// launches on rows kept across calls: the head is all a call still has to prepare
+__global__ __launch_bounds__ (256)
+void mfma_head_kernel (ArtFirArgs a, MfmaGeom g)
+{
+    gather_head (a, g, (int) gridDim.x, (int) blockIdx.x, (int) threadIdx.x);
+}
+
 template <bool INTERP>
 __global__ __launch_bounds__ (256)
-void mfma_prepare_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
+void mfma_prepare_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g, ArtRowsTable tb)
 {
     const int st = blockIdx.x, row = blockIdx.y, tid = threadIdx.x;
     const int R = g.tile_rows;
     const int rows_valid = min (R, g.P - st * R);
+    // slot k of the launch's first period by the reference's arithmetic — or, for rows kept across calls, slot k of the stream's CANONICAL
+    // period from its constants (what the host evaluated, to the bit: fir_matrix_i8.hip, "The rows across calls")
+    auto slot_pos = [&] (int k) -> Pos {
+        if (tb.on) {
+            const unsigned int n = tb.n0 + (unsigned int) k;
+            const double step = n ? (double) n / a.ratio : 0.0;
+            const double off = tb.base + step;
+            const double whole = floor (off);
+            Pos t;
+            double fr = off - whole;
+            fr = fr * (double) a.F;
+            if (INTERP) { t.fi = (int) floor (fr); t.frac = fr - (double) t.fi; }
+            else { t.fi = (int) floor (fr + 0.5); t.frac = 0.0; }
+            t.ip = (int) whole + tb.lin + tb.w;
+            return t;
+        }
+        return locate<INTERP> (a, segs, a.n_begin + (unsigned int) k);
+    };
     // every thread derives the two positions it needs (uniform, a few dozen fp64 ops)
-    const Pos p0 = locate<INTERP> (a, segs, a.n_begin + st * R);
-    const Pos p = locate<INTERP> (a, segs, a.n_begin + st * R + min (row, rows_valid - 1));
+    const Pos p0 = slot_pos (st * R);
+    const Pos p = slot_pos (st * R + min (row, rows_valid - 1));
     if (tid == 0) {
         g.canon_ip [st * R + row] = p.ip; g.canon_fi [st * R + row] = p.fi; g.canon_frac [st * R + row] = p.frac;
         if (st == 0 && row == 0) a.fix_count [0] = 0;       // per-launch count of off-pattern outputs (the main kernel follows in-stream)
@@ -68,7 +105,7 @@ void mfma_prepare_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
         if (tid == 0) s_pass = 0u;
         __syncthreads ();
         if (!INTERP && !a.lowpass && tid < rows_valid && tid < 32) {
-            const Pos q = locate<INTERP> (a, segs, a.n_begin + st * R + tid);
+            const Pos q = slot_pos (st * R + tid);
             if ((q.fi % a.F) == 0) atomicOr (&s_pass, 1u << tid);
         }
         __syncthreads ();
@@ -90,18 +127,8 @@ void mfma_prepare_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
         }
         dst [k] = c;
     }
-    // the call's head, gathered by the whole grid: linear frame lin = index - MF_HEAD_PAD; history below H, input above
-    if (g.head) {
-        const int blocks = gridDim.x * gridDim.y, me = blockIdx.y * gridDim.x + blockIdx.x;
-        const long total = (long) g.head_frames * a.C;
-        for (long e = (long) me * 256 + tid; e < total; e += (long) blocks * 256) {
-            const int f = (int)(e / a.C), c = (int)(e - (long) f * a.C), lin = f - MF_HEAD_PAD;
-            float v = 0.0f;
-            if (lin >= 0 && lin < a.H) v = a.hist [(size_t) lin * a.C + c];
-            else if (lin >= a.H && lin - a.H < a.in_frames) v = a.in [(size_t)(lin - a.H) * a.C + c];
-            g.head [e] = v;
-        }
-    }
+    // the call's head, gathered by the whole grid
+    if (g.head) gather_head (a, g, (int)(gridDim.x * gridDim.y), (int)(blockIdx.y * gridDim.x + blockIdx.x), tid);
 }
 
 // the flagged slots of every period of a launch <- their input samples (see artfir_pass_fixup_wanted)
@@ -676,7 +703,7 @@ void fir_mfma_split_kernel (ArtFirArgs a, MfmaGeom g, int wgs_per_xcd, int KS, d
             f_live = item_at (f_within, st, jg, ks);
             if (!f_live) return;
             chunks_of (ks, f_chunk, f_end);
-            const int w0 = g.tile_w0 [3 * st] + jg * PPW * g.Q;
+            const int w0 = g.tile_w0 [3 * st] + g.w_shift + jg * PPW * g.Q;
             const bool touches_hist = w0 < a.H;              // (first period group of a call: staged from the gathered head)
             const int origin = touches_hist ? -MF_HEAD_PAD : a.H;
             const char *base = touches_hist ? reinterpret_cast<const char *> (g.head) : reinterpret_cast<const char *> (a.in);
@@ -795,6 +822,7 @@ void fir_mfma_split_kernel (ArtFirArgs a, MfmaGeom g, int wgs_per_xcd, int KS, d
         const size_t left = (size_t)(a.n_end - n_tile) * CG * 4;
         const __amdgpu_buffer_rsrc_t rs_out = make_rsrc (a.out + (size_t) n_tile * CG, left > 0xffffff00ull ? 0xffffff00u : (unsigned int) left);
         const unsigned int pass_rows = PASS ? (unsigned int) g.tile_w0 [3 * st + 1] : 0u;
+        const int lo = a.n_skip != 0 && jg == 0 && wave == 0 ? a.n_skip - st * 32 : 0;      // (a launch on rows kept across calls starts mid-period: fir_i8_stream_kernel's epilogue)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i_const = (r & 3) + 8 * (r >> 2);      // compile-time part of the slot
@@ -802,9 +830,9 @@ void fir_mfma_split_kernel (ArtFirArgs a, MfmaGeom g, int wgs_per_xcd, int KS, d
             const int i = i_const + 4 * (lane >> 5);
             if constexpr (PASS) {
                 if ((pass_rows >> i) & 1u)
-                    y = load_frame (a, INT_MIN, g.canon_ip [st * 32 + i] + g.canon_fi [st * 32 + i] / a.F + (jg * PPW + jl) * g.Q, c);
+                    y = load_frame (a, INT_MIN, g.canon_ip [st * 32 + i] + g.w_shift + g.canon_fi [st * 32 + i] / a.F + (jg * PPW + jl) * g.Q, c);
             }
-            if (col_live && i < rows_valid)
+            if (col_live && i < rows_valid && (i >= lo || (lane & 31) >= CG))
                 __builtin_amdgcn_raw_buffer_store_b32 (__float_as_uint (y), rs_out, (int)(out_off + (unsigned int)(i_const * CG) * 4u), 0, 0);
         }
     }
@@ -1020,11 +1048,26 @@ size_t artfir_planes_bytes (const ArtFirArgs *a_, unsigned int outputs, int kern
 // device bytes of the rows the fixed-point kernel keeps across the calls of a context (0: this call is not for that kernel)
 size_t artfir_rows_bytes (const ArtFirArgs *a_, unsigned int outputs, int kernel_pref)
 {
-    if (!artfir_planes_bytes (a_, outputs, kernel_pref)) return 0;
+    if (!artfir_rows_cache_enabled ()) return 0;
     const ArtFirArgs wg_ = widest_group (a_), *a = &wg_;
+    if (!a->period_out || a->mode != ART_MODE_FAST) return 0;
     MfmaGeom g;
     const int cgt = matrix_geometry (a, g);
-    return cgt ? artfir_i8_rows_bytes (a, g, cgt, outputs) : 0;
+    if (!cgt) return 0;
+    // the f32 streaming kernel's set at the head, the fixed-point kernel's sets (where the call is for that kernel) behind it
+    return artfir_f32_set_bytes (g) + (artfir_planes_bytes (a_, outputs, kernel_pref) ? artfir_i8_rows_bytes (a, g, cgt, outputs) : 0);
+}
+
+// Upkeep of the stream's canonical period (fir_matrix_i8.hip, "The rows across calls") by EVERY launch of a rational-ratio stream, whichever kernel
+// runs it: which launch founds the period, and which one re-founds it when the positions have drifted off it, then depends on the stream's
+// positions alone — not on which of its launches happened to take a matrix path — so that two contexts fed the same stream (a shard and an ordinary
+// context, a group of another width) hold the same period and build the same rows.
+void artfir_rows_touch (const ArtFirArgs *a, const ArtSegTable *segs)
+{
+    if (!a->rows_cache || !a->period_out || (a->mode & 3) != ART_MODE_FAST || a->n_end <= a->n_begin) return;
+    const int mu = artfir_period_multiple (a->period_out, artfir_i8_slab_enabled () ? 64 : 32);
+    HostPos pos0; int slot0, w;
+    (void) artfir_rows_canonical (a, segs, mu * a->period_out, mu * a->period_in, (ArtRowsCache *) a->rows_cache, &pos0, &slot0, &w, false);
 }
 
 // Launch the matrix-core path for this call if it applies: returns ART_KERNEL_MFMA (| ART_FIR_ROLLED), -1 on a launch failure,
@@ -1077,8 +1120,52 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
         // device) and takes the history roll along.  kernel_pref 6 pins the f32 kernel.
         if (regular && kernel_pref != 6 && artfir_i8_launch (a, segs, g, cgt, roll_blocks, st))
             return hipGetLastError () == hipSuccess ? (ART_KERNEL_MFMA | (a->roll_dst ? ART_FIR_ROLLED : 0)) : -1;
-        if (a->interpolate) hipLaunchKernelGGL (mfma_prepare_kernel<true>, dim3 (g.slot_tiles, g.tile_rows), dim3 (256), 0, st, *a, *segs, g);
-        else hipLaunchKernelGGL (mfma_prepare_kernel<false>, dim3 (g.slot_tiles, g.tile_rows), dim3 (256), 0, st, *a, *segs, g);
+        // The f32 streaming kernel on rows kept across calls (fir_matrix_i8.hip, "The rows across calls": the same canonical period, one set of
+        // eff / canon_* / tile_w0 at the head of a->rows — no block alignment to honour): the launch is anchored on the canonical period
+        // (n_skip slots of its first period computed and not stored), the set's linear indices carried w_shift frames on, and all the call
+        // still prepares is its head (mfma_head_kernel) — or, once per stream, the set itself, from the canonical period's constants.
+        // (Both forms of the streaming kernel, K split or not; the one-tile-per-workgroup kernel keeps building its rows from its own positions.)
+        ArtFirArgs a_v = *a;
+        ArtRowsTable tb; tb.on = 0; tb.lin = tb.w = 0; tb.n0 = 0u; tb.base = 0.0;
+        bool rows_ready = false, on_kept_rows = false;
+        {
+            ArtRowsCache *rc = regular && g.head && artfir_rows_cache_enabled () && a->rows && artfir_f32_set_bytes (g) <= a->rows_bytes ? (ArtRowsCache *) a->rows_cache : nullptr;
+            HostPos pos0; int slot0 = 0, w = 0;
+            if (rc && artfir_rows_canonical (a, segs, g.P, g.Q, rc, &pos0, &slot0, &w) &&
+                rc->c_ip [0] + w - a->T / 2 + 1 >= -MF_HEAD_PAD) {                        // (the virtual start's window inside the head's zero frames)
+                ArtFirArgs t = *a;
+                t.n_begin = a->n_begin + (unsigned int)(g.P - slot0); t.n_end = a->n_end + (unsigned int) g.P;
+                t.out = a->out - (size_t) g.P * a->C; t.n_skip = slot0;
+                MfmaGeom g2;
+                if (matrix_geometry (&t, g2) == cgt && g2.slot_tiles == g.slot_tiles && g2.ktot == g.ktot && (size_t) t.n_end * t.C * 4 < 0xffff0000ull) {
+                    // (the tables in the set; the head stays in the call's scratch)
+                    const size_t rows = (size_t) g.slot_tiles * 32, eff_bytes = rows * g.ktot * sizeof (float);
+                    char *base = (char *) a->rows;
+                    g2.eff = (float *) base;
+                    g2.canon_frac = (double *)(base + ((eff_bytes + 15) & ~(size_t) 15));
+                    g2.canon_ip = (int *)(g2.canon_frac + rows); g2.canon_fi = g2.canon_ip + rows; g2.tile_w0 = g2.canon_fi + rows;
+                    g2.head = g.head; g2.head_frames = g.head_frames;
+                    const bool same = rc->f_valid && rc->f_lowpass == a->lowpass && rc->f_slot_tiles == g.slot_tiles && rc->f_ktot == g.ktot;
+                    if (same) { g2.w_shift = w - rc->f_w_build; rows_ready = true; }
+                    else {
+                        rc->f_valid = 1; rc->f_w_build = w; rc->f_lowpass = a->lowpass; rc->f_slot_tiles = g.slot_tiles; rc->f_ktot = g.ktot;
+                        g2.w_shift = 0;
+                        tb.on = 1; tb.base = rc->c_base; tb.lin = rc->c_lin; tb.n0 = rc->c_n0; tb.w = w;
+                    }
+                    a_v = t; g = g2; on_kept_rows = true;
+                }
+            }
+        }
+        a = &a_v;
+        {   static const bool trace = [] { const char *e = getenv ("ARTAMD_ROWS_TRACE"); return e && *e == '1'; } ();
+            if (trace) fprintf (stderr, "rows (f32): launch n %u..%u C %d  kept %d  ready %d  n_skip %d  w_shift %d  regular %d split %p\n", a->n_begin, a->n_end, a->C, (int) on_kept_rows, (int) rows_ready, a->n_skip, g.w_shift, (int) regular, a->split);
+        }
+        if (rows_ready) {
+            const unsigned int hb = (unsigned int)(((size_t) g.head_frames * a->C + 1023) / 1024);
+            hipLaunchKernelGGL (mfma_head_kernel, dim3 (hb < 1u ? 1u : hb > 512u ? 512u : hb), dim3 (256), 0, st, *a, g);
+        }
+        else if (a->interpolate) hipLaunchKernelGGL (mfma_prepare_kernel<true>, dim3 (g.slot_tiles, g.tile_rows), dim3 (256), 0, st, *a, *segs, g, tb);
+        else hipLaunchKernelGGL (mfma_prepare_kernel<false>, dim3 (g.slot_tiles, g.tile_rows), dim3 (256), 0, st, *a, *segs, g, tb);
         if (a->ev_start) arthip_event_record (a->ev_start, stream);
 
         // Regular launches (all but very long calls and nearest-filter phases on a half step) stream their tiles through
@@ -1095,7 +1182,8 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
             { static const int k_env = [] { const char *e = getenv ("ARTAMD_TILES_PER_WG"); return e && *e ? atoi (e) : 0; } (); if (k_env > 0) wgs_per_xcd = (tiles_per_xcd + k_env - 1) / k_env; }
             // launches of few tiles: a tile's K range as several work items (fir_mfma_split_kernel)
             const bool fixup = artfir_pass_fixup_wanted (a);
-            const int ks = a->split ? matrix_split_parts (a, g, a->n_end - a->n_begin, kernel_pref) : 1;
+            // (the rule looks at the launch's own outputs: the slots a launch on kept rows computes in front of its first do not count)
+            const int ks = a->split ? matrix_split_parts (a, g, a->n_end - a->n_begin - (unsigned int) a->n_skip, kernel_pref) : 1;
             if (ks > 1 && (size_t) 8 * tiles_per_xcd * 16 <= ART_SPLIT_HEAD_BYTES &&
                 ART_SPLIT_HEAD_BYTES + (size_t) 8 * tiles_per_xcd * ks * 16 * MF_THREADS * sizeof (double) <= a->split_bytes) {
                 const int items = tiles_per_xcd * ks;

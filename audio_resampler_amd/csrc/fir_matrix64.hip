@@ -303,6 +303,7 @@ bool artfir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int
 // 0 when the call is for the general kernel.
 size_t artfir_planes_bytes (const ArtFirArgs *, unsigned int, int) { return 0; }
 size_t artfir_rows_bytes (const ArtFirArgs *, unsigned int, int) { return 0; }
+void artfir_rows_touch (const ArtFirArgs *, const ArtSegTable *) { }
 extern "C" {      // (the fixed-point kernel's rows across calls: 4-byte samples only)
 size_t arthip_fir_rows_cache_bytes (void) { return 0; }
 void arthip_fir_rows_cache_reset (void *) { }

@@ -83,3 +83,117 @@ template <> struct VecLoad<4> { static __device__ __forceinline__ void load (flo
 
 
 } // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// Filter rows kept across calls (ArtFirArgs.rows on the device, this block on the host: ArtFirArgs.rows_cache) — the scheme is described
+// in front of artfir_i8_launch (fir_matrix_i8.hip); the f32 streaming kernel keeps one set of its own tables (eff / canon_* / tile_w0) at the
+// head of the same device buffer (fir_matrix.hip).
+// ---------------------------------------------------------------------------------------------------
+struct ArtRowsCache {
+    // the canonical period
+    const void *bank; int T, F, interp, P, Q; double ratio;
+    int canon_valid, cap;
+    double *c_ph; int *c_ip, *c_fi;       // [cap >= P]
+    double c_base; int c_lin; unsigned int c_n0;              // ... as the device evaluates it: epoch offset, ring-to-linear shift, first output
+    // the fixed-point kernel's sets built for it
+    int lowpass, tr, ktot, tiles, g, slot_tiles, ktot32; size_t set_bytes;
+    int nsets, victim, valid [4], w_build [4];
+    // the f32 streaming kernel's set
+    int f_valid, f_w_build, f_lowpass, f_slot_tiles, f_ktot;
+};
+// the canonical period's constants as a kernel argument (the row workgroups evaluate slot k themselves)
+struct ArtRowsTable { int on; int lin, w; unsigned int n0; double base; };
+
+namespace {
+
+struct HostPos { int ip, fi; double ph; };
+// locate () on the host: the reference's position arithmetic (compiled, like the device's, without contraction)
+__attribute__ ((unused)) static HostPos host_locate (const ArtFirArgs *a, const ArtSegTable *segs, unsigned int n)
+{
+    int e = 0;
+    while (e + 1 < segs->count && segs->first [e + 1] <= n) ++e;
+    const double step = n ? (double) n / a->ratio : 0.0;
+    const double off = segs->base [e] + step;
+    const double whole = floor (off);
+    double fr = off - whole;
+    fr = fr * (double) a->F;
+    HostPos p;
+    p.ph = fr;
+    p.fi = a->interpolate ? (int) floor (fr) : (int) floor (fr + 0.5);
+    p.ip = (int) whole + segs->lin_base [e];
+    return p;
+}
+
+__attribute__ ((unused)) static bool artfir_rows_cache_enabled ()
+{
+    static const bool on = [] { const char *e = getenv ("ARTAMD_ROWS_CACHE"); return !(e && *e == '0'); } ();
+    return on;
+}
+
+// device bytes of the f32 streaming kernel's set (at the head of ArtFirArgs.rows)
+__attribute__ ((unused)) static size_t artfir_f32_set_bytes (const MfmaGeom &g)
+{
+    const size_t rows = (size_t) g.slot_tiles * 32;
+    return ((rows * g.ktot * sizeof (float) + rows * (sizeof (double) + 2 * sizeof (int)) + (size_t) 3 * g.slot_tiles * sizeof (int) + 1024) + 4095) & ~(size_t) 4095;
+}
+
+// The launch's place in the stream's canonical period: *pos0 = its first output's position; with a cache, slot0 / w = the canonical slot
+// that output is and the whole number of frames it sits further on (a new canonical period — this launch's first — where the stream has
+// left the old one: every set is then invalid).  false: no cache for this launch (none given, or out of memory).
+// verify_nearest: a nearest-filter launch that is about to USE kept rows checks the canonical filter index of every slot against its own positions
+// (the matrix paths); the per-launch upkeep of the canonical period (artfir_rows_touch) does not.
+__attribute__ ((unused)) static bool artfir_rows_canonical (const ArtFirArgs *a_in, const ArtSegTable *segs, int P, int Q, ArtRowsCache *rc, HostPos *pos0_out, int *slot0_out, int *w_out,
+                                                            bool verify_nearest = true)
+{
+    const HostPos pos0 = host_locate (a_in, segs, a_in->n_begin);
+    *pos0_out = pos0; *slot0_out = 0; *w_out = 0;
+    if (!rc) return false;
+    const bool same = rc->canon_valid && rc->bank == (const void *) a_in->bank && rc->T == a_in->T && rc->F == a_in->F && rc->interp == a_in->interpolate &&
+                      rc->P == P && rc->Q == Q && rc->ratio == a_in->ratio;
+    if (!same) rc->canon_valid = 0;
+    if (rc->cap < P) {
+        free (rc->c_ph); free (rc->c_ip); free (rc->c_fi);
+        rc->cap = P; rc->canon_valid = 0;
+        rc->c_ph = (double *) malloc (sizeof (double) * (size_t) rc->cap); rc->c_ip = (int *) malloc (sizeof (int) * (size_t) rc->cap); rc->c_fi = (int *) malloc (sizeof (int) * (size_t) rc->cap);
+        if (!rc->c_ph || !rc->c_ip || !rc->c_fi) { free (rc->c_ph); free (rc->c_ip); free (rc->c_fi); rc->c_ph = nullptr; rc->c_ip = rc->c_fi = nullptr; rc->cap = 0; return false; }
+    }
+    int slot0 = 0, w = 0;
+    if (rc->canon_valid) {
+        const double tol = 1e-6, F = (double) a_in->F;
+        bool found = false;
+        for (int s = 0; s < P && !found; ++s) {
+            double d = fabs (rc->c_ph [s] - pos0.ph);
+            if (d > 0.5 * F) d = F - d;
+            if (d > tol) continue;
+            // (positions in frames: the same lattice point up to the tolerance, a whole number of frames apart)
+            const double w_exact = ((double) pos0.ip + pos0.ph / F) - ((double) rc->c_ip [s] + rc->c_ph [s] / F);
+            const int wr = (int) floor (w_exact + 0.5);
+            if (fabs (w_exact - (double) wr) > 1e-6) break;
+            found = true; slot0 = s; w = wr;
+        }
+        if (found && !a_in->interpolate && verify_nearest)    // nearest filter: the canonical rounded filter index in every slot, from this launch's own positions
+            for (int t = 0; t < P && found; ++t) {                // (its first P outputs are slots s, s + 1, ... of the canonical period, wrapping into the next)
+                const unsigned int n = a_in->n_begin + (unsigned int) t;
+                if (n >= a_in->n_end) break;
+                found = host_locate (a_in, segs, n).fi == rc->c_fi [(slot0 + t) % P];
+            }
+        if (!found) rc->canon_valid = 0;
+    }
+    if (!rc->canon_valid) {                                   // a new canonical period: this launch's first
+        // (the epoch of the launch's first output, carried through the whole period even where the ring rewinds inside it: the same lattice,
+        // and constants the row workgroups can evaluate themselves)
+        int e = 0;
+        while (e + 1 < segs->count && segs->first [e + 1] <= a_in->n_begin) ++e;
+        rc->c_base = segs->base [e]; rc->c_lin = segs->lin_base [e]; rc->c_n0 = a_in->n_begin;
+        ArtSegTable one; one.count = 1; one.lin_floor = segs->lin_floor; one.first [0] = 0u; one.lin_base [0] = rc->c_lin; one.base [0] = rc->c_base;
+        for (int i = 0; i < P; ++i) { const HostPos p = host_locate (a_in, &one, rc->c_n0 + (unsigned int) i); rc->c_ph [i] = p.ph; rc->c_ip [i] = p.ip; rc->c_fi [i] = p.fi; }
+        rc->bank = (const void *) a_in->bank; rc->T = a_in->T; rc->F = a_in->F; rc->interp = a_in->interpolate; rc->P = P; rc->Q = Q; rc->ratio = a_in->ratio;
+        rc->canon_valid = 1; slot0 = 0; w = 0;
+        for (int k = 0; k < 4; ++k) rc->valid [k] = 0;
+        rc->f_valid = 0;
+    }
+    *slot0_out = slot0; *w_out = w;
+    return true;
+}
+
+} // namespace

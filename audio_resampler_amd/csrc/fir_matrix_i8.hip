@@ -1480,36 +1480,7 @@ size_t artfir_i8_bytes (const ArtFirArgs *a, const MfmaGeom &g, int cgt, unsigne
 //     canonical filter index in every slot; a stream that left the lattice (advance, reset to another phase, another ratio) starts a new
 //     canonical period.  ARTAMD_ROWS_CACHE=0: off — every launch builds its rows from its own positions, as before.
 // ---------------------------------------------------------------------------------------------------
-struct ArtRowsCache {
-    // the canonical period
-    const void *bank; int T, F, interp, P, Q; double ratio;
-    int canon_valid, cap;
-    double *c_ph; int *c_ip, *c_fi;       // [cap >= P]
-    // the sets built for it
-    int lowpass, tr, ktot, tiles, g, slot_tiles, ktot32; size_t set_bytes;
-    int nsets, victim, valid [4], w_build [4];
-    double c_base; int c_lin; unsigned int c_n0;              // ... as the device evaluates it: epoch offset, ring-to-linear shift, first output
-};
-
 namespace {
-
-struct HostPos { int ip, fi; double ph; };
-// locate () on the host: the reference's position arithmetic (compiled, like the device's, without contraction)
-static HostPos host_locate (const ArtFirArgs *a, const ArtSegTable *segs, unsigned int n)
-{
-    int e = 0;
-    while (e + 1 < segs->count && segs->first [e + 1] <= n) ++e;
-    const double step = n ? (double) n / a->ratio : 0.0;
-    const double off = segs->base [e] + step;
-    const double whole = floor (off);
-    double fr = off - whole;
-    fr = fr * (double) a->F;
-    HostPos p;
-    p.ph = fr;
-    p.fi = a->interpolate ? (int) floor (fr) : (int) floor (fr + 0.5);
-    p.ip = (int) whole + segs->lin_base [e];
-    return p;
-}
 
 struct RowsSetPtrs {
     unsigned long long *a_masks, *tile_masks; unsigned char *a_planes;
@@ -1532,12 +1503,6 @@ static size_t rows_set_layout (const MfmaGeom &g, const I8Geom &q, char *base, R
     return off;
 }
 
-static bool rows_cache_enabled ()
-{
-    static const bool on = [] { const char *e = getenv ("ARTAMD_ROWS_CACHE"); return !(e && *e == '0'); } ();
-    return on;
-}
-
 } // namespace
 
 extern "C" {
@@ -1545,7 +1510,7 @@ size_t arthip_fir_rows_cache_bytes (void) { return sizeof (ArtRowsCache); }
 void arthip_fir_rows_cache_reset (void *cache)               // (the device buffer was replaced: no set in it is valid; the canonical period stays)
 {
     ArtRowsCache *rc = (ArtRowsCache *) cache;
-    if (rc) for (int k = 0; k < 4; ++k) rc->valid [k] = 0;
+    if (rc) { for (int k = 0; k < 4; ++k) rc->valid [k] = 0; rc->f_valid = 0; }
 }
 void arthip_fir_rows_cache_free (void *cache)
 {
@@ -1560,9 +1525,9 @@ void arthip_fir_rows_cache_free (void *cache)
 size_t artfir_i8_rows_bytes (const ArtFirArgs *a, const MfmaGeom &g, int cgt, unsigned int outputs)
 {
     I8Geom q;
-    if (!rows_cache_enabled () || !i8_layout (a, g, cgt, q, nullptr, outputs ? outputs : 1u)) return 0;
+    if (!i8_layout (a, g, cgt, q, nullptr, outputs ? outputs : 1u)) return 0;
     // (4 / g sets: one per place of the windows inside their 4-frame blocks that the period residues do not cover)
-    return (size_t)(4 / q.g) * (rows_set_layout (g, q, nullptr, nullptr) + 4096);
+    return (size_t)(4 / q.g) * (rows_set_layout (g, q, nullptr, nullptr) + 4096);      // (behind the f32 kernel's set: artfir_rows_bytes adds it)
 }
 
 int artfir_i8_launch (const ArtFirArgs *a_in, const ArtSegTable *segs, const MfmaGeom &g_in, int cgt, unsigned int roll_blocks, hipStream_t st)
@@ -1574,54 +1539,10 @@ int artfir_i8_launch (const ArtFirArgs *a_in, const ArtSegTable *segs, const Mfm
     MfmaGeom g = g_in;
 
     // ---- the launch's place in the canonical period
-    ArtRowsCache *rc = rows_cache_enabled () && a_in->rows ? (ArtRowsCache *) a_in->rows_cache : nullptr;
-    const HostPos pos0 = host_locate (a_in, segs, a_in->n_begin);
+    ArtRowsCache *rc = artfir_rows_cache_enabled () && a_in->rows ? (ArtRowsCache *) a_in->rows_cache : nullptr;
+    HostPos pos0;
     int slot0 = 0, w = 0;
-    if (rc) {
-        const bool same = rc->canon_valid && rc->bank == (const void *) a_in->bank && rc->T == a_in->T && rc->F == a_in->F && rc->interp == a_in->interpolate &&
-                          rc->P == g.P && rc->Q == g.Q && rc->ratio == a_in->ratio;
-        if (!same) rc->canon_valid = 0;
-        if (rc->cap < g.P) {
-            free (rc->c_ph); free (rc->c_ip); free (rc->c_fi);
-            rc->cap = g.P; rc->canon_valid = 0;
-            rc->c_ph = (double *) malloc (sizeof (double) * (size_t) rc->cap); rc->c_ip = (int *) malloc (sizeof (int) * (size_t) rc->cap); rc->c_fi = (int *) malloc (sizeof (int) * (size_t) rc->cap);
-            if (!rc->c_ph || !rc->c_ip || !rc->c_fi) { arthip_fir_rows_cache_free (rc); rc = nullptr; }
-        }
-    }
-    if (rc && rc->canon_valid) {
-        const double tol = 1e-6, F = (double) a_in->F;
-        bool found = false;
-        for (int s = 0; s < g.P && !found; ++s) {
-            double d = fabs (rc->c_ph [s] - pos0.ph);
-            if (d > 0.5 * F) d = F - d;
-            if (d > tol) continue;
-            // (positions in frames: the same lattice point up to the tolerance, a whole number of frames apart)
-            const double w_exact = ((double) pos0.ip + pos0.ph / F) - ((double) rc->c_ip [s] + rc->c_ph [s] / F);
-            const int wr = (int) floor (w_exact + 0.5);
-            if (fabs (w_exact - (double) wr) > 1e-6) break;
-            found = true; slot0 = s; w = wr;
-        }
-        if (found && !a_in->interpolate)                      // nearest filter: the canonical rounded filter index in every slot, from this launch's own positions
-            for (int t = 0; t < g.P && found; ++t) {              // (its first P outputs are slots s, s + 1, ... of the canonical period, wrapping into the next)
-                const unsigned int n = a_in->n_begin + (unsigned int) t;
-                if (n >= a_in->n_end) break;
-                found = host_locate (a_in, segs, n).fi == rc->c_fi [(slot0 + t) % g.P];
-            }
-        if (!found) rc->canon_valid = 0;
-    }
-    if (rc && !rc->canon_valid) {                             // a new canonical period: this launch's first
-        {   // (the epoch of the launch's first output, carried through the whole period even where the ring rewinds inside it: the same lattice,
-            // and constants the row workgroups can evaluate themselves)
-            int e = 0;
-            while (e + 1 < segs->count && segs->first [e + 1] <= a_in->n_begin) ++e;
-            rc->c_base = segs->base [e]; rc->c_lin = segs->lin_base [e]; rc->c_n0 = a_in->n_begin;
-            ArtSegTable one; one.count = 1; one.lin_floor = segs->lin_floor; one.first [0] = 0u; one.lin_base [0] = rc->c_lin; one.base [0] = rc->c_base;
-            for (int i = 0; i < g.P; ++i) { const HostPos p = host_locate (a_in, &one, rc->c_n0 + (unsigned int) i); rc->c_ph [i] = p.ph; rc->c_ip [i] = p.ip; rc->c_fi [i] = p.fi; }
-        }
-        rc->bank = (const void *) a_in->bank; rc->T = a_in->T; rc->F = a_in->F; rc->interp = a_in->interpolate; rc->P = g.P; rc->Q = g.Q; rc->ratio = a_in->ratio;
-        rc->canon_valid = 1; slot0 = 0; w = 0;
-        for (int k = 0; k < 4; ++k) rc->valid [k] = 0;
-    }
+    if (!artfir_rows_canonical (a_in, segs, g.P, g.Q, rc, &pos0, &slot0, &w)) rc = nullptr;
     // (the virtual start's window must not begin in front of the zero frames the planes hold before linear frame 0)
     if (rc && rc->c_ip [0] + w - a_in->T / 2 + 1 + I8_PADF < 0) rc = nullptr;
     if (rc) {
@@ -1643,7 +1564,7 @@ int artfir_i8_launch (const ArtFirArgs *a_in, const ArtSegTable *segs, const Mfm
         const int nsets = 4 / q.g;
         const bool same = rc->lowpass == a_in->lowpass && rc->tr == q.tr && rc->ktot == q.ktot && rc->tiles == q.tiles && rc->g == q.g && rc->slot_tiles == g.slot_tiles &&
                           rc->ktot32 == g.ktot && rc->set_bytes == set_bytes && rc->nsets == nsets;
-        if ((size_t) nsets * (set_bytes + 4096) > a_in->rows_bytes) {          // (no room: this launch alone, in its own buffers, from its own positions)
+        if (artfir_f32_set_bytes (g) + (size_t) nsets * (set_bytes + 4096) > a_in->rows_bytes) {          // (no room: this launch alone, in its own buffers, from its own positions)
             rc = nullptr; a_v = *a_in;
             need = i8_layout (a, g, cgt, q, (char *) a_in->planes);
             if (!need || need > a_in->planes_bytes) return 0;
@@ -1667,7 +1588,7 @@ int artfir_i8_launch (const ArtFirArgs *a_in, const ArtSegTable *segs, const Mfm
                 g.w_shift = 0; q.jr_rot = 0; q.rows_cached = 0; build_from_table = true;
             }
             RowsSetPtrs sp;
-            rows_set_layout (g, q, (char *) a_in->rows + (size_t) set * (set_bytes + 4096), &sp);
+            rows_set_layout (g, q, (char *) a_in->rows + artfir_f32_set_bytes (g) + (size_t) set * (set_bytes + 4096), &sp);      // (behind the f32 kernel's own set)
             q.a_masks = sp.a_masks; q.tile_masks = sp.tile_masks; q.a_planes = sp.a_planes;
             g.eff = sp.eff; g.canon_frac = sp.canon_frac; g.canon_ip = sp.canon_ip; g.canon_fi = sp.canon_fi; g.tile_w0 = sp.tile_w0;
         }

@@ -68,7 +68,7 @@ struct artamd_resampler {
     void *d_scratch; size_t scratch_cap;     /* MFMA path: effective rows + canonical positions of one launch */
     void *d_pad; size_t pad_cap;             /* matrix path of a channel count the kernels are not compiled for: the groups' padded buffers (arthip_fir_pad_bytes) */
     void *d_planes; size_t planes_cap;       /* fixed-point matrix kernel: digit planes of one launch (flag word first) */
-    void *d_rows; size_t rows_cap; void *rows_cache; void *last_masks;      /* ... its filter rows, kept across calls (art_internal.h), and where the last launch's row masks live */
+    int rows_off; void *d_rows; size_t rows_cap; void *rows_cache; void *last_masks;      /* ... its filter rows, kept across calls (art_internal.h), and where the last launch's row masks live */
     void *d_split; size_t split_cap;         /* K-split streaming kernel: arrival counters (zero at rest) + partial sums of one launch */
     int last_fixed [4];                      /* its last launch of the last call: flag value (0: none), mask words, chunks per tile, kernel form (art_hip.h) */
     unsigned int *d_fix; size_t fix_cap;    /* [0] per-launch, [1] running count of outputs the matrix kernels evaluated off-pattern */
@@ -822,6 +822,12 @@ void resampleHipSetKernel (Resample *cxt, int which)
     for (int k = 0; k < cxt->hip->nshards; ++k) resampleHipSetKernel (cxt->hip->shards [k], which);
 }
 
+void resampleHipKeepRows (Resample *cxt, int on)
+{
+    cxt->hip->rows_off = !on;
+    for (int k = 0; k < cxt->hip->nshards; ++k) resampleHipKeepRows (cxt->hip->shards [k], on);
+}
+
 int resampleHipGetDevice (Resample *cxt) { return cxt->hip->device; }
 int resampleHipNumShards (Resample *cxt) { return cxt->hip->nshards; }
 
@@ -1216,6 +1222,12 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
          * pays for them) */
         int matrix_sized = 0;
         hip->last_fixed [0] = 0;
+        /* the canonical period of the rows the matrix kernels keep across calls: looked after by every launch of a rational-ratio stream,
+         * whichever kernel runs it (fir_matrix.hip, artfir_rows_touch) */
+        if (a.period_out && a.mode == ART_MODE_FAST && !hip->rows_off && !is_flush) {
+            if (!hip->rows_cache && arthip_fir_rows_cache_bytes ()) hip->rows_cache = calloc (1, arthip_fir_rows_cache_bytes ());
+            a.rows_cache = hip->rows_cache;
+        }
         if (a.period_out && a.mode == ART_MODE_FAST && hip->kernel_pref != ART_KERNEL_GENERAL && !is_flush) {
             ArtSegTable probe;
             probe.count = 1; probe.lin_floor = lin_floor;
@@ -1241,14 +1253,13 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
                 if (hip->d_planes) arthip_zero (hip->d_planes, ART_I8_HEAD_BYTES, hip->stream);
             }
             a.planes = want ? hip->d_planes : NULL; a.planes_bytes = hip->d_planes ? hip->planes_cap : 0;
-            /* ... and its filter rows, which outlive the call: built by the first launch of a stream, looked up by the others */
-            const size_t rows_want = want ? arthip_fir_rows_bytes (&a, res.output_generated, hip->kernel_pref) : 0;
-            if (rows_want && !hip->rows_cache) hip->rows_cache = calloc (1, arthip_fir_rows_cache_bytes ());
+            /* ... and the matrix kernels' filter rows, which outlive the call: built by the first launch of a stream, looked up by the others */
+            const size_t rows_want = hip->rows_off ? 0 : arthip_fir_rows_bytes (&a, res.output_generated, hip->kernel_pref);
             if (rows_want > hip->rows_cap && hip->rows_cache) {
                 hip->d_rows = grow (hip->d_rows, &hip->rows_cap, rows_want);
                 arthip_fir_rows_cache_reset (hip->rows_cache);
             }
-            if (rows_want && hip->d_rows && hip->rows_cache) { a.rows = hip->d_rows; a.rows_bytes = hip->rows_cap; a.rows_cache = hip->rows_cache; }
+            if (rows_want && hip->d_rows && hip->rows_cache) { a.rows = hip->d_rows; a.rows_bytes = hip->rows_cap; }
             hip->last_masks = NULL; a.rows_masks_out = &hip->last_masks;
             /* calls of few tiles: room for the K-split kernel's partial sums (a grown buffer starts with its counters zeroed; the
              * old one is released behind the launches that used it: stream order) */

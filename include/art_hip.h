@@ -61,6 +61,11 @@ void resampleHipSynchronize (Resample *cxt);
  * differs from them in the last place), 7 = as 2 and the fixed-point kernel wherever it can run (automatically it takes
  * filters of 512 taps and more in calls of about a billion output-sample taps and more, where it is the faster one) */
 void resampleHipSetKernel (Resample *cxt, int which);
+/* The streaming matrix kernels keep their filter rows across the calls of a context (built once for the stream's canonical period; every later
+ * launch is anchored on that period: DESIGN.md 4.1) — on by default.  Off: every launch builds its rows from its own positions and anchors its
+ * tiles on its own first output, as before round 5 (comparisons of kernel forms bit for bit; ARTAMD_ROWS_CACHE=0 does it for a whole process).
+ * Either way a sample is within the parity bar; the two differ in the last place of a few per cent of the samples. */
+void resampleHipKeepRows (Resample *cxt, int on);
 int  resampleHipLastKernel (Resample *cxt);          /* which kernel produced the bulk of the last call */
 /* the matrix-core path's fixed-point kernel (regular launches, 4-byte samples): 0 = the last call did not use it, 1 = it ran,
  * 2 = it was enqueued and stood down for the f32 kernel behind it (a sample outside (-1.98, 1.98) or not finite).

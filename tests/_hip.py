@@ -8,10 +8,12 @@ class HipResampler(A.Resampler):
     """same constructor shape as _oracle.OracleResampler"""
 
     def __init__(self, channels, taps, filters, lowpass_ratio=0.0, flags=A.BLACKMAN_HARRIS | A.SUBSAMPLE_INTERPOLATE,
-                 fixed=None, extra=0, kernel=0):
+                 fixed=None, extra=0, kernel=0, keep_rows=True):
         super().__init__(channels, taps, filters, lowpass_ratio, flags | extra, fixed)
         if kernel:
             self.set_kernel(kernel)
+        if not keep_rows:          # (comparisons of kernel forms bit for bit: every launch on rows built from its own positions, include/art_hip.h)
+            self.keep_rows(False)
 
 
 def strict(**kw):

@@ -14,6 +14,11 @@ STREAMS = [
     (8, 988, 988, 96000, 44100, True, BH | INTERP | LOWPASS, (280000, 140000, 280000)),
     (4, 380, 32, 44100, 48000, False, BH, (250000, 120000, 250000)),
 ]
+F32_STREAMS = [
+    (2, 380, 380, 44100, 48000, False, BH | INTERP, (200000, 200000, 90000, 200001)),
+    (8, 988, 988, 44100, 48000, False, BH | INTERP, (90000, 90000, 40000)),
+    (16, 156, 156, 44100, 48000, False, BH | INTERP, (100000, 100000)),
+]
 
 
 def main():
@@ -29,6 +34,17 @@ def main():
             u, g, y = r.process(x[pos:pos + n], int(n * ratio) + 4000, 0.0 if fixed else ratio)
             assert u == n and r.fixed_point()[0] == 1
             out[f"s{si}_call{ci}"] = np.array(y).copy(); pos += n
+    for si, (ch, T, F, src, dst, fixed, flags, blocks) in enumerate(F32_STREAMS):
+        r = HipResampler(ch, T, F, 0.0, flags, kernel=6)
+        r.advance(T / 2)
+        ratio = dst / src
+        x, _ = noise(sum(blocks) * ch, state=(ch * 1000 + T + 7) | 1)
+        x = x.reshape(-1, ch)
+        pos = 0
+        for ci, n in enumerate(blocks):
+            u, g, y = r.process(x[pos:pos + n], int(n * ratio) + 4000, ratio)
+            assert u == n and r.last_kernel() == 2 and r.fixed_point()[0] == 0
+            out[f"f{si}_call{ci}"] = np.array(y).copy(); pos += n
     fd, path = tempfile.mkstemp(suffix=".npz"); os.close(fd)
     np.savez(path, **out)
     print(path)

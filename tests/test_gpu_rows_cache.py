@@ -29,6 +29,18 @@ STREAMS = [
 ]
 
 
+F32_STREAMS = [
+    # the f32 streaming kernel on kept rows (kernel preference 6, or the library's own choice for short filters / narrow streams)
+    (2, 380, 380, 44100, 48000, False, BH | INTERP, (120000, 120000, 120001, 50000, 120000)),           # BASELINE configs[1]
+    (8, 988, 988, 44100, 48000, False, BH | INTERP, (70000, 70000, 70003)),
+    (1, 48, 48, 44100, 48000, False, BH | INTERP, (300000, 300000, 299999)),                            # configs[0]: many ring epochs per call
+    (16, 156, 156, 44100, 48000, False, BH | INTERP, (100000, 100000, 100001)),
+    (2, 380, 160, 44100, 48000, True, BH | INTERP | LOWPASS, (150000, 150000, 150001)),                 # ART's form: nearest filter, low-pass
+    (4, 512, 32, 44100, 48000, False, BH, (90000, 90000, 90003)),                                       # nearest filter, pass-through slots
+    (8, 988, 988, 44100, 88200, False, BH | INTERP, (40000, 40000, 40001)),
+]
+
+
 def _play(stream, make, tail=None):
     ch, T, F, src, dst, fixed, flags, blocks = stream
     r = make(ch, T, F, flags, (float(src), float(dst), 0) if fixed else None)
@@ -52,6 +64,18 @@ def test_streams_on_cached_rows_against_the_oracle(stream):
     got = _play(stream, lambda ch, T, F, fl, fx: HipResampler(ch, T, F, 0.0, fl, fixed=fx, kernel=7), tail=lambda r: kinds.append(int(r.fixed_point()[0])))
     want = _play(stream, lambda ch, T, F, fl, fx: OracleResampler(ch, T, F, 0.0, fl | PRECISE, fixed=fx))
     assert all(k == 1 for k in kinds), kinds                  # (every call ran in fixed point)
+    for i, (y, yo) in enumerate(zip(got, want)):
+        assert y.shape == yo.shape, (i, y.shape, yo.shape)
+        ok, worst, rms = tolerance_ok(y, yo)
+        assert ok, (i, worst, rms)
+
+
+@pytest.mark.parametrize("stream", F32_STREAMS, ids=lambda s: f"{s[0]}ch_{s[1]}x{s[2]}_{s[3]}to{s[4]}")
+def test_f32_streams_on_kept_rows_against_the_oracle(stream):
+    kinds = []
+    got = _play(stream, lambda ch, T, F, fl, fx: HipResampler(ch, T, F, 0.0, fl, fixed=fx, kernel=6), tail=lambda r: kinds.append((int(r.last_kernel()), int(r.fixed_point()[0]))))
+    want = _play(stream, lambda ch, T, F, fl, fx: OracleResampler(ch, T, F, 0.0, fl | PRECISE, fixed=fx))
+    assert all(k == (2, 0) for k in kinds), kinds             # (every call on the f32 matrix kernels)
     for i, (y, yo) in enumerate(zip(got, want)):
         assert y.shape == yo.shape, (i, y.shape, yo.shape)
         ok, worst, rms = tolerance_ok(y, yo)
