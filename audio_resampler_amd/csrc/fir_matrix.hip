@@ -58,10 +58,21 @@ __device__ __forceinline__ void gather_head (const ArtFirArgs &a, const MfmaGeom
     }
 }
 // launches on rows kept across calls: the head is all a call still has to prepare
+// (interleaved frames on both sides: the head is MF_HEAD_PAD zero frames, the history, the call's first input frames — three runs of
+// consecutive floats; one element per thread, no division, as many workgroups as it takes: the launch is a latency chain of one load)
 __global__ __launch_bounds__ (256)
 void mfma_head_kernel (ArtFirArgs a, MfmaGeom g)
 {
-    gather_head (a, g, (int) gridDim.x, (int) blockIdx.x, (int) threadIdx.x);
+    const unsigned int total = (unsigned int) g.head_frames * (unsigned int) a.C, e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= total) return;
+    const unsigned int pad = (unsigned int) MF_HEAD_PAD * (unsigned int) a.C, hist = (unsigned int) a.H * (unsigned int) a.C;
+    float v = 0.0f;
+    if (e >= pad) {
+        unsigned int k = e - pad;
+        if (k < hist) v = a.hist [k];
+        else { k -= hist; if (k < (unsigned int) a.in_frames * (unsigned int) a.C) v = a.in [k]; }
+    }
+    g.head [e] = v;
 }
 
 template <bool INTERP>
@@ -1161,8 +1172,8 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
             if (trace) fprintf (stderr, "rows (f32): launch n %u..%u C %d  kept %d  ready %d  n_skip %d  w_shift %d  regular %d split %p\n", a->n_begin, a->n_end, a->C, (int) on_kept_rows, (int) rows_ready, a->n_skip, g.w_shift, (int) regular, a->split);
         }
         if (rows_ready) {
-            const unsigned int hb = (unsigned int)(((size_t) g.head_frames * a->C + 1023) / 1024);
-            hipLaunchKernelGGL (mfma_head_kernel, dim3 (hb < 1u ? 1u : hb > 512u ? 512u : hb), dim3 (256), 0, st, *a, g);
+            const unsigned int hb = (unsigned int)(((size_t) g.head_frames * a->C + 255) / 256);
+            hipLaunchKernelGGL (mfma_head_kernel, dim3 (hb < 1u ? 1u : hb), dim3 (256), 0, st, *a, g);
         }
         else if (a->interpolate) hipLaunchKernelGGL (mfma_prepare_kernel<true>, dim3 (g.slot_tiles, g.tile_rows), dim3 (256), 0, st, *a, *segs, g, tb);
         else hipLaunchKernelGGL (mfma_prepare_kernel<false>, dim3 (g.slot_tiles, g.tile_rows), dim3 (256), 0, st, *a, *segs, g, tb);

@@ -1057,12 +1057,18 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
     // issued — the piece is not fetched either: a scalar offset past the resource's end, zeros into the LDS, nothing through the L2.
     // The rows' first plane lives in 4 of 33 images, the second in 24: a quarter of the rows' bytes stay where they are)
     int d_skip [2] = { 0, 0 };
+    // (likewise the samples' LEAST significant digit plane: it only meets the rows' two upper planes — pairs (0,3) and (1,3) — so an image in
+    // which both of those are all zero does not read it, and its four pieces per image are not fetched: 9 of 33 images at 988 taps, 5 % of the staged bytes)
+    int d_skip3 [2] = { 0, 0 };
     auto next_chunk = [&] () {
         if (issued < total) {
             if (f_seg < 0 || f_ch == f_c1) open_segment ();
             d_va = f_va; d_vb = f_vb;
 #pragma unroll
-            for (int im = 0; im < 2; ++im) d_skip [im] = (wave >> 1) < 2 && !((f_live [wave >> 1] >> (2 * f_ch + im)) & 1ull) ? 0x7ffffff0 : 0;
+            for (int im = 0; im < 2; ++im) {
+                d_skip [im] = (wave >> 1) < 2 && !((f_live [wave >> 1] >> (2 * f_ch + im)) & 1ull) ? 0x7ffffff0 : 0;
+                d_skip3 [im] = !(((f_live [0] | f_live [1]) >> (2 * f_ch + im)) & 1ull) ? 0x7ffffff0 : 0;
+            }
             f_va += 2 * A_STEP; f_vb += 2 * B_STEP;
             ++f_ch; ++issued;
         }
@@ -1078,7 +1084,7 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
 #define I8_SLAB_X_AUX 0
 #endif
         if (pc == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds (f_ra, (lds_ptr_t)(img + wave * 1024), 16, (int)(d_va + (unsigned int) im * A_STEP), d_skip [im], 0, I8_SLAB_A_AUX);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds (f_rb, (lds_ptr_t)(img + SL_A_IMG + (pc - 1) * 8192 + wave * 1024), 16, (int)(d_vb + (unsigned int) im * B_STEP), (pc - 1) * plane_step, 0, I8_SLAB_X_AUX);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds (f_rb, (lds_ptr_t)(img + SL_A_IMG + (pc - 1) * 8192 + wave * 1024), 16, (int)(d_vb + (unsigned int) im * B_STEP), pc == 4 ? (d_skip3 [im] ? d_skip3 [im] : 3 * plane_step) : (pc - 1) * plane_step, 0, I8_SLAB_X_AUX);
     };
 
     {   // the two waves of a SIMD share its matrix pipe: left alone they fall into step (both read, then both multiply);

@@ -5,13 +5,13 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-evidence}
-RND=${2:-r4}
+RND=${2:-r5}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py --steps 100 --warmup 10 > $OUT/bench100.json 2> $OUT/bench100.err
 python $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
-python $R/bench.py --steps 100 --warmup 10 --kernel 6 --no-cpu-baseline > $OUT/bench_f32.json 2> $OUT/bench_f32.err
+python $R/bench.py --steps 100 --warmup 10 --kernel 6 --no-cpu-baseline --no-other-configs > $OUT/bench_f32.json 2> $OUT/bench_f32.err
 prof() {   # name, command...
   local name=$1; shift
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o $name -- "$@" > $OUT/$name.stats.log 2>&1
@@ -28,12 +28,12 @@ allpasses() {  # name, command...
   pmc $name p3 FETCH_SIZE GRBM_GUI_ACTIVE -- "$@"
   pmc $name p4 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- "$@"
 }
-BENCH="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+BENCH="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs"
 prof headline $BENCH
-allpasses headline python $R/bench.py --steps 3 --warmup 1 --preroll-ms 60 --no-cpu-baseline
-pmc headline p2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS -- python $R/bench.py --steps 3 --warmup 1 --preroll-ms 60 --no-cpu-baseline
+allpasses headline python $R/bench.py --steps 3 --warmup 1 --preroll-ms 60 --no-cpu-baseline --no-other-configs
+pmc headline p2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS -- python $R/bench.py --steps 3 --warmup 1 --preroll-ms 60 --no-cpu-baseline --no-other-configs
 prof headline_f32 $BENCH --kernel 6
-allpasses headline_f32 python $R/bench.py --steps 3 --warmup 1 --preroll-ms 60 --no-cpu-baseline --kernel 6
+allpasses headline_f32 python $R/bench.py --steps 3 --warmup 1 --preroll-ms 60 --no-cpu-baseline --no-other-configs --kernel 6
 for c in fixed_D4 fixed_D32 general_E general_P matrix_P general_A matrix_B matrix_D4 matrix_D32 wide biquad biquad_serial decimate strict; do
   python $R/tools/profile_case.py $c > $OUT/case_$c.json 2> $OUT/case_$c.err
   prof $c python $R/tools/profile_case.py $c 12
