@@ -93,6 +93,7 @@ struct ArtRowsCache {
     // the canonical period
     const void *bank; int T, F, interp, P, Q; double ratio;
     int canon_valid, cap;
+    int last_slot, next_slot;             // where the last launch looked up started and where a launch that continues it will (tried before the scan)
     double *c_ph; int *c_ip, *c_fi;       // [cap >= P]
     double c_base; int c_lin; unsigned int c_n0;              // ... as the device evaluates it: epoch offset, ring-to-linear shift, first output
     // the fixed-point kernel's sets built for it
@@ -161,7 +162,14 @@ __attribute__ ((unused)) static bool artfir_rows_canonical (const ArtFirArgs *a_
     if (rc->canon_valid) {
         const double tol = 1e-6, F = (double) a_in->F;
         bool found = false;
-        for (int s = 0; s < P && !found; ++s) {
+        // (a stream's launches follow one another: the slot behind the last launch's outputs first, the last launch's own slot second — the
+        // upkeep and the matrix path look the same launch up twice — and only then the whole period)
+        // (where several periods are taken at a time the period's slots repeat every period_out: the FIRST of the equal slots is the launch's,
+        // whichever way it was found — the choice must not depend on a context's history)
+        const int P0 = a_in->period_out > 0 && P % a_in->period_out == 0 ? a_in->period_out : P;
+        for (int t = -2; t < P0 && !found; ++t) {
+            const int s = t == -2 ? rc->next_slot % P0 : t == -1 ? rc->last_slot % P0 : t;
+            if (s < 0 || s >= P) continue;
             double d = fabs (rc->c_ph [s] - pos0.ph);
             if (d > 0.5 * F) d = F - d;
             if (d > tol) continue;
@@ -192,6 +200,7 @@ __attribute__ ((unused)) static bool artfir_rows_canonical (const ArtFirArgs *a_
         for (int k = 0; k < 4; ++k) rc->valid [k] = 0;
         rc->f_valid = 0;
     }
+    rc->last_slot = slot0; rc->next_slot = (int)(((unsigned int) slot0 + (a_in->n_end - a_in->n_begin)) % (unsigned int) P);
     *slot0_out = slot0; *w_out = w;
     return true;
 }
