@@ -136,7 +136,7 @@ with open(os.path.join(dst, f"{rnd}_roofline.md"), "w") as f:
             "correction) + WRITE_SIZE of the kernel's last dispatch, separate --pmc passes.\n\n")
     f.write("| config | kernel | launches | avg us (rocprofv3) | flop / sample | bytes / sample | achieved vs peak | HBM traffic / algorithmic bytes |\n|---|---|---|---|---|---|---|---|\n")
     for (cfg, k, calls, avg, fl, by, frac, traffic, alg) in rows:
-        short = k.replace("void (anonymous namespace)::", "").split("(")[0] if k else "-"
+        short = k.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0] if k else "-"
         tr = f"{traffic / 1e6:.1f} MB / {alg / 1e6:.1f} MB = {traffic / alg:.2f}" if traffic and alg else "-"
         f.write(f"| {cfg} | `{short}` | {calls} | {avg / 1e3:.1f} | {fl} | {by} | {frac} | {tr} |\n")
 with open(os.path.join(dst, f"{rnd}_pmc_summary.txt"), "w") as f:
