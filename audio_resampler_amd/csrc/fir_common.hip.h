@@ -182,7 +182,7 @@ __device__ __forceinline__ void wave_reduce (double (&v) [NV], int lane)
 __attribute__ ((unused)) __device__ __forceinline__ float fused (float a, float b, float c) { return __builtin_fmaf (a, b, c); }
 __attribute__ ((unused)) __device__ __forceinline__ double fused (double a, double b, double c) { return __builtin_fma (a, b, c); }
 
-// lanes per output frame: 16 up to 256 taps, 32 above (64 — one frame per wave — is what the kernel started with and still
+// lanes per output frame: 16 up to 512 taps (256 until round 5), 32 above (64 — one frame per wave — is what the kernel started with and still
 // instantiates for experiments).  Measured at 1M-frame blocks: 8 ch x 48 taps 15 -> 35 Gsamples/s, stereo x 156 taps 7.7 ->
 // 13.9 (16 lanes); stereo x 380 taps 6.7 -> 8.2, 8 ch x 988 taps 7.5 -> 8.4 (32 lanes): several frames per wave keep more
 // coefficient loads in flight and share the reduction.  The price is latency on calls too small to fill the chip — a
@@ -213,6 +213,9 @@ static inline int artfir_period_multiple (int P, int rows)
     return best;
 }
 
-__host__ __device__ constexpr int general_group (int taps) { return taps <= 256 ? 16 : 32; }
+// (round 5, with the lean tap loop and the DPP reduction: 16 lanes win up to 512 taps — kernel time, 32 | 16 lanes, 65,536-frame calls: stereo x 380 no-lerp
+// 15.1 | 13.1 us, mono 13.3 | 11.4, 4 ch 19.2 | 16.1, 8 ch x 380 interpolating 33.2 | 28.5, stereo x 512 21.4 | 20.1, stereo x 380 interpolating 17.2 | 17.3;
+// a 4,096-frame stereo call 5.3 | 5.6)
+__host__ __device__ constexpr int general_group (int taps) { return taps <= 512 ? 16 : 32; }
 
 } // namespace

@@ -917,7 +917,7 @@ bool artfir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int
         // channels, 2.3x at 8, 5x at 32; one or two channels pay 1.7x at any size — re-fitted to tools/bench_crossover2.py,
         // profiles/r4_dispatch_crossover.txt: the rule had 32 ch x 988 taps on the general kernel up to 5k frames where the
         // matrix path is ahead from 2k on, 1-2 ch x 988 taps up to 100k frames where it is ahead from 45k on)
-        const double k_base = ((0.2 + 0.04 * C) + 0.00007 * C * a->T) * (general_group (a->T) == 16 ? 0.47 : 0.85) * (a->T >= 512 && C <= 2 ? 1.7 : 1.0);
+        const double k_base = ((0.2 + 0.04 * C) + 0.00007 * C * a->T) * (a->T <= 256 ? 0.47 : a->T <= 512 ? 0.74 : 0.85) * (a->T >= 512 && C <= 2 ? 1.7 : 1.0);
         const double k_mid = k_base * (a->T >= 512 && C > 2 ? 1.5 * pow ((double) C / 4.0, 0.6) : 1.0);      // below ~40k outputs
         const double chunks = (a->T + 63) / 32;
         const double floor_ns = 13500.0 + 550.0 * chunks + (C <= 2 ? 2000.0 : 0.0);

@@ -286,7 +286,7 @@ bool artfir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int
     if (a->n_end <= a->n_begin || (a->mode & 3) == ART_MODE_STRICT) return false;
     const unsigned int total = a->n_end - a->n_begin;
     const int Cs = a->stream_C > a->C ? a->stream_C : a->C;     // (a group of a wider stream decides as the stream does)
-    const double k_ns = ((0.2 + 0.05 * Cs) + 0.00021 * Cs * a->T) * (general_group (a->T) == 16 ? 0.55 : a->T <= 512 ? 0.85 : 0.95);
+    const double k_ns = ((0.2 + 0.05 * Cs) + 0.00021 * Cs * a->T) * (a->T <= 256 ? 0.55 : a->T <= 512 ? 0.85 : 0.95);
     const double floor_ns = (15000.0 + 4100.0 * ((a->T + 63) / 32)) * ((Cs + 31) / 32);
     const bool enough = total * k_ns >= floor_ns - 5000.0;
     const bool small = (size_t) a->in_frames * a->C * 8 < 0x7fff0000ull && (size_t) a->H * a->C * 8 < 0x7fff0000ull &&
