@@ -1007,9 +1007,15 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
     // ---- this wave's share of the staging, per 32-tap image: piece `wave` of the rows' 8 KB; of every X plane, 4-tap blocks
     // 2 (wave & 3) and + 1 of column half wave >> 2 (64 lanes = 2 blocks x 32 column quads = 1 KB, lane-linear in the LDS)
     constexpr int VPF = CG / 4;                               // 16-byte vectors per 4-frame block of the stream
+#ifdef I8_ABL_CONTIG     // (TIMING ONLY: every X piece one contiguous kilobyte — what the DMA path delivers when its 64 lanes read consecutive memory)
+    constexpr unsigned int A_STEP = 8192u, B_STEP = 8192u;
+    const int kb = 2 * (wave & 3) + (lane >> 5), colquad = (wave >> 2) * 32 + (lane & 31), m = colquad / VPF, cv = colquad - m * VPF;
+    const unsigned int boff = (unsigned int)(wave * 1024 + lane * 16) + 0u * (unsigned int)(kb + cv);
+#else
     constexpr unsigned int A_STEP = 8192u, B_STEP = (I8_KC / 4) * CG * 4u;
     const int kb = 2 * (wave & 3) + (lane >> 5), colquad = (wave >> 2) * 32 + (lane & 31), m = colquad / VPF, cv = colquad - m * VPF;
     const unsigned int boff = (unsigned int)((m * q.gq4 + kb) * CG + cv * 4) * 4u;           // (the tile's first block sits in the resource base)
+#endif
     const unsigned int a_off = (unsigned int)(wave * 1024 + lane * 16);
     // a column whose period lies d exponent blocks behind the tile's first column stages from that block's own planes: d regions
     // further on, where the same 4-frame block sits d * eb_step blocks earlier
@@ -1074,7 +1080,12 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
         }
         else { f_ra = make_rsrc (nullptr, 0u); f_rb = f_ra; }
     };
+    // (TIMING-ONLY ablation builds, tools/micro/slab_ablation.sh — wrong samples, the schedule with one ingredient taken out:
+    //  I8_ABL_NO_DMA no staging pieces, I8_ABL_NO_READ no LDS operand reads, I8_ABL_NO_MFMA no products, I8_ABL_NO_XCHG no exchange of parts)
     auto piece = [&] (int buf, int idx) {
+#ifdef I8_ABL_NO_DMA
+        return;
+#endif
         const int im = idx / 5, pc = idx % 5;
         unsigned char *img = smem_ + buf * SL_BUF + im * SL_IMG;
 #ifndef I8_SLAB_A_AUX
@@ -1148,7 +1159,14 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
         int shift_v = q.shifts [((j0 + jl * q.g) / q.eb_periods) * CG + c];
 
         i32x4 av [2] [4], bv [4];
+#ifdef I8_ABL_NO_READ
+#pragma unroll
+        for (int pn = 0; pn < 4; ++pn) { av [0] [pn] = i32x4 {lane, pn, 3, 4}; av [1] [pn] = i32x4 {lane, pn, 5, 6}; bv [pn] = i32x4 {pn, lane, 7, 8}; }
+#endif
         auto read_image = [&] (int im) {
+#ifdef I8_ABL_NO_READ
+            if (im >= 0) { asm volatile ("" : "+v" (av [0] [0]), "+v" (av [1] [0]), "+v" (bv [0])); return; }
+#endif
             const unsigned char *Ab = Ab0 + cur * SL_BUF + im * SL_IMG, *Bb = Bb0 + cur * SL_BUF + im * SL_IMG;
 #pragma unroll
             for (int pn = 0; pn < 4; ++pn) {
@@ -1162,6 +1180,10 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
         // between them, one behind every fourth product or so: issued in a burst the pieces of eight waves queue up in front of the
         // CU's one address unit (~20 cycles a piece), and a wave stuck behind them multiplies nothing
         auto products = [&] (int sub, int to, int first) {
+#ifdef I8_ABL_NO_MFMA
+            for (int i = 0; i < 5; ++i) piece (to, first + i);
+            return;
+#endif
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 int n = 0;                                    // products issued so far in this register tile's block
@@ -1238,7 +1260,11 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
 #pragma unroll
             for (int r = 0; r < 16; ++r) tot [h] [r] = i8_total (acc [h] [0] [r], acc [h] [1] [r], acc [h] [2] [r], acc [h] [3] [r], acc [h] [4] [r]);
         TR (9);
+#ifdef I8_ABL_NO_XCHG
+        if (false) {
+#else
         if (c0 != 0 || c1 != nch) {
+#endif
             // ---- part of a tile: leave the sums, count the arrival; the last wave to arrive goes on with everybody's
             constexpr int COHERENT = 1 | 16;                 // (aux bits of the raw buffer instructions on gfx940+: sc0, sc1)
             const int t = within - D * W;
