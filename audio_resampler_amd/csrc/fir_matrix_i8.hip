@@ -998,10 +998,11 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
             c1 = hi - t * nch; if (c1 > nch) c1 = nch;
         }
     };
+    const int g_mask = q.g - 1, g_log2 = q.g >> 1;            // (g = 4 / gcd (Q, 4) is 1, 2 or 4: no divisions by it)
     auto tile_of = [&] (int within, int &st, int &j0) {
         st = within % q.tiles;
-        const int t2 = within / q.tiles, jr = t2 % q.g, sg = xcd * q.sg_per_xcd + t2 / q.g;
-        j0 = sg * q.g * PPW + jr;
+        const int t2 = within / q.tiles, jr = t2 & g_mask, sg = xcd * q.sg_per_xcd + (t2 >> g_log2);
+        j0 = ((sg * PPW) << g_log2) + jr;
     };
 
     // ---- this wave's share of the staging, per 32-tap image: piece `wave` of the rows' 8 KB; of every X plane, 4-tap blocks
@@ -1041,9 +1042,9 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
         const size_t from = (size_t) eb * x_total + skip;
         f_rb = make_rsrc (q.x_planes + from, (unsigned int) min (q.x_bytes - from, (size_t) 0xfffffff0u));
         const unsigned int fa_bytes = (unsigned int) nsub * A_STEP;
-        f_ra = make_rsrc (q.a_planes + (size_t)(st * q.g + (j0 + q.jr_rot) % q.g) * fa_bytes, fa_bytes);
+        f_ra = make_rsrc (q.a_planes + (size_t)(st * q.g + ((j0 + q.jr_rot) & g_mask)) * fa_bytes, fa_bytes);
         {
-            const __attribute__ ((address_space (4))) unsigned long long *tm = (const __attribute__ ((address_space (4))) unsigned long long *) q.tile_masks + (st * q.g + (j0 + q.jr_rot) % q.g) * 2;
+            const __attribute__ ((address_space (4))) unsigned long long *tm = (const __attribute__ ((address_space (4))) unsigned long long *) q.tile_masks + (st * q.g + ((j0 + q.jr_rot) & g_mask)) * 2;
             f_live [0] = tm [0] | tm [1];
             f_live [1] = tm [q.tiles * q.g * 2] | tm [q.tiles * q.g * 2 + 1];
         }
@@ -1150,7 +1151,7 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
         // (through the scalar cache, like the tile table)
         unsigned long long top [2], sec [2];                  // (sec: the same for the second digit plane — zero in the window's tails)
         {
-            const __attribute__ ((address_space (4))) unsigned long long *tm = (const __attribute__ ((address_space (4))) unsigned long long *) q.tile_masks + (st * q.g + (j0 + q.jr_rot) % q.g) * 2;
+            const __attribute__ ((address_space (4))) unsigned long long *tm = (const __attribute__ ((address_space (4))) unsigned long long *) q.tile_masks + (st * q.g + ((j0 + q.jr_rot) & g_mask)) * 2;
             top [0] = tm [0]; top [1] = tm [1];
             sec [0] = tm [q.tiles * q.g * 2]; sec [1] = tm [q.tiles * q.g * 2 + 1];
         }
@@ -1163,18 +1164,36 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
 #pragma unroll
         for (int pn = 0; pn < 4; ++pn) { av [0] [pn] = i32x4 {lane, pn, 3, 4}; av [1] [pn] = i32x4 {lane, pn, 5, 6}; bv [pn] = i32x4 {pn, lane, 7, 8}; }
 #endif
-        auto read_image = [&] (int im) {
+        auto read_image = [&] (int im, int sub) {
 #ifdef I8_ABL_NO_READ
             if (im >= 0) { asm volatile ("" : "+v" (av [0] [0]), "+v" (av [1] [0]), "+v" (bv [0])); return; }
 #endif
             const unsigned char *Ab = Ab0 + cur * SL_BUF + im * SL_IMG, *Bb = Bb0 + cur * SL_BUF + im * SL_IMG;
+            // (only the digit planes this image multiplies: the rows' first plane lives in 4 of 33 images at 988 taps, the second in 24, and the samples'
+            // last plane meets nothing else — the CU's LDS is as busy as its matrix pipes (80 KB of DMA writes and 8 waves x 12 KB of operand reads per
+            // chunk: ~2,200 clocks at 128 B a clock against ~2,150 of products), and two thirds of the reads are the rows, which every wave reads whole)
+            const bool l0 = ((top [0] | top [1]) >> sub) & 1ull, l1 = ((sec [0] | sec [1]) >> sub) & 1ull;
+            // (the conditional reads FIRST: the products that use them come last, and the first products' waits can then be counted — behind a
+            // branch of unknown length the compiler waits for everything)
+            if (l0 | l1) {
+                av [0] [1] = *reinterpret_cast<const i32x4 *> (Ab + 2048);
+                av [1] [1] = *reinterpret_cast<const i32x4 *> (Ab + 2048 + 512);
 #pragma unroll
-            for (int pn = 0; pn < 4; ++pn) {
+                for (int i = 0; i < 4; ++i) bv [3] [i] = *reinterpret_cast<const int *> (Bb + 3 * 8192 + i * 512);
+                if (l0) {
+                    av [0] [0] = *reinterpret_cast<const i32x4 *> (Ab);
+                    av [1] [0] = *reinterpret_cast<const i32x4 *> (Ab + 512);
+                }
+            }
+#pragma unroll
+            for (int pn = 2; pn < 4; ++pn) {
                 av [0] [pn] = *reinterpret_cast<const i32x4 *> (Ab + pn * 2048);
                 av [1] [pn] = *reinterpret_cast<const i32x4 *> (Ab + pn * 2048 + 512);
+            }
+#pragma unroll
+            for (int pn = 0; pn < 3; ++pn)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bv [pn] [i] = *reinterpret_cast<const int *> (Bb + pn * 8192 + i * 512);
-            }
         };
         // the products of one image, and five DMA pieces of the chunk being issued (pieces first .. first + 4 -> buffer `to`) spread
         // between them, one behind every fourth product or so: issued in a burst the pieces of eight waves queue up in front of the
@@ -1226,13 +1245,13 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
         for (int ch = c0; ch < c1; ++ch) {
             TR (0);                                           // (0: everything between chunks — tile set-up, epilogue, exchange)
             // ---- the chunk's first image
-            read_image (0);
+            read_image (0, 2 * ch);
             __builtin_amdgcn_sched_group_barrier (0x100, 16, 0);
             products (2 * ch, cur ^ 1, 5);                    // (with the second five pieces of the chunk announced behind the last barrier)
             TR (4);
             // ---- its second image (a tile's last chunk may have none): operands now, products behind the barrier
             const bool two = 2 * ch + 1 < nsub;
-            if (two) read_image (1);
+            if (two) read_image (1, 2 * ch + 1);
             asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the chunk has been read: its buffer may be written again)
             asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");         // (this wave's pieces of the next chunk have landed)
             if (ch == c0) asm volatile ("" : "+v" (shift_v));   // (the exponent's load is waited for here)
@@ -1241,6 +1260,7 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
             asm volatile ("" ::: "memory");
             TR (2);                                           // (2: the barrier)
             next_chunk ();                                    // the stream's next-but-one chunk -> the buffer just read
+            // (moving this scalar upkeep in front of the barrier, where the faster waves wait anyway, was measured: + 1 .. 2 us, profiles/r5_slab_kernel_trims.txt)
             TR (3);                                           // (3: moving the stream on)
             if (two) products (2 * ch + 1, cur, 0);             // (with the first five pieces)
             else {
