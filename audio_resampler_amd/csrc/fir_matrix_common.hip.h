@@ -183,7 +183,13 @@ __attribute__ ((unused)) static bool artfir_rows_canonical (const ArtFirArgs *a_
             for (int t = 0; t < P && found; ++t) {                // (its first P outputs are slots s, s + 1, ... of the canonical period, wrapping into the next)
                 const unsigned int n = a_in->n_begin + (unsigned int) t;
                 if (n >= a_in->n_end) break;
-                found = host_locate (a_in, segs, n).fi == rc->c_fi [(slot0 + t) % P];
+                // (compared as frame x F + filter: a slot ON an input sample is (ip, F) from a position a hair below it and (ip + 1, 0) from one a hair above —
+                // the bank's row F is row 0 one frame on, the same taps on the same samples — and the two must not count as a stream that has left its
+                // period: an exact-ratio stream whose filters are a multiple of its phases has such slots in every period, and re-founding the period on
+                // whichever launch saw the other spelling first moved the tiles, i.e. the bits, with the way the input was cut into calls)
+                const int sidx = slot0 + t, sp = sidx % P;
+                const HostPos p = host_locate (a_in, segs, n);
+                found = (long long) p.ip * a_in->F + p.fi == ((long long) rc->c_ip [sp] + w + (long long) Q * (sidx / P)) * a_in->F + rc->c_fi [sp];
             }
         if (!found) rc->canon_valid = 0;
     }
