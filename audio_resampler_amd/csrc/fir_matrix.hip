@@ -949,7 +949,10 @@ static int matrix_geometry (const ArtFirArgs *a, MfmaGeom &g)
         g.P = mu * a->period_out; g.Q = mu * a->period_in;
     }
     // compile-time channel count where the whole stream is one column group and the buffers allow vector loads
-    const bool small = (size_t) a->in_frames * a->C * 4 < 0xffff0000ull && ((uintptr_t) a->in % 16) == 0 && ((uintptr_t) a->hist % 16) == 0;
+    // (the staging waves load whole frames of one or two channels, 16-byte vectors of four channels: the input wants that alignment, not more — a stereo
+    // stream handed over at an odd frame of the caller's buffer is still the specialised kernels')
+    const size_t in_align = a->C >= 4 ? 16 : (size_t) a->C * 4;
+    const bool small = (size_t) a->in_frames * a->C * 4 < 0xffff0000ull && ((uintptr_t) a->in % in_align) == 0 && ((uintptr_t) a->hist % 16) == 0;
     const int cgt = (small && (a->C == 1 || a->C == 2 || a->C == 4 || a->C == 8 || a->C == 16 || a->C == 32)) ? a->C : 0;
     g.tile_rows = 32;
     g.slot_tiles = (g.P + g.tile_rows - 1) / g.tile_rows;

@@ -63,7 +63,7 @@ void resampleHipSynchronize (Resample *cxt);
 void resampleHipSetKernel (Resample *cxt, int which);
 /* (6 on a fixed-ratio stream — resampleFixedRatioInit — also makes the output independent of how the input is cut into calls, bit for bit, as the
  * reference's is: every launch runs the one kernel on tiles anchored on the stream's canonical period.  Calls of at least one period of outputs;
- * device-pointer input 16-byte aligned.  resampler.h's header; tests/test_gpu_cut_invariance.py) */
+ * device-pointer input aligned to a frame (1 - 2 channels) / 16 bytes (4 and more).  resampler.h's header; tests/test_gpu_cut_invariance.py) */
 /* The streaming matrix kernels keep their filter rows across the calls of a context (built once for the stream's canonical period; every later
  * launch is anchored on that period: DESIGN.md 4.1) — on by default.  Off: every launch builds its rows from its own positions and anchors its
  * tiles on its own first output, as before round 5 (comparisons of kernel forms bit for bit; ARTAMD_ROWS_CACHE=0 does it for a whole process).

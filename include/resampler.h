@@ -18,8 +18,8 @@
  * kernels keep their filter rows across calls and anchor every launch's tiles on the stream's canonical period —
  * on the f32 matrix-core streaming kernel alone (resampleHipSetKernel (cxt, 6), art_hip.h): a stream initialised
  * with resampleFixedRatioInit gives the same bits for any cut into calls of at least one period of outputs
- * (1,000 frames is plenty), from host buffers of any length or from 16-byte aligned device buffers
- * (tests/test_gpu_cut_invariance.py).  In the DEFAULT mode
+ * (1,000 frames is plenty), from host buffers of any length or from device buffers aligned to a frame (one or
+ * two channels) / to 16 bytes (four channels and more) (tests/test_gpu_cut_invariance.py).  In the DEFAULT mode
  * the size of a call picks the kernel (general / f32 matrix cores / fixed point on the integer matrix
  * cores), each of which rounds differently inside the parity bar: the same stream cut into other blocks
  * gives output that is within 2^-23 max(1,|y|) of the double-accumulate result either way — two cuts differ
