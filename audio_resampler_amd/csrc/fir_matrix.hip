@@ -810,11 +810,11 @@ void fir_mfma_split_kernel (ArtFirArgs a, MfmaGeom g, int wgs_per_xcd, int KS, d
         // every part's sums, in the order of the parts (all loads of a register pair in flight together)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sum [r] = 0.0;
-        for (int k0 = 0; k0 < KS; k0 += 2) {                  // (KS is 2, 4 or 8: two parts at a time, 16 loads in flight)
+        for (int k0 = 0; k0 < KS; k0 += 2) {                  // (two parts at a time, 16 loads in flight; an odd count's last pair: the second reads an empty resource — zeros)
             u32x4 v [2] [8];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                const __amdgpu_buffer_rsrc_t rs_part = make_rsrc (reinterpret_cast<char *> (partials) + (size_t)(tile_g * KS + k0 + kk) * part_bytes, (unsigned int) part_bytes);
+                const __amdgpu_buffer_rsrc_t rs_part = make_rsrc (reinterpret_cast<char *> (partials) + (size_t)(tile_g * KS + k0 + kk) * part_bytes, k0 + kk < KS ? (unsigned int) part_bytes : 0u);
 #pragma unroll
                 for (int r2 = 0; r2 < 8; ++r2) v [kk] [r2] = __builtin_amdgcn_raw_buffer_load_b128 (rs_part, (r2 * MF_THREADS + pt) * 16, 0, COHERENT);
             }
@@ -998,15 +998,30 @@ static int matrix_split_parts (const ArtFirArgs *a, const MfmaGeom &g, unsigned 
     const int C = a->stream_C > a->C ? a->stream_C : a->C;
     const double periods = ceil ((double) outputs / g.P);
     const double cols = C >= 2 ? 128.0 : 64.0;                                   // (mono: 64 periods per tile, half the columns idle)
-    const double tiles = g.slot_tiles * ceil (periods * C / cols);
+    const double groups = ceil (periods * C / cols), tiles = g.slot_tiles * groups;
     const int nchunks = g.ktot / MF_KC;
-    int ks = (tiles >= 50 && tiles <= 110 && nchunks >= 16) ? 2 : 1;
+    // As many parts as keep an XCD's items within ONE round of its 32 CUs (a tile walked alone is a chain of ~0.6 us a chunk whatever else the chip does;
+    // a second round of items costs more than the parts save), at most four, four chunks a part at least.  Re-fitted in round 5 (tools/micro/split_sweep.sh,
+    // profiles/r5_split_rule.txt): the rule had been "two parts from 50 to 110 tiles" — which left 8 ch x 988 taps at 12,288 - 16,384 frames (ART's block) and
+    // 32 ch at 4,096 unsplit (22.9 / 25.4 us a call where three parts take 19.2 / 19.9) and split 40,960 - 49,152 frames (9 - 11 period groups: two per XCD,
+    // 40 items on 32 CUs) into two rounds (29.5 - 30.1 us where the uncut launch takes 23.6).
+    // Long filters only: at 14 chunks a tile (380 taps) three parts LOSE 12 % (16.1 against 14.3 us), at 18 (512 taps) 3 %; at 33 (988 taps) they win 16 - 26 %.
+    int ks = 1;
+    if (nchunks >= 24) {
+        const int gpx = (int) ceil (groups / 8.0);
+        int k = 32 / (gpx * g.slot_tiles);
+        if (k > 4) k = 4;
+        if (k >= 2) ks = k;
+    }
     if (kernel_pref == 8) {                                   // (forced: the library's own parts where it splits, else as many as fill the chip)
         if (ks == 1) ks = tiles * 8 <= 768 ? 8 : tiles * 4 <= 768 ? 4 : 2;
         static const int k_env = [] { const char *e = getenv ("ARTAMD_SPLIT_KS"); return e && *e ? atoi (e) : 0; } ();
         if (k_env > 0) ks = k_env;
     }
-    while (ks > 1 && nchunks / ks < 4) ks >>= 1;
+    {   static const int force = [] { const char *e = getenv ("ARTAMD_SPLIT_FORCE_KS"); return e && *e ? atoi (e) : 0; } ();      // (A/B runs)
+        if (force > 0 && kernel_pref != 8) return force;
+    }
+    while (ks > 1 && nchunks / ks < 4) --ks;
     return ks;
 }
 

@@ -1,6 +1,6 @@
 """GPU (-m gpu): fir_mfma_split_kernel — the f32 streaming kernel for launches of few tiles (calls of some ten thousand frames), a
-tile's K range cut into 2 / 4 / 8 work items whose fp64 partial sums the last-arriving wave adds in the order of the parts.
-Kernel preference 8 forces it wherever the matrix path runs; the library's own choice (0 / 2) takes it below ~768 / parts tiles.
+tile's K range cut into 2 .. 8 work items whose fp64 partial sums the last-arriving wave adds in the order of the parts.
+Kernel preference 8 forces it wherever the matrix path runs; the library's own choice (0 / 2) takes it where the parts of an XCD's tiles fit one round of its 32 CUs (long filters only).
 Against the double-accumulate oracle (the parity bar), against the unsplit streaming kernel (a part starts its own f32 accumulators where
 the unsplit walk carries one through the rows' tails: last-bit differences in some outputs, both inside the bar), and against itself (the
 result must not depend on which part arrives last: repeated runs give the same bits)."""
@@ -64,8 +64,8 @@ def test_split_kernel_meets_the_bar_and_does_not_depend_on_the_order_of_arrival(
 
 
 def test_the_library_takes_the_split_kernel_where_it_was_measured_to_win_and_only_there():
-    """8 ch x 988 taps: the 32,768-frame call (70 tiles: half the CUs idle through a K walk) runs in two parts — the forced split kernel's
-    bits; the 65,536-frame call (140 tiles) does not — the streaming kernel's bits"""
+    """8 ch x 988 taps: the 32,768-frame call (70 tiles: half the CUs idle through a K walk) runs in three parts — the forced split kernel's
+    bits; the 65,536-frame call (140 tiles: two period groups per XCD, 20 tiles — their parts would need a second round) does not — the streaming kernel's bits"""
     ch, T = 8, 988
     ratio = 48000 / 44100
     for frames, same_as in ((32768, 8), (65536, 6)):
