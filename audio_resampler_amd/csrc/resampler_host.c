@@ -30,6 +30,7 @@
  * output written there by the FIR kernels themselves, no copy-engine command at all —; larger ones are copied straight
  * from / to the caller's memory */
 #define KERNEL_COPY_LIMIT ((size_t) 1 << 20)     /* staged transfers up to this size are made by a copy kernel, not a copy-engine command */
+#define DIRECT_OUT_LIMIT ((size_t) 1 << 20)      /* staged outputs up to this size are written by the FIR kernels straight into the page-locked buffer */
 #define STAGE_LIMIT ((size_t) 3 << 19)          /* 1.5 MB: measured on MI355X hosts, 8 ch x 988 taps: 16,384-frame calls 107 -> 92 us staged, 65,536-frame
                                                  * calls 176 us direct vs 235-378 staged (the CPU's own copies into and out of the staging cost more than
                                                  * the runtime's pipelined pageable path saves).  Environment ARTAMD_STAGE_LIMIT=bytes overrides (tests) */
@@ -1837,7 +1838,9 @@ static void host_begin (Resample *cxt, const art_s *input, int in_stride, const 
     TRACE_MARK (2);
     /* small staged calls: the FIR kernels write their output straight into the page-locked buffer (it is mapped into the
      * device's address space; one launch and its dependency gap less than copying it out afterwards) */
-    const int direct_out = staged && sizeof (art_s) * out_samples <= KERNEL_COPY_LIMIT && !hip->nshards;
+    static long direct_limit = -1;                             /* (ARTAMD_DIRECT_OUT_LIMIT=bytes: A/B runs) */
+    if (direct_limit < 0) { const char *e = getenv ("ARTAMD_DIRECT_OUT_LIMIT"); direct_limit = e && *e ? atol (e) : (long) DIRECT_OUT_LIMIT; }
+    const int direct_out = staged && sizeof (art_s) * out_samples <= (size_t) direct_limit && !hip->nshards;
     pend->res = hip->nshards ? sharded_device_call (cxt, hip->d_in, 0, nIn, hip->d_out, 0, cap, ratio)
                              : enqueue_call (cxt, hip->d_in, 0, nIn, direct_out ? hip->h_out : hip->d_out, 0, cap, ratio);
     pend->failed = 0;
