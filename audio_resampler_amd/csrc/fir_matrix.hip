@@ -922,7 +922,11 @@ bool artfir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int
         const double chunks = (a->T + 63) / 32;
         const double floor_ns = 13500.0 + 550.0 * chunks + (C <= 2 ? 2000.0 : 0.0);
         // (one threshold, so that a longer call never goes back to the general kernel)
-        const double need = (floor_ns - 5000.0) / k_mid < 40000.0 ? (floor_ns - 5000.0) / k_mid : (floor_ns - 5000.0) / k_base;
+        double need = (floor_ns - 5000.0) / k_mid < 40000.0 ? (floor_ns - 5000.0) / k_mid : (floor_ns - 5000.0) / k_base;
+        // (round 5: filters of 24 chunks and more — 704 taps — have their mid-sized launches cut into three parts (matrix_split_parts) and their rows kept across
+        // calls: the matrix path's floor fell from ~23 to ~19.3 us a call and the crossover with it — tools/micro/crossover_r5.sh, profiles/r5_crossover.txt:
+        // 8 ch x 988 taps from ~7k frames (was ~11k: the 8,192-frame call 22.6 -> 19.1 us), 4 ch ~17k (was ~30k: 24,576 frames 26.0 -> 19.9), 2 ch ~27k, mono ~38k, 16 ch ~3.5k)
+        if ((a->T + 64) / 32 >= 24) need *= C >= 16 ? 0.8 : 0.62;
         enough = (double) total >= need;
     }
     else {

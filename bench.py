@@ -355,8 +355,19 @@ def main():
     # ("preroll_ms"); --preroll-ms 0 disables it (value == a second cold-ish run then).
     if args.preroll_ms > 0:
         t_pre = time.perf_counter()
+        pre_calls = 0
         while (time.perf_counter() - t_pre) * 1e3 < args.preroll_ms:
             for _ in range(8):
+                rs.process_device(d_in, block, d_out, cap, ratio)
+            pre_calls += 8
+            torch.cuda.synchronize()
+        if dist is not None:
+            # (the pre-roll is bounded by time, so ranks make different numbers of calls — and a call's frame count depends on the stream's phase
+            # (1,048,576 x 160 / 147 is not whole): every rank goes on to the longest rank's count, so that all streams enter the timed region at the
+            # same position and the ranks' frame counts agree whatever K is)
+            n_pre = torch.tensor([pre_calls], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(n_pre, op=dist.ReduceOp.MAX)
+            for _ in range(int(n_pre.item()) - pre_calls):
                 rs.process_device(d_in, block, d_out, cap, ratio)
             torch.cuda.synchronize()
     dt, out_frames, kernel_ms, launches, prep_ms = timed_region()
