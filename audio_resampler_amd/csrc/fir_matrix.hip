@@ -1075,6 +1075,23 @@ size_t artfir_planes_bytes (const ArtFirArgs *a_, unsigned int outputs, int kern
     if (off) return 0;
     MfmaGeom g;
     const int cgt = matrix_geometry (a, g);
+    if (cgt && kernel_pref != 7) {
+        // Mid-sized calls (round 5, tools/micro/fixed_crossover_r5.sh, profiles/r5_fixed_crossover.txt): the f32 streaming kernel's time is a staircase — a round of 32
+        // tiles per XCD costs the same however full it is — and where its rounds are well filled it beats the fixed-point path, whose time grows smoothly with the
+        // samples: 8 ch x 988 taps at 196,608 frames 41.9 against 47.7 us a call, 16 ch at 81,920 - 98,304 40.5 against 49.5, 32 ch at 49,152 44.3 against 54.3,
+        // 8 ch x 512 taps at 196,608 28.5 against 40.1.  Two fitted models (us a call; the stream's size, so that a shard decides as its stream would), the f32 kernel
+        // taken where it is ahead by 8 % and more; from ~3 M samples a call on the fixed-point path is ahead everywhere.
+        const int Cs = a_->stream_C > a_->C ? a_->stream_C : a_->C;      // (the stream's own channel count: not a group's padded width)
+        const double periods = ceil ((double) outputs / g.P), groups = ceil (periods * Cs / 128.0);
+        const double rounds = ceil (ceil (groups / 8.0) * g.slot_tiles / 32.0), nchunks = g.ktot / MF_KC;
+        const double t_f32 = 7.5 + rounds * (0.45 * nchunks + 1.8);
+        const double ks = (double) outputs * a->period_in / a->period_out * Cs * 1e-3;       // thousands of input samples of the call
+        const double t_fixed = (ks < 1150.0 ? 20.0 + 0.0145 * ks : 33.0 + 0.0105 * ks) * (0.68 + 0.32 * a->T / 988.0);
+        static const bool model_off = [] { const char *e = getenv ("ARTAMD_FIXED_MODEL"); return e && *e == '0'; } ();
+        // (streams of a compiled width only: others run as several group launches, which the f32 model does not describe; the stream's width, so that its shards agree)
+        const bool one_launch = Cs == 4 || Cs == 8 || Cs == 16 || Cs == 32;
+        if (!model_off && one_launch && t_f32 < 0.92 * t_fixed) return 0;
+    }
     return cgt ? artfir_i8_bytes (a, g, cgt, outputs) : 0;
 }
 

@@ -26,15 +26,17 @@ def test_a_channel_is_the_same_in_a_group_and_in_a_stream_of_a_compiled_width(ch
     sizes = [150000, 3000, 60000] if ch < 33 else [40000, 3000, 20000]
     x, _ = noise(sum(sizes) * wide, state=ch * 77 + 1); x = x.reshape(-1, wide)
     if wide > 32:                                               # (a 64-channel stream is two groups of 32 itself: compare with a 32-channel one)
-        narrow = HipResampler(ch, T, T, 0.0, BH | INTERP, kernel=2); narrow.advance(T / 2)
-        ref = HipResampler(32, T, T, 0.0, BH | INTERP, kernel=2); ref.advance(T / 2)
+        # (kernel preference 7 — the fixed-point kernel wherever it can run — in all three: the library's own choice between the f32 and the fixed-point kernels
+        # follows the STREAM's size (a model of both kernels' times since round 5), which a 33-, a 32- and a 64-channel stream do not share at every call size)
+        narrow = HipResampler(ch, T, T, 0.0, BH | INTERP, kernel=7); narrow.advance(T / 2)
+        ref = HipResampler(32, T, T, 0.0, BH | INTERP, kernel=7); ref.advance(T / 2)
         ya, ka = _run(narrow, np.ascontiguousarray(x[:, :ch]), sizes)
         yb, kb = _run(ref, np.ascontiguousarray(x[:, :32]), sizes)
         assert np.array_equal(ya[:, :32].view(np.uint32), yb.view(np.uint32)), (ka, kb)
         assert all(k[0] == 2 for k in ka)
         # the channels of the LAST group (one channel wide here, copied into a 4-wide buffer): what the same channels give in the
         # second group of a 64-channel stream (the kernel family follows the STREAM's size, so a stream of a similar size is the reference)
-        full = HipResampler(wide, T, T, 0.0, BH | INTERP, kernel=2); full.advance(T / 2)
+        full = HipResampler(wide, T, T, 0.0, BH | INTERP, kernel=7); full.advance(T / 2)
         yc, kc = _run(full, x, sizes)
         # (like for like: the kernel family AND the f32 kernels' K split follow the stream's size, which a 33- and a 64-channel stream do
         # not share at every call size; the first call runs the fixed-point kernel in both — whose bits depend on no launch geometry)
