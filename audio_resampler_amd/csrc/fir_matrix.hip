@@ -1086,7 +1086,7 @@ size_t artfir_planes_bytes (const ArtFirArgs *a_, unsigned int outputs, int kern
         const double rounds = ceil (ceil (groups / 8.0) * g.slot_tiles / 32.0), nchunks = g.ktot / MF_KC;
         const double t_f32 = 7.5 + rounds * (0.45 * nchunks + 1.8);
         const double ks = (double) outputs * a->period_in / a->period_out * Cs * 1e-3;       // thousands of input samples of the call
-        const double t_fixed = (ks < 1150.0 ? 20.0 + 0.0145 * ks : 33.0 + 0.0105 * ks) * (0.68 + 0.32 * a->T / 988.0);
+        const double t_fixed = (20.0 + 0.0145 * ks) * (0.68 + 0.32 * a->T / 988.0);
         static const bool model_off = [] { const char *e = getenv ("ARTAMD_FIXED_MODEL"); return e && *e == '0'; } ();
         // (streams of a compiled width only: others run as several group launches, which the f32 model does not describe; the stream's width, so that its shards agree)
         const bool one_launch = Cs == 4 || Cs == 8 || Cs == 16 || Cs == 32;

@@ -1427,7 +1427,9 @@ bool artfir_i8_slab_enabled ()
 // fill the chip better and walk their K range sooner)
 static int i8_slab_min_tiles ()
 {
-    static const int v = [] { const char *e = getenv ("ARTAMD_I8_SLAB_MIN"); return e && *e ? atoi (e) : 16; } ();
+    // (16 until round 5: re-measured with the rows kept across calls, tools/micro/fixed_crossover_r5.sh + ARTAMD_I8_SLAB_MIN — at 20 slabs per XCD the 32-slot kernels are
+    // ahead: 8 ch x 988 taps at 196,608 frames 42.0 against 48.0 us a call, 16 ch at 98,304 40.0 against 56.9, 4 ch at 393,216 46.1 against 49.4; at 30 they are level)
+    static const int v = [] { const char *e = getenv ("ARTAMD_I8_SLAB_MIN"); return e && *e ? atoi (e) : 24; } ();
     return v;
 }
 
