@@ -927,6 +927,10 @@ bool artfir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int
         // calls: the matrix path's floor fell from ~23 to ~19.3 us a call and the crossover with it — tools/micro/crossover_r5.sh, profiles/r5_crossover.txt:
         // 8 ch x 988 taps from ~7k frames (was ~11k: the 8,192-frame call 22.6 -> 19.1 us), 4 ch ~17k (was ~30k: 24,576 frames 26.0 -> 19.9), 2 ch ~27k, mono ~38k, 16 ch ~3.5k)
         if ((a->T + 64) / 32 >= 24) need *= C >= 16 ? 0.8 : 0.62;
+        // (shorter filters, tools/micro/crossover_short_r5.sh, profiles/r5_crossover.txt: without the prepare launch the matrix path's floor is ~14 us at 380 taps,
+        // ~12.7 at 256 — 8 ch x 380 taps from ~19k frames instead of ~27k (24,576 frames 16.6 -> 14.2 us), 32 ch from ~6k (8,192 frames 22.0 -> 15.0), 8 ch x 256 from
+        // ~29k (32,768 frames 15.0 -> 12.7); 512 .. 703 taps the other way: 8 ch x 512 at 12,288 frames is the general kernel's, 13.5 against 16.9 us)
+        else need *= a->T < 512 ? (C <= 2 ? 0.85 : 0.7) : 1.15;
         enough = (double) total >= need;
     }
     else {
