@@ -1094,7 +1094,9 @@ size_t artfir_planes_bytes (const ArtFirArgs *a_, unsigned int outputs, int kern
         static const bool model_off = [] { const char *e = getenv ("ARTAMD_FIXED_MODEL"); return e && *e == '0'; } ();
         // (streams of a compiled width only: others run as several group launches, which the f32 model does not describe; the stream's width, so that its shards agree)
         const bool one_launch = Cs == 4 || Cs == 8 || Cs == 16 || Cs == 32;
-        if (!model_off && one_launch && t_f32 < 0.92 * t_fixed) return 0;
+        // (fitted, and used, up to 3 M samples a call: beyond, the slab kernel's slope is lower than this line's and the product rule above stands — a first
+        // version without the bound sent 8 ch x 380 taps and 16 ch x 512 taps at 1M frames to the f32 kernel: 81.6 against 75.7 and 197 against 178 us)
+        if (!model_off && one_launch && ks <= 3000.0 && t_f32 < 0.92 * t_fixed) return 0;
     }
     return cgt ? artfir_i8_bytes (a, g, cgt, outputs) : 0;
 }
