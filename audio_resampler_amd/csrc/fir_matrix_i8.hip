@@ -1368,11 +1368,16 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
         // 128-byte lines per eight lanes of an 8-channel stream.
         TR (11);
         {
-            const int qm = lane & 3;                          // this lane's place in its quad = the slot it ends up with
+            int lane_e = lane;                                // (an opaque copy: see q_off below)
+            asm volatile ("" : "+v" (lane_e));
+            const int qm = lane_e & 3;                        // this lane's place in its quad = the slot it ends up with
             // (a launch on rows kept across calls starts mid-period: the slots of its first period in front of its first output are not stored —
             // the first CG columns of the first wave of the launch's first period group: a scalar bound and a test on the lane's own number)
             const int lo = a.n_skip != 0 && j0 == 0 && wave == 0 ? a.n_skip - st * 64 : 0;
-            const unsigned int q_off = (unsigned int)((jl * q.g * g.P + 4 * (lane >> 5) + qm) * CG + (c & ~3)) * 4u;
+            // (the lane's period and channel worked out afresh from its number: carried from the top of the kernel, jl * g was the one register the tile loop
+            // left no room for — a spill stored in front of the loop and read back here for every tile)
+            const int col_e = wave * 32 + (lane_e & 31), jl_e = col_e / CG, c_e = col_e - jl_e * CG;
+            const unsigned int q_off = (unsigned int)((((jl_e << g_log2) * g.P) + 4 * (lane_e >> 5) + qm) * CG + (c_e & ~3)) * 4u;
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
