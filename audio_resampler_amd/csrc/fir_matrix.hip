@@ -834,11 +834,15 @@ void fir_mfma_split_kernel (ArtFirArgs a, MfmaGeom g, int wgs_per_xcd, int KS, d
         const __amdgpu_buffer_rsrc_t rs_out = make_rsrc (a.out + (size_t) n_tile * CG, left > 0xffffff00ull ? 0xffffff00u : (unsigned int) left);
         const unsigned int pass_rows = PASS ? (unsigned int) g.tile_w0 [3 * st + 1] : 0u;
         const int lo = a.n_skip != 0 && jg == 0 && wave == 0 ? a.n_skip - st * 32 : 0;      // (a launch on rows kept across calls starts mid-period: fir_i8_stream_kernel's epilogue)
+        // (the lane's half, opaque and per item: as a loop invariant the sixteen slot numbers below were computed in front of the item loop, spilled — this kernel has
+        // no register to spare — and read back from scratch one by one, a round trip per output register: ~3 us a tile)
+        int half = lane >> 5;
+        asm volatile ("" : "+v" (half));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i_const = (r & 3) + 8 * (r >> 2);      // compile-time part of the slot
             float y = (float) sum [r];
-            const int i = i_const + 4 * (lane >> 5);
+            const int i = i_const + 4 * half;
             if constexpr (PASS) {
                 if ((pass_rows >> i) & 1u)
                     y = load_frame (a, INT_MIN, g.canon_ip [st * 32 + i] + g.w_shift + g.canon_fi [st * 32 + i] / a.F + (jg * PPW + jl) * g.Q, c);
