@@ -650,13 +650,16 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
         // They sit in the first CG columns of the first matrix wave of the launch's first period group: a scalar bound — 0 everywhere else —
         // and a test on the lane's own number, nothing kept live through the tile loop)
         const int lo = a.n_skip != 0 && j0 == 0 && wave == 0 ? a.n_skip - st * 32 : 0;
+        // (the lane's half, opaque and per tile: as loop invariants the slot numbers below were computed in front of the tile loop, spilled and read back per tile)
+        int half = lane >> 5;
+        asm volatile ("" : "+v" (half));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i_const = (r & 3) + 8 * (r >> 2);      // compile-time part of the slot
             // class sums, weights 256^(4 - s), as one exact 64-bit integer, scaled back by the rows' and the channel's exponents (a
             // power of two: exact) and rounded ONCE to float — the same arithmetic in every fixed-point kernel: the same bits
             float y = i8_round (i8_total (acc [0] [r], acc [1] [r], acc [2] [r], acc [3] [r], acc [4] [r]), out_exp);
-            const int i = i_const + 4 * (lane >> 5);
+            const int i = i_const + 4 * half;
             if constexpr (PASS) {
                 // nearest-filter mode, the position falls exactly on an input sample: the reference copies it (resampler.c:1141-1142)
                 if ((pass_rows >> i) & 1u)
@@ -885,11 +888,14 @@ void fir_i8_dma_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
         // They sit in the first CG columns of the first matrix wave of the launch's first period group: a scalar bound — 0 everywhere else —
         // and a test on the lane's own number, nothing kept live through the tile loop)
         const int lo = a.n_skip != 0 && j0 == 0 && wave == 0 ? a.n_skip - st * 32 : 0;
+        // (the lane's half, opaque and per tile: as loop invariants the slot numbers below were computed in front of the tile loop, spilled and read back per tile)
+        int half = lane >> 5;
+        asm volatile ("" : "+v" (half));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i_const = (r & 3) + 8 * (r >> 2);      // compile-time part of the slot
             float y = i8_round (i8_total (acc [0] [r], acc [1] [r], acc [2] [r], acc [3] [r], acc [4] [r]), out_exp);
-            const int i = i_const + 4 * (lane >> 5);
+            const int i = i_const + 4 * half;
             if constexpr (PASS) {
                 if ((pass_rows >> i) & 1u)
                     y = load_frame (a, INT_MIN, g.canon_ip [st * 32 + i] + g.w_shift + g.canon_fi [st * 32 + i] / a.F + (j0 + jl * q.g) * g.Q, c);
