@@ -210,6 +210,10 @@ typedef struct { ArtStretchArgs args; const art_s *in; art_s *out; double ratio;
 typedef struct { int made, pad; ArtStretchState state [2]; } ArtStretchDone;
 int arthip_stretch_batch (const ArtStretchItem *d_items, ArtStretchDone *d_done, int n, void *stream);
 
+/* a failure of an entry point that cannot return one (the reference's ABI has no error codes): printed, counted (artamdErrorCount /
+ * artamdLastError), fatal under ARTAMD_ABORT_ON_ERROR=1 — pcm_host.c */
+void artamd_note_failure (const char *what);
+
 int arthip_ingest (const unsigned char *d_in, art_s gain_factor, int bits, int bytes, int stride, art_s *d_out, int n, void *stream);
 
 #ifdef __cplusplus

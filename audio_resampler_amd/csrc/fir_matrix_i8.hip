@@ -1089,12 +1089,24 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
     };
     // (TIMING-ONLY ablation builds, tools/micro/slab_ablation.sh — wrong samples, the schedule with one ingredient taken out:
     //  I8_ABL_NO_DMA no staging pieces, I8_ABL_NO_READ no LDS operand reads, I8_ABL_NO_MFMA no products, I8_ABL_NO_XCHG no exchange of parts)
+#ifdef I8_ABL_XRES
+    int abl_n = 0;
+#endif
     auto piece = [&] (int buf, int idx) {
 #ifdef I8_ABL_NO_DMA
         return;
 #endif
         const int im = idx / 5, pc = idx % 5;
         unsigned char *img = smem_ + buf * SL_BUF + im * SL_IMG;
+#ifdef I8_ABL_XRES
+        // (TIMING ONLY, round 6: the staging traffic of an X-RESIDENT tile of 64 slots x 128 columns cut in two along K between the wave groups —
+        // per image-step of 8 x 17 products TWO images of the rows (16 KB less their zero planes) and 1 / 41 of a 107 KB span of X (one 1 KB piece
+        // per wave every third image) instead of 8 + 32 KB.  Wrong samples.)
+        // (I8_ABL_XRES == 2: ONE image of the rows per step — a 256-column resident tile, which no LDS holds: the floor of the idea)
+        if (pc == 0 || (pc == 1 && I8_ABL_XRES == 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds (f_ra, (lds_ptr_t)(img + pc * SL_A_IMG + wave * 1024), 16, (int)(d_va + (unsigned int)(im + 2 * pc) * A_STEP), d_skip [im], 0, 0);
+        else if (pc == 2 && (abl_n++ % 3) == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds (f_rb, (lds_ptr_t)(img + 2 * SL_A_IMG + wave * 1024), 16, (int)(d_vb + (unsigned int) im * B_STEP), 0, 0, 0);
+        return;
+#endif
 #ifndef I8_SLAB_A_AUX
 #define I8_SLAB_A_AUX 0
 #endif
@@ -1184,8 +1196,18 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
             if (l0 | l1) {
                 av [0] [1] = *reinterpret_cast<const i32x4 *> (Ab + 2048);
                 av [1] [1] = *reinterpret_cast<const i32x4 *> (Ab + 2048 + 512);
+#if defined (I8_ABL_XRES) && !defined (I8_ABL_XRES_NOALIGN)
+                {
+                    int d5 [5];
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) d5 [i] = *reinterpret_cast<const int *> (Bb + 3 * 8192 + i * 512);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bv [3] [i] = (int) __builtin_amdgcn_alignbyte ((unsigned int) d5 [i + 1], (unsigned int) d5 [i], (unsigned int)(lane & 3));
+                }
+#else
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bv [3] [i] = *reinterpret_cast<const int *> (Bb + 3 * 8192 + i * 512);
+#endif
                 if (l0) {
                     av [0] [0] = *reinterpret_cast<const i32x4 *> (Ab);
                     av [1] [0] = *reinterpret_cast<const i32x4 *> (Ab + 512);
@@ -1196,10 +1218,22 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
                 av [0] [pn] = *reinterpret_cast<const i32x4 *> (Ab + pn * 2048);
                 av [1] [pn] = *reinterpret_cast<const i32x4 *> (Ab + pn * 2048 + 512);
             }
+#if defined (I8_ABL_XRES) && !defined (I8_ABL_XRES_NOALIGN)
+            // (a column of a resident span starts at any frame: five dwords and four v_alignbyte_b32 per plane instead of four dwords)
+#pragma unroll
+            for (int pn = 0; pn < 3; ++pn) {
+                int d5 [5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) d5 [i] = *reinterpret_cast<const int *> (Bb + pn * 8192 + i * 512);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bv [pn] [i] = (int) __builtin_amdgcn_alignbyte ((unsigned int) d5 [i + 1], (unsigned int) d5 [i], (unsigned int)(lane & 3));
+            }
+#else
 #pragma unroll
             for (int pn = 0; pn < 3; ++pn)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bv [pn] [i] = *reinterpret_cast<const int *> (Bb + pn * 8192 + i * 512);
+#endif
         };
         // the products of one image, and five DMA pieces of the chunk being issued (pieces first .. first + 4 -> buffer `to`) spread
         // between them, one behind every fourth product or so: issued in a burst the pieces of eight waves queue up in front of the

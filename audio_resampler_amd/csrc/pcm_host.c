@@ -38,6 +38,8 @@ static void pcm_fail (const char *what)
     pthread_mutex_unlock (&pcm_error_lock);
     if (fatal) abort ();
 }
+/* (the resampler's entry points report a failed launch the same way: resampler_host.c) */
+void artamd_note_failure (const char *what) { pcm_fail (what); }
 int artamdErrorCount (void) { return __atomic_load_n (&pcm_errors, __ATOMIC_RELAXED); }
 const char *artamdLastError (void)
 {

@@ -455,6 +455,9 @@ static Resample *init_leaf (int numChannels, int numTaps, int numFilters, double
     cxt->outputOffset = numTaps / 2;
     cxt->inputIndex = numTaps;
     hip->device = arthip_current_device ();
+    // (A/B runs and the PCM-level tests of programs that cannot call resampleHipSetKernel — the reference's own art / artest binaries:
+    // ARTAMD_KERNEL=<n> is the kernel preference every new context starts with, see include/art_hip.h)
+    { const char *env = getenv ("ARTAMD_KERNEL"); if (env && *env) hip->kernel_pref = atoi (env); }
     if (private_stream) { hip->stream = arthip_stream_create (); hip->own_stream = hip->stream != NULL; }
 
     /* the bank: shared on the device, a private host copy exposed through the reference's `filters` row-pointer table */
@@ -1170,7 +1173,7 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
         nseg = artamdPlanCall (&trial, nIn, cap, ratio, &res, hip->segs, hip->seg_cap, &lin_floor);
         if (nseg <= hip->seg_cap) break;
         ArtamdSegment *grown = realloc (hip->segs, sizeof (ArtamdSegment) * (size_t)(nseg + 16));
-        if (!grown) { fprintf (stderr, "artamd: out of memory (segment table)\n"); res.input_used = res.output_generated = 0; return res; }
+        if (!grown) { artamd_note_failure ("resampler: out of memory (segment table)"); res.input_used = res.output_generated = 0; return res; }
         hip->segs = grown; hip->seg_cap = nseg + 16;
     }
 
@@ -1320,7 +1323,12 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
                     whole = 0; s0 = -ART_MAX_SEGS; continue;
                 }
                 if (k >= 0 && (k & ART_FIR_ROLLED)) { rolled = 1; k &= ~ART_FIR_ROLLED; }
-                if (k < 0) { fprintf (stderr, "artamd: FIR launch failed: %s\n", arthip_last_error ()); res.input_used = res.output_generated = 0; return res; }
+                if (k < 0) {
+                    /* nothing of the stream has moved: the position and the history ring are committed below, behind the call's last
+                     * launch — a caller sees { 0, 0 }, the count in artamdErrorCount, and with ARTAMD_ABORT_ON_ERROR=1 the process stops here */
+                    artamd_note_failure ("resampler: FIR launch failed");
+                    res.input_used = res.output_generated = 0; return res;
+                }
                 hip->last_kernel = k;
             }
             if (whole) break;
@@ -1673,7 +1681,7 @@ static ResampleResult sharded_device_call (Resample *cxt, const art_s *d_in, lon
     if (prev >= 0) arthip_set_device (prev);
 
     res = shards_agree (cxt, per_shard);
-    if (failed) { fprintf (stderr, "artamd: sharded context: device allocation failed: %s\n", arthip_last_error ()); res.input_used = res.output_generated = 0; }
+    if (failed) { artamd_note_failure ("resampler: sharded context: device allocation failed"); res.input_used = res.output_generated = 0; }
     return res;
 }
 

@@ -59,7 +59,9 @@ void resampleHipSynchronize (Resample *cxt);
  * 1 elsewhere), 5 = as 2 but always the one-tile-per-workgroup f32 kernel, 6 = as 2 but never the fixed-point kernel: the f32
  * streaming kernel for regular launches (5 and 6 give the same bits; the fixed-point kernel rounds once per output and
  * differs from them in the last place), 7 = as 2 and the fixed-point kernel wherever it can run (automatically it takes
- * filters of 512 taps and more in calls of about a billion output-sample taps and more, where it is the faster one) */
+ * filters of 512 taps and more in calls of about a billion output-sample taps and more, where it is the faster one).
+ * ARTAMD_KERNEL=<n> in the environment is the preference every NEW context starts with (programs that cannot make this call:
+ * the reference's own art / artest binaries on this library, tests/test_gpu_pcm_default_mode.py). */
 void resampleHipSetKernel (Resample *cxt, int which);
 /* (6 on a fixed-ratio stream — resampleFixedRatioInit — also makes the output independent of how the input is cut into calls, bit for bit, as the
  * reference's is: every launch runs the one kernel on tiles anchored on the stream's canonical period.  Calls of at least one period of outputs;
@@ -71,7 +73,8 @@ void resampleHipSetKernel (Resample *cxt, int which);
 void resampleHipKeepRows (Resample *cxt, int on);
 int  resampleHipLastKernel (Resample *cxt);          /* which kernel produced the bulk of the last call */
 /* the matrix-core path's fixed-point kernel (regular launches, 4-byte samples): 0 = the last call did not use it, 1 = it ran,
- * 2 = it was enqueued and stood down for the f32 kernel behind it (a sample outside (-1.98, 1.98) or not finite).
+ * 2 = it was enqueued and stood down for the f32 kernel's tile loop (an infinity or a NaN among the frames the launch reads: any finite
+ * amplitude is held, the block exponents follow the channel's peak).
  * *pairsPerChunk (may be NULL): digit-pair products issued per 32-tap chunk, 5 .. 13 (5 where both upper digit planes of the rows are zero, + 4 for each that is not).  Synchronises. */
 int  resampleHipLastFixedPoint (Resample *cxt, double *pairsPerChunk);
 /* the form of the fixed-point kernel the last call's last launch was given to: 0 none, 1 fir_i8_stream_kernel (register-staged: 1 and 2
