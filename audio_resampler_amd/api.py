@@ -119,6 +119,8 @@ def _bind(width):
         "resampleHipSynchronize": (None, [RP]),
         "resampleHipSetKernel": (None, [RP, C.c_int]),
         "resampleHipKeepRows": (None, [RP, C.c_int]),
+        "resampleHipSetCutInvariant": (None, [RP, C.c_int]),
+        "resampleHipCutInvariantFallbacks": (C.c_uint, [RP]),
         "resampleHipLastKernel": (C.c_int, [RP]),
         "resampleHipLastHandedBack": (C.c_uint, [RP]),
         "resampleHipLastFixedPoint": (C.c_int, [RP, C.POINTER(C.c_double)]),
@@ -260,6 +262,13 @@ def _bind(width):
 
         def set_kernel(self, which):
             self.L.resampleHipSetKernel(self.p, which)
+
+        def set_cut_invariant(self, on=True):
+            """the cut-invariant stream policy (art_hip.h): one arithmetic per stream, the same bits for any cut of the input into calls"""
+            self.L.resampleHipSetCutInvariant(self.p, 1 if on else 0)
+
+        def cut_invariant_fallbacks(self):
+            return self.L.resampleHipCutInvariantFallbacks(self.p)
 
         def keep_rows(self, on):
             self.L.resampleHipKeepRows(self.p, 1 if on else 0)

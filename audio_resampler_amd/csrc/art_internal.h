@@ -31,7 +31,13 @@ enum { ART_MODE_FAST = 0,        /* f32 FMA accumulation, any order (default) */
        ART_MODE_PRECISE = 1,     /* f64 accumulation (EXTEND_CONVOLUTION_MATH) */
        ART_MODE_STRICT = 2 };    /* reference C source order, un-fused (RESAMPLE_STRICT_ORDER) */
 
-enum { ART_KERNEL_AUTO = 0, ART_KERNEL_GENERAL = 1, ART_KERNEL_MFMA = 2 };
+enum { ART_KERNEL_AUTO = 0, ART_KERNEL_GENERAL = 1, ART_KERNEL_MFMA = 2,
+       /* the cut-invariant stream policy (art_hip.h, resampleHipSetCutInvariant): ONE arithmetic for every output of a rational-ratio stream however its
+        * input is cut into calls — every launch, shorter than a period or not, on the f32 streaming kernel, un-split, anchored on the stream's canonical
+        * period; a launch that cannot run anchored is the general kernel's (whose outputs never depend on the cut either) and is counted */
+       ART_KERNEL_INVARIANT = 9 };
+/* (preferences 6 and 9 both pin the f32 streaming kernel: no fixed point, no K split) */
+#define ART_PREF_PINS_F32(k) ((k) == 6 || (k) == ART_KERNEL_INVARIANT)
 #define ART_FIR_ROLLED 0x100             /* arthip_fir: the history roll rode along with this launch */
 
 typedef struct {

@@ -9,7 +9,9 @@
 namespace {
 
 constexpr int GEN_THREADS = 256;
-constexpr int GEN_MAX_TILE = 32;
+// (outputs per workgroup tile at most: 32 until round 6 — three passes of the four waves amortise a tile's positions, staging and barriers better than two, four
+// lose again: tools/micro/general_tile_sweep.sh, profiles/r6_config_e.txt.  An output's bits do not depend on its tile.)
+constexpr int GEN_MAX_TILE = 48;
 
 // General kernel: one workgroup per tile of consecutive output frames; the tile's input span is
 // staged once in LDS (coalesced frame-major reads), then each wave evaluates whole output frames:
@@ -18,7 +20,7 @@ constexpr int GEN_MAX_TILE = 32;
 // reduction and the per-output bookkeeping are then paid once per FOUR outputs, which is most of the cost when taps x
 // channels is small).  G depends on the tap count only, never on the tile, so a frame's value does not depend on how a
 // call is cut up.
-template <int CG, bool INTERP, bool PRECISE, int G, bool PIPE = false, int LEAN = 0>
+template <int CG, bool INTERP, bool PRECISE, int G, bool PIPE = false, bool LEAN = false>
 __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const ArtSegTable &segs, int tile, unsigned int bx, unsigned int by)
 {
     constexpr int SUBS = 64 / G;
@@ -67,42 +69,6 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
 
     const int lin_lo = s_ip [0] - half + 1;
     const int span = s_ip [cnt - 1] + half + 1 - lin_lo;
-
-    // LEAN >= 2 (round 6; 1 - 2 channel streams): ALL of an output's coefficient loads — at most 16 steps per lane whatever the filter: half <= 512
-    // taps over 32 lanes, <= 256 over 16 — are issued at once, and for the wave's first output BEFORE the tile's input span is staged: they need the
-    // filter index only, so the bank's trip to the L2 and the span's overlap, where the r5 loop (LEAN == 1) made one dependent trip per three steps
-    // behind the staging barrier (four in a row at 380 taps — most of a workgroup's life: profiles/r6_config_e.txt).  A wave's next output's loads are
-    // issued behind this output's last multiply-add, under its reduction.  Same taps, same order per lane: same bits.
-    // (LEAN = 2, 3, 4, 5: room for 4, 8, 12, 16 steps — the launch picks the smallest that holds the filter's: registers are occupancy)
-    constexpr int L2_MAXS = LEAN >= 2 ? 4 * (LEAN - 1) : 1;
-    art_s q0 [L2_MAXS] [2], q1 [LEAN >= 2 && INTERP ? L2_MAXS : 1] [2];
-    auto prefetch_all = [&] (int i) {
-        if constexpr (LEAN >= 2) {
-            constexpr unsigned int SZ = sizeof (art_s);
-            const __amdgpu_buffer_rsrc_t r_bank_ = __builtin_amdgcn_make_buffer_rsrc (const_cast<art_s *> (a.bank), 0, (int)((unsigned int)(a.F + 1) * (unsigned int) a.T * SZ), 0x00020000);
-            const int steps = (half + G - 1) / G;
-            const int le = l < half ? l : 0;
-            const unsigned int row = (unsigned int) s_fi [i] * (unsigned int) a.T;
-            const unsigned int lo = (row + (unsigned int) le) * SZ, hi = (row + (unsigned int)(a.T - 1 - le)) * SZ;
-            const unsigned int next_row = INTERP ? (unsigned int) a.T * SZ : 0u;
-            auto ld = [&] (unsigned int voff, unsigned int soff) -> art_s {
-                if constexpr (sizeof (art_s) == 4) return __uint_as_float (__builtin_amdgcn_raw_buffer_load_b32 (r_bank_, (int) voff, (int) soff, 0));
-                else {
-                    typedef unsigned int u32x2_ __attribute__ ((ext_vector_type (2)));
-                    const u32x2_ w = __builtin_amdgcn_raw_buffer_load_b64 (r_bank_, (int) voff, (int) soff, 0);
-                    return (art_s) __longlong_as_double ((long long)(((unsigned long long) w.y << 32) | w.x));
-                }
-            };
-#pragma unroll
-            for (int u = 0; u < L2_MAXS; ++u)
-                if (u < steps) {
-                    q0 [u] [0] = ld (lo + (unsigned int)(u * G) * SZ, 0u);
-                    q0 [u] [1] = ld (hi - (unsigned int)(u * G) * SZ, 0u);
-                    if constexpr (INTERP) { q1 [u] [0] = ld (lo + (unsigned int)(u * G) * SZ, next_row); q1 [u] [1] = ld (hi - (unsigned int)(u * G) * SZ, next_row); }
-                }
-        }
-    };
-    if constexpr (LEAN >= 2) { if (wave * SUBS < cnt) prefetch_all (wave * SUBS + sub < cnt ? wave * SUBS + sub : cnt - 1); }
 
     if constexpr (PIPE) {
         // (four loads in flight per thread: one at a time, a long span's rounds are as many trips to memory)
@@ -171,7 +137,6 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
 #pragma unroll
             for (int c = 0; c < CG; ++c) result [c] = x [(size_t)(half - 1 + (fi == a.F ? 1 : 0)) * CG + c];
             if constexpr (PIPE) { if (i0 + (GEN_THREADS / 64) * SUBS < cnt) fetch (index_of (i0 + (GEN_THREADS / 64) * SUBS), 0); }     // (these lanes' next output)
-            if constexpr (LEAN >= 2) { if (i0 + STRIDE < cnt) prefetch_all (index_of (i0 + STRIDE)); }
         }
         else {
             const art_s *h0 = a.bank + (size_t) fi * a.T;
@@ -214,39 +179,7 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
                 }
                 if (i0 + STRIDE < cnt) fetch (index_of (i0 + STRIDE), 0);      // (the next output's first round travels under this one's reduction)
             }
-            else if constexpr (LEAN >= 2) {
-                const int steps = (half + G - 1) / G;                // (uniform)
-                const int le = l < half ? l : 0;
-                const art_s *xl = x + (size_t) le * CG, *xh = x + (size_t)(a.T - 1 - le) * CG;
-#pragma unroll
-                for (int u = 0; u < L2_MAXS; ++u)
-                    if (u < steps) {
-                        art_s xv [2] [CG];
-#pragma unroll
-                        for (int c = 0; c < CG; ++c) { xv [0] [c] = xl [(size_t)(u * G) * CG + c]; xv [1] [c] = (xh - (size_t)(u * G) * CG) [c]; }
-                        if (l + u * G < half) {
-#pragma unroll
-                            for (int side = 0; side < 2; ++side) {
-                                const art_s c0 = q0 [u] [side];
-                                const art_s c1 = INTERP ? q1 [u] [side] : 0.0f;
-#pragma unroll
-                                for (int c = 0; c < CG; ++c) {
-                                    const art_s v = xv [side] [c];
-                                    if (PRECISE) {
-                                        acc0 [c] = acc0 [c] + (Acc) c0 * (Acc) v;
-                                        if (INTERP) acc1 [c] = acc1 [c] + (Acc) c1 * (Acc) v;
-                                    }
-                                    else {
-                                        acc0 [c] = fused ((Acc) c0, (Acc) v, acc0 [c]);
-                                        if (INTERP) acc1 [c] = fused ((Acc) c1, (Acc) v, acc1 [c]);
-                                    }
-                                }
-                            }
-                        }
-                    }
-                if (i0 + STRIDE < cnt) prefetch_all (index_of (i0 + STRIDE));      // (the wave's next output: its coefficients travel under this one's reduction)
-            }
-            else if constexpr (LEAN == 1) {
+            else if constexpr (LEAN) {
                 // The plain loop below, instruction for instruction leaner (the kernel is bound by vector-instruction ISSUE — ~210 wave
                 // instructions per pass of two outputs for its 12 packed multiply-adds at 380 taps, tools/attic/fir_cell_kernel_r5.txt —
                 // not by the trips its loads make): R steps at a time, their coefficient loads (buffer loads: one address per lane and
@@ -366,7 +299,7 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
   }
 }
 
-template <int CG, bool INTERP, bool PRECISE, int G, bool PIPE, int LEAN>
+template <int CG, bool INTERP, bool PRECISE, int G, bool PIPE, bool LEAN>
 __global__ __launch_bounds__ (GEN_THREADS)
 void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile)
 {
@@ -488,6 +421,10 @@ bool general_geometry (const ArtFirArgs &a, int *tile_out, size_t *lds_out, dim3
     const int max_span = lds_budget / ((int) sizeof (art_s) * CG);
     int tile = (int) floor ((max_span - a.T - 3) * a.ratio);
     if (tile > GEN_MAX_TILE) tile = GEN_MAX_TILE;
+    {   // (tile-size sweeps: tools/micro/general_tile_sweep.sh)
+        static const int t_env = [] { const char *e = getenv ("ARTAMD_GENERAL_TILE"); return e && *e ? atoi (e) : 0; } ();
+        if (t_env > 0 && t_env < tile) tile = t_env;
+    }
     // small calls: prefer many small tiles (each wave walks its tile's outputs serially, so latency ~ tile/4
     // outputs) over staging efficiency, until there are about four workgroups per CU
     // (`crowd` = launches of this size sharing the grid — the batched entry point: many streams fill the chip together, so
@@ -497,7 +434,12 @@ bool general_geometry (const ArtFirArgs &a, int *tile_out, size_t *lds_out, dim3
     // doubles the workgroups for nothing; at 4 outputs a 4,096-frame call of 8 ch x 988 taps was 1,115 workgroups, more than the
     // 1,024 the chip holds at once: 20.7 us against 13.7 at 2,896 frames)
     const int pass = (GEN_THREADS / 64) * (64 / general_group (a.T));
-    while (tile > pass && (unsigned long long)((total_outputs + tile - 1) / tile) * crowd < 1024u) tile >>= 1;
+    // (whole passes: a tile of 40 outputs costs its first wave three passes like one of 48)
+    if (tile > pass) {
+        int k = tile / pass;
+        while (k > 1 && (unsigned long long)((total_outputs + (unsigned int)(k * pass) - 1) / (unsigned int)(k * pass)) * crowd < 1024u) --k;
+        tile = k * pass;
+    }
     if (tile < 1) tile = 1;
     long span = a.T + (long) ceil (tile / a.ratio) + 3;
     size_t lds = (size_t) span * CG * sizeof (art_s);
@@ -518,14 +460,8 @@ int launch_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st
     static const bool pipe_on = [] { const char *e = getenv ("ARTAMD_GENERAL_PIPE"); return !(e && *e == '0'); } ();      // (A/B runs and the bit-identity test)
 
 #define GO(I, P) do { const int gg = general_group (a.T); if (gg == 16) GO_ (I, P, 16); else if (gg == 32) GO_ (I, P, 32); else GO_ (I, P, 64); } while (0)
-    static const int lean_on = [] { const char *e = getenv ("ARTAMD_GENERAL_LEAN"); return e && *e >= '0' && *e <= '2' ? *e - '0' : 2; } ();      // (likewise: =0 pins the plain loop, =1 round 5's lean loop)
-#define GO_(I, P, GG) do { const int steps_ = (a.T / 2 + GG - 1) / GG; \
-        if (CG >= 4 && a.T >= 512 && pipe_on) GO__ (I, P, GG, (CG >= 4), 0); \
-        else if (lean_on == 2 && CG <= 2 && steps_ <= 4) GO__ (I, P, GG, false, (CG <= 2 ? 2 : 0)); \
-        else if (lean_on == 2 && CG <= 2 && steps_ <= 8) GO__ (I, P, GG, false, (CG <= 2 ? 3 : 0)); \
-        else if (lean_on == 2 && CG <= 2 && steps_ <= 12) GO__ (I, P, GG, false, (CG <= 2 ? 4 : 0)); \
-        else if (lean_on == 2 && CG <= 2 && steps_ <= 16) GO__ (I, P, GG, false, (CG <= 2 ? 5 : 0)); \
-        else if (lean_on >= 1 && CG <= 2) GO__ (I, P, GG, false, (CG <= 2 ? 1 : 0)); else GO__ (I, P, GG, false, 0); } while (0)
+    static const bool lean_on = [] { const char *e = getenv ("ARTAMD_GENERAL_LEAN"); return !(e && *e == '0'); } ();      // (likewise: =0 pins the plain loop)
+#define GO_(I, P, GG) do { if (CG >= 4 && a.T >= 512 && pipe_on) GO__ (I, P, GG, (CG >= 4), false); else if (lean_on && CG <= 2) GO__ (I, P, GG, false, (CG <= 2)); else GO__ (I, P, GG, false, false); } while (0)
 #define GO__(I, P, GG, PP, LL) do { auto k = fir_general_kernel<CG, I, P, GG, PP, LL>; \
         if (lds > 48 * 1024) (void) hipFuncSetAttribute ((const void *) k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
         hipLaunchKernelGGL (k, grid, dim3 (GEN_THREADS), lds, st, a, segs, tile); } while (0)

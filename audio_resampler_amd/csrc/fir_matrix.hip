@@ -946,7 +946,10 @@ bool artfir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int
     }
     return a->mode == ART_MODE_FAST && a->period_out > 0 && a->fix_list && a->scratch && a->in_pitch == 0 && a->out_pitch == 0 &&
                          segs->lin_floor == INT_MIN && kernel_pref != ART_KERNEL_GENERAL &&
-                         (enough || kernel_pref >= ART_KERNEL_MFMA) && total >= (unsigned int) a->period_out;
+                         (enough || kernel_pref >= ART_KERNEL_MFMA) &&
+                         // (a launch of less than a period is the general kernel's — unless the stream runs under the cut-invariant policy: anchored on the
+                         // canonical period it is the same tiles as any other launch, the slots in front of its first output computed and not stored)
+                         (total >= (unsigned int) a->period_out || (kernel_pref == ART_KERNEL_INVARIANT && a->rows_cache));
 }
 
 // Tile geometry of a launch (everything but the tables in device scratch); returns the compile-time channel count of the
@@ -1004,7 +1007,7 @@ static ArtFirArgs widest_group (const ArtFirArgs *a)
 
 static int matrix_split_parts (const ArtFirArgs *a, const MfmaGeom &g, unsigned int outputs, int kernel_pref)
 {
-    if (kernel_pref == 5 || kernel_pref == 6 || kernel_pref == 7) return 1;
+    if (kernel_pref == 5 || ART_PREF_PINS_F32 (kernel_pref) || kernel_pref == 7) return 1;
     static const bool off = [] { const char *e = getenv ("ARTAMD_NO_SPLIT"); return e && *e && *e != '0'; } ();
     if (off) return 1;
     const int C = a->stream_C > a->C ? a->stream_C : a->C;
@@ -1063,7 +1066,7 @@ bool artfir_matrix_spans_segments (const ArtFirArgs *a, const ArtSegTable *segs,
 size_t artfir_planes_bytes (const ArtFirArgs *a_, unsigned int outputs, int kernel_pref)
 {
     const ArtFirArgs wg_ = widest_group (a_), *a = &wg_;
-    if (!a->period_out || a->mode != ART_MODE_FAST || kernel_pref == 5 || kernel_pref == 6 || kernel_pref == 8) return 0;
+    if (!a->period_out || a->mode != ART_MODE_FAST || kernel_pref == 5 || ART_PREF_PINS_F32 (kernel_pref) || kernel_pref == 8) return 0;
     // Where it pays (MI355X, tools/bench_shapes.py with and without ARTAMD_NO_FIXED, profiles/r2_fixed_point_shapes.txt): the
     // integer kernel gains in proportion to outputs x channels x taps, its staging pass costs in proportion to the input
     // and its extra launch ~4 us: long filters and big calls win (8 ch x 988 taps: from ~90k frames per call, +27 % at 1M;
@@ -1178,7 +1181,7 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
         // Fixed point on the integer matrix cores (fir_matrix_i8.hip) where the launch has its digit planes: staging pass + main
         // kernel, which carries the f32 tile loop as its own stand-by (a sample the digits cannot hold is only found on the
         // device) and takes the history roll along.  kernel_pref 6 pins the f32 kernel.
-        if (regular && kernel_pref != 6 && artfir_i8_launch (a, segs, g, cgt, roll_blocks, st))
+        if (regular && !ART_PREF_PINS_F32 (kernel_pref) && artfir_i8_launch (a, segs, g, cgt, roll_blocks, st))
             return hipGetLastError () == hipSuccess ? (ART_KERNEL_MFMA | (a->roll_dst ? ART_FIR_ROLLED : 0)) : -1;
         // The f32 streaming kernel on rows kept across calls (fir_matrix_i8.hip, "The rows across calls": the same canonical period, one set of
         // eff / canon_* / tile_w0 at the head of a->rows — no block alignment to honour): the launch is anchored on the canonical period
@@ -1191,8 +1194,12 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
         {
             ArtRowsCache *rc = regular && g.head && artfir_rows_cache_enabled () && a->rows && artfir_f32_set_bytes (g) <= a->rows_bytes ? (ArtRowsCache *) a->rows_cache : nullptr;
             HostPos pos0; int slot0 = 0, w = 0;
+            // (the tile that holds the launch's first STORED output must start inside the head's zero frames: all its rows share its K origin.  Tiles
+            // in front of it — a period_in longer than T/2 + 64 and a launch that starts late in its period: downsampling streams — hold skipped slots only; their
+            // origin is clamped to the head's first frame by the staging (a shifted window: sums that are never stored).  Round 5 tested slot 0's window here,
+            // and such launches fell back to rows of their own: other bits for other cuts)
             if (rc && artfir_rows_canonical (a, segs, g.P, g.Q, rc, &pos0, &slot0, &w) &&
-                rc->c_ip [0] + w - a->T / 2 + 1 >= -MF_HEAD_PAD) {                        // (the virtual start's window inside the head's zero frames)
+                rc->c_ip [(slot0 / 32) * 32] + w - a->T / 2 + 1 >= -MF_HEAD_PAD) {
                 ArtFirArgs t = *a;
                 t.n_begin = a->n_begin + (unsigned int)(g.P - slot0); t.n_end = a->n_end + (unsigned int) g.P;
                 t.out = a->out - (size_t) g.P * a->C; t.n_skip = slot0;
@@ -1216,6 +1223,8 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
                 }
             }
         }
+        // the cut-invariant policy runs anchored launches only: anything else is handed to the general kernel (0: arthip_fir counts it)
+        if (kernel_pref == ART_KERNEL_INVARIANT && !on_kept_rows) return 0;
         a = &a_v;
         {   static const bool trace = [] { const char *e = getenv ("ARTAMD_ROWS_TRACE"); return e && *e == '1'; } ();
             if (trace) fprintf (stderr, "rows (f32): launch n %u..%u C %d  kept %d  ready %d  n_skip %d  w_shift %d  regular %d split %p\n", a->n_begin, a->n_end, a->C, (int) on_kept_rows, (int) rows_ready, a->n_skip, g.w_shift, (int) regular, a->split);

@@ -60,6 +60,7 @@ struct artamd_resampler {
     ArtamdSegment *segs; int seg_cap;
     int floor_active;                       /* ring index 0 is a hard history floor (after a flush-time rewind) */
     int kernel_pref, last_kernel;
+    unsigned int invariant_fallbacks;        /* launches the cut-invariant policy had to give to the general kernel (resampleHipCutInvariantFallbacks) */
     int stream_channels;                     /* a shard: channels of the whole stream (kernel choice); 0 otherwise */
     /* cached rational structure of the current ratio */
     double period_ratio; int period_out, period_in;
@@ -820,6 +821,18 @@ void resampleHipSynchronize (Resample *cxt)
     LEAVE_DEVICE (hip);
 }
 
+void resampleHipSetCutInvariant (Resample *cxt, int on)
+{
+    resampleHipSetKernel (cxt, on ? ART_KERNEL_INVARIANT : ART_KERNEL_AUTO);
+}
+
+unsigned int resampleHipCutInvariantFallbacks (Resample *cxt)
+{
+    unsigned int n = cxt->hip->invariant_fallbacks;
+    for (int k = 0; k < cxt->hip->nshards; ++k) n += resampleHipCutInvariantFallbacks (cxt->hip->shards [k]);
+    return n;
+}
+
 void resampleHipSetKernel (Resample *cxt, int which)
 {
     cxt->hip->kernel_pref = which;
@@ -1330,6 +1343,10 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
                     res.input_used = res.output_generated = 0; return res;
                 }
                 hip->last_kernel = k;
+                /* the cut-invariant policy: a launch of a rational-ratio stream that could not run anchored on the matrix cores went to the general
+                 * kernel — still independent of the cut by itself, but another arithmetic than the stream's other outputs: counted (art_hip.h) */
+                if (hip->kernel_pref == ART_KERNEL_INVARIANT && k == ART_KERNEL_GENERAL && a.period_out && a.mode == ART_MODE_FAST && !is_flush)
+                    hip->invariant_fallbacks++;
             }
             if (whole) break;
         }
@@ -1696,7 +1713,8 @@ static ResampleResult enqueue_call_layouts (Resample *cxt, const art_s *d_in, lo
     static int planar_off = -1;
     if (planar_off < 0) { const char *e = getenv ("ARTAMD_PLANAR_DIRECT"); planar_off = e && *e && *e != '0'; }
     if ((in_pitch || out_pitch) && !planar_off && nIn > 0 && cap > 0 && d_in && d_out &&
-        (double) nIn * (hip->stream_channels > cxt->numChannels ? hip->stream_channels : cxt->numChannels) * cxt->numTaps >= 2.0e8) {      /* (a shard: its whole stream's size) */
+        ((double) nIn * (hip->stream_channels > cxt->numChannels ? hip->stream_channels : cxt->numChannels) * cxt->numTaps >= 2.0e8 ||       /* (a shard: its whole stream's size) */
+         hip->kernel_pref == ART_KERNEL_INVARIANT)) {            /* (the cut-invariant policy: every call, whatever its size, on the same kernel) */
         const int C = cxt->numChannels;
         const art_s *in_i = d_in; art_s *out_i = d_out;
         int ok = 1;

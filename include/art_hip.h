@@ -66,6 +66,21 @@ void resampleHipSetKernel (Resample *cxt, int which);
 /* (6 on a fixed-ratio stream — resampleFixedRatioInit — also makes the output independent of how the input is cut into calls, bit for bit, as the
  * reference's is: every launch runs the one kernel on tiles anchored on the stream's canonical period.  Calls of at least one period of outputs;
  * device-pointer input aligned to a frame (1 - 2 channels) / 16 bytes (4 and more).  resampler.h's header; tests/test_gpu_cut_invariance.py) */
+/* THE CUT-INVARIANT STREAM POLICY (round 6).  The reference's fixed-ratio output is bitwise independent of how the input is cut into calls
+ * (resampler.c:323-335, 533-535: `artest -e -b256 | -b1000 | -b4096 | -b65536`, one checksum).  In the default mode this library picks a kernel per
+ * CALL (general / f32 matrix cores, K split or not / fixed point), each inside the parity bar with its own last bits.  With this policy on, the
+ * arithmetic is chosen per STREAM: every launch of a rational-ratio stream — big, small, shorter than one period, planar or interleaved — runs on the
+ * f32 matrix-core streaming kernel, un-split, anchored on the stream's canonical period (an output sits in the same tile row, on the same K chunks
+ * and flush points whichever call brought it), and the outputs only a flush can make (the stream's last T/2 x ratio) on the general kernel, whose
+ * outputs never depend on the cut either: the same bits for ANY cut into calls, host or device buffers.  A launch that cannot run anchored (a
+ * nearest-filter stream with a slot on a half step, a device buffer not aligned to 16 bytes / one frame, a call of several million frames whose
+ * position drift exceeds the kernels' tolerance) is given to the general kernel and COUNTED: resampleHipCutInvariantFallbacks () == 0 says the
+ * guarantee held for every output so far.  Equivalent: resampleHipSetKernel (cxt, 9), ARTAMD_KERNEL=9.
+ * What it costs against the library's own choice (tools/bench_cut_invariant.py, profiles/r6_cut_invariant.txt): nothing is free — small calls lose the
+ * general kernel's short launch, mid-sized calls of long filters the K split, big calls the fixed-point kernel — which is why it is a context
+ * setting and not the default.  RESAMPLE_STRICT_ORDER (bit-exact reference order) and preference 1 (the general kernel alone) are cut-invariant too. */
+void resampleHipSetCutInvariant (Resample *cxt, int on);
+unsigned int resampleHipCutInvariantFallbacks (Resample *cxt);
 /* The streaming matrix kernels keep their filter rows across the calls of a context (built once for the stream's canonical period; every later
  * launch is anchored on that period: DESIGN.md 4.1) — on by default.  Off: every launch builds its rows from its own positions and anchors its
  * tiles on its own first output, as before round 5 (comparisons of kernel forms bit for bit; ARTAMD_ROWS_CACHE=0 does it for a whole process).

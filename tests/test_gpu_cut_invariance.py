@@ -40,23 +40,31 @@ def _cuts(kind, rng):
     return c
 
 
-def _play(stream, cuts, x, device):
+def _play(stream, cuts, x, device, policy=False, rates=(44100.0, 48000.0), planar=False, flush=False):
     ch, T, F, flags = stream
-    r = HipResampler(ch, T, F, flags=flags, fixed=(44100.0, 48000.0, 0), kernel=6); r.advance(T / 2)
+    r = HipResampler(ch, T, F, flags=flags, fixed=(rates[0], rates[1], 0), kernel=0 if policy else 6); r.advance(T / 2)
+    if policy:
+        r.set_cut_invariant(True)      # (kernel preference stays the library's own: the POLICY pins the arithmetic per stream)
     outs, pos = [], 0
     if device:
         import torch
         d_x = torch.from_numpy(x).cuda()
-    for n in cuts:
-        cap = int(n * 48000 / 44100) + 4000
+    for i, n in enumerate(cuts):
+        cap = int(n * rates[1] / rates[0]) + 4000
+        last = flush and i == len(cuts) - 1
         if device:
             d_y = torch.zeros(cap, ch, device="cuda")
-            u, g = r.process_device(d_x[pos:pos + n], n, d_y, cap, 0.0)
+            u, g = r.process_device(d_x[pos:pos + n], n, d_y, cap, 0.0, and_flush=last)
             y = d_y[:g].cpu().numpy()
+        elif planar:
+            u, g, planes = r.process_planar([np.ascontiguousarray(x[pos:pos + n, c]) for c in range(ch)], cap, 0.0, and_flush=last)
+            y = np.stack(planes, axis=1) if g else np.zeros((0, ch), np.float32)
         else:
-            u, g, y = r.process(x[pos:pos + n], cap, 0.0)
-        assert u == n and r.last_kernel() == 2
+            u, g, y = r.process(x[pos:pos + n], cap, 0.0, and_flush=last)
+        assert u == n and (g == 0 or last or r.last_kernel() == 2), (i, n, u, g, r.last_kernel())
         outs.append(np.array(y).copy()); pos += n
+    if policy:
+        assert r.cut_invariant_fallbacks() == 0
     return np.concatenate(outs)
 
 
@@ -72,3 +80,73 @@ def test_fixed_ratio_output_does_not_depend_on_the_cuts(stream):
         y = _play(stream, _cuts(kind, rng), x, device)
         assert y.shape == ref.shape, (kind, device, y.shape, ref.shape)
         assert hashlib.sha256(y.tobytes()).hexdigest() == want, (kind, device, int(np.count_nonzero(y.view(np.uint32) != ref.view(np.uint32))))
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# The cut-invariant STREAM POLICY (art_hip.h: resampleHipSetCutInvariant; round 6): kernel preference 0 — the library's own — and the policy on.
+# Any cut: calls shorter than one period (160 outputs = 147 input frames) down to single frames, planar host calls, the flush in the last call; and
+# a downsampling stream, whose input period (320 frames) is longer than T/2 + 64 — round 5's anchoring test sent such launches back to rows of their own.
+# ------------------------------------------------------------------------------------------------------------------------
+POLICY_STREAMS = [
+    ((2, 380, 380, BH | INTERP), (44100.0, 48000.0)),
+    ((8, 988, 988, BH | INTERP), (44100.0, 48000.0)),
+    ((1, 380, 380, BH | INTERP), (44100.0, 48000.0)),
+    ((4, 256, 256, BH | INTERP), (44100.0, 48000.0)),
+    ((8, 988, 988, BH | INTERP), (96000.0, 44100.0)),      # BASELINE configs[2]'s conversion: 147 x 988, period_in 320
+    ((2, 380, 380, BH | INTERP), (96000.0, 44100.0)),      # period_in 320 > T/2 + 64 = 254
+    ((2, 156, 156, BH | INTERP), (48000.0, 32000.0)),      # 2 outputs per 3 inputs: the kernels take 16 periods at a time
+]
+
+
+def _tiny_cuts(rng, total):
+    c = []
+    while sum(c) < min(total, 30000):
+        c.append(int(min(rng.integers(1, 400), total - sum(c))))
+    while sum(c) < total:
+        c.append(int(min(rng.integers(100, 20000), total - sum(c))))
+    return c
+
+
+@pytest.mark.parametrize("stream,rates", POLICY_STREAMS, ids=[f"c{s[0]}_t{s[1]}_{int(r[0])}_{int(r[1])}" for s, r in POLICY_STREAMS])
+def test_cut_invariant_policy_any_cut_default_kernel_preference(stream, rates):
+    ch = stream[0]
+    total = 200000
+    x, _ = noise(total * ch, state=0xC077 | 1)
+    x = x.reshape(total, ch)
+    rng = np.random.default_rng(5)
+    ref = _play(stream, [total], x, device=True, policy=True, rates=rates, flush=True)
+    want = hashlib.sha256(ref.tobytes()).hexdigest()
+    fixed = lambda k: [k] * (total // k) + ([total - k * (total // k)] if total % k else [])
+    for name, cuts, kw in (("65536", fixed(65536), dict(device=True)), ("16384", fixed(16384), dict(device=False)), ("4096", fixed(4096), dict(device=True)),
+                           ("1000", fixed(1000), dict(device=False)), ("tiny", _tiny_cuts(rng, total), dict(device=False)), ("tiny-dev", _tiny_cuts(rng, total), dict(device=True)),
+                           ("planar", fixed(16384), dict(device=False, planar=True)), ("random", _cuts("random", rng)[:1] + fixed(7777), dict(device=True))):
+        cuts = [c for c in cuts if c > 0]
+        if sum(cuts) > total:                      # (the random head may overshoot: trim the tail)
+            over = sum(cuts) - total
+            while over > 0:
+                d = min(over, cuts[-1]); cuts[-1] -= d; over -= d
+                if cuts[-1] == 0: cuts.pop()
+        y = _play(stream, cuts, x, policy=True, rates=rates, flush=True, **kw)
+        assert y.shape == ref.shape, (name, y.shape, ref.shape)
+        assert hashlib.sha256(y.tobytes()).hexdigest() == want, (name, int(np.count_nonzero(y.view(np.uint32) != ref.view(np.uint32))))
+
+
+def test_reference_artest_fixed_ratio_block_size_invariance_on_the_library():
+    """SURVEY appendix C, the reference's own test program (oracle/_ref/artest_amd = artest.c on this library): `-e` output has ONE checksum at
+    every -b — under the policy (ARTAMD_KERNEL=9) in the DEFAULT numeric mode, as under ARTAMD_STRICT=1."""
+    import os, re, subprocess
+    from _oracle import ORACLE_DIR
+    exe = os.path.join(ORACLE_DIR, "_ref", "artest_amd")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/artest_amd not built (needs /root/reference at build time)")
+    sums = {}
+    for args in ("-3 -e -c2 -n3 -s44100 -d48000", "-4 -e -l -c8 -n2 -s96000 -d44100"):
+        for b in (256, 1000, 4096, 65536):
+            env = dict(os.environ, ARTAMD_KERNEL="9"); env.pop("ARTAMD_STRICT", None)
+            p = subprocess.run([exe] + args.split() + [f"-b{b}"], capture_output=True, text=True, env=env, timeout=600)
+            assert p.returncode == 0, p.stderr[-1500:]
+            m = re.search(r"output \(-w\d\): count =\s*(\d+), checksum = ([0-9a-f]{16})", p.stderr)
+            assert m, p.stderr[-1500:]
+            sums.setdefault(args, set()).add((m.group(1), m.group(2)))
+    for args, got in sums.items():
+        assert len(got) == 1, (args, got)

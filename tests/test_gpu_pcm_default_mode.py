@@ -11,8 +11,8 @@ What must hold (reference decimator.c:245-283: scale, subtract shaped error, add
     steps: P(flip) = E|dy| * 2^(bits-1), dy measured on the same conversion written as 32-bit float;
   * WITH noise shaping the first flip changes the error fed back, and two quantisations of (nearly) the same signal run
     apart for good — the reference's OWN two builds (Makefile flags vs source order, oracle/_ref/art_make vs art_strict) differ in
-    65 - 80 % of the samples by up to 8 steps.  There: identical up to the first flip, each file's error against the un-quantised
-    signal has the same rms, and the difference is no larger than the reference's own builds' difference.
+    65 - 80 % of the samples by up to 8 steps.  There: each file's error against the un-quantised signal has the same rms (1 %), and
+    the difference between the files is no larger than the reference's own two builds' difference.
 The reference's Makefile build is run beside every case as the yardstick: our default mode must be no further from art_strict
 than the reference's shipped build is (x a margin), measured on the same input.
 """
@@ -161,6 +161,27 @@ def test_device_resident_art_tool_in_default_mode_at_the_pcm_level(tmp_path, tmp
     ours = _convert_all(tmp_path, "gpu", ART_GPU, opts + " -q", src)
     report = []
     _check(f"{name} [tools/art_gpu.py]", ours, strict, make, report)
+    with capsys.disabled():
+        print("\n" + "\n".join(report))
+
+
+@needs_ref
+def test_clipped_counts_in_default_mode(tmp_path, capsys):
+    """+5 dB on the stereo shape drives the peaks past full scale: the decimator's clipped-sample count (art.c:1066, 1148) must be the reference's.
+    Without shaping a flip moves the count only where it crosses the clip level itself; with shaping the two quantisations differ sample by
+    sample (above) and so may the count, by a few per cent at most."""
+    opts, rate, ch = SHAPES["B_stereo_380"]
+    src = str(tmp_path / "in.wav")
+    P.write_float_wav(src, rate, P.signal(rate, ch, SECONDS))
+    report = []
+    for extra, slack in (("-o16 -d0 -n0", 0.0), ("-o16 -n0", 0.0), ("-o16", 0.05), ("-o24 -d0 -n0", 0.0), ("-o24", 0.05)):
+        o = f"{opts} -g5 {extra}"
+        c_ref = _run(ART_REF, o, src, str(tmp_path / "ref.wav"))
+        c_amd = _run(ART_AMD, o, src, str(tmp_path / "amd.wav"))
+        c_gpu = _run(ART_GPU, o, src, str(tmp_path / "gpu.wav"))
+        report.append(f"B_stereo_380 -g5 {extra}: clipped samples reference {c_ref}, art.c on the library {c_amd}, tools/art_gpu.py {c_gpu}")
+        assert c_ref > 100
+        assert abs(c_amd - c_ref) <= 2 + slack * c_ref and abs(c_gpu - c_ref) <= 2 + slack * c_ref, report[-1]
     with capsys.disabled():
         print("\n" + "\n".join(report))
 

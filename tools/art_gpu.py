@@ -291,9 +291,11 @@ def main(argv):
         f.write(body)
         if len(body) & 1:
             f.write(b"\0")
+    clipped = dec.clipped() if dec is not None else 0
     if not quiet:
-        clipped = dec.clipped() if dec is not None else 0
-        print(f"{produced} frames x {ch} ch written to {dst}" + (f"; {clipped} samples clipped" if clipped else ""), file=sys.stderr)
+        print(f"{produced} frames x {ch} ch written to {dst}", file=sys.stderr)
+    if clipped:                                               # (the reference's warning, quiet or not: art.c:1148-1149)
+        print(f"warning: {clipped} samples were clipped, suggest reducing gain!", file=sys.stderr)
     for p in (d_raw, d_in, d_st, d_out, d_pcm):
         if p:
             L.artamdDeviceFree(p)
