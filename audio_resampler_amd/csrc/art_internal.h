@@ -66,6 +66,8 @@ typedef struct {
     int mode;                            /* ART_MODE_* */
     double ratio;
     unsigned int n_begin, n_end;         /* call-relative output frames to produce */
+    long long lin_origin;                /* stream frame (input frames appended since init / reset, less H) that linear frame 0 of this call is: two calls' linear
+                                          * indices differ by the difference of theirs — the rows kept across calls place a launch in the stream's tiling with it */
     int n_skip;                          /* matrix kernels on cached rows (below): the launch's tiles start at the cached period's first slot, n_skip
                                           * slots before the launch's first output — those slots of the first period are computed and not stored */
     int segs_truncated;                  /* the launch reaches beyond the segments of its table (a call of more than ART_MAX_SEGS ring epochs

@@ -9,6 +9,6 @@ bool artfir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int
 int  artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, void *stream);    // fir_matrix.hip | fir_matrix64.hip
 size_t artfir_split_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref);           // fir_matrix.hip | fir_matrix64.hip (0)
 bool artfir_matrix_spans_segments (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref);  // fir_matrix.hip | fir_matrix64.hip (never)
-size_t artfir_planes_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref);
-size_t artfir_rows_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref);
-void artfir_rows_touch (const ArtFirArgs *a, const ArtSegTable *segs);                               // fir_matrix.hip | fir_matrix64.hip (nothing)        // fir_matrix.hip | fir_matrix64.hip (0)                                                      // fir_matrix.hip | fir_matrix64.hip (0)
+size_t artfir_planes_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref);          // fir_matrix.hip | fir_matrix64.hip (0: no fixed-point path)
+size_t artfir_rows_bytes (const ArtFirArgs *a, unsigned int outputs, int kernel_pref);            // fir_matrix.hip | fir_matrix64.hip (0: no rows kept)
+void artfir_rows_touch (const ArtFirArgs *a, const ArtSegTable *segs);                               // fir_matrix.hip | fir_matrix64.hip (nothing)

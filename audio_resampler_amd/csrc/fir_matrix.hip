@@ -50,7 +50,7 @@ __device__ __forceinline__ void gather_head (const ArtFirArgs &a, const MfmaGeom
 {
     const long total = (long) g.head_frames * a.C;
     for (long e = (long) me * 256 + tid; e < total; e += (long) blocks * 256) {
-        const int f = (int)(e / a.C), c = (int)(e - (long) f * a.C), lin = f - MF_HEAD_PAD;
+        const int f = (int)(e / a.C), c = (int)(e - (long) f * a.C), lin = f - g.head_pad;
         float v = 0.0f;
         if (lin >= 0 && lin < a.H) v = a.hist [(size_t) lin * a.C + c];
         else if (lin >= a.H && lin - a.H < a.in_frames) v = a.in [(size_t)(lin - a.H) * a.C + c];
@@ -65,7 +65,7 @@ void mfma_head_kernel (ArtFirArgs a, MfmaGeom g)
 {
     const unsigned int total = (unsigned int) g.head_frames * (unsigned int) a.C, e = blockIdx.x * 256u + threadIdx.x;
     if (e >= total) return;
-    const unsigned int pad = (unsigned int) MF_HEAD_PAD * (unsigned int) a.C, hist = (unsigned int) a.H * (unsigned int) a.C;
+    const unsigned int pad = (unsigned int) g.head_pad * (unsigned int) a.C, hist = (unsigned int) a.H * (unsigned int) a.C;
     float v = 0.0f;
     if (e >= pad) {
         unsigned int k = e - pad;
@@ -465,7 +465,7 @@ void fir_mfma_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g)
                 // loop is unrolled by the two LDS buffers so their addresses are immediates.
                 constexpr unsigned int A_STEP = MF_KC * 4u, B_STEP = MF_KC * CG * 4u;
                 // tiles that reach into the history read the call's contiguous head instead of `in` (same loop, other base)
-                const int origin = touches_hist ? -MF_HEAD_PAD : a.H;                  // linear index of the base's first frame
+                const int origin = touches_hist ? -g.head_pad : a.H;                  // linear index of the base's first frame
                 const unsigned int a_bytes = (unsigned int)((size_t) ROWS * g.ktot * 4);
                 const unsigned int b_bytes = touches_hist ? (unsigned int)((size_t) g.head_frames * a.C * 4) : (unsigned int)((size_t) a.in_frames * a.C * 4);
                 const char *a_base = reinterpret_cast<const char *> (g.eff + (size_t) st * ROWS * g.ktot);
@@ -716,7 +716,7 @@ void fir_mfma_split_kernel (ArtFirArgs a, MfmaGeom g, int wgs_per_xcd, int KS, d
             chunks_of (ks, f_chunk, f_end);
             const int w0 = g.tile_w0 [3 * st] + g.w_shift + jg * PPW * g.Q;
             const bool touches_hist = w0 < a.H;              // (first period group of a call: staged from the gathered head)
-            const int origin = touches_hist ? -MF_HEAD_PAD : a.H;
+            const int origin = touches_hist ? -g.head_pad : a.H;
             const char *base = touches_hist ? reinterpret_cast<const char *> (g.head) : reinterpret_cast<const char *> (a.in);
             const size_t total_b = touches_hist ? (size_t) g.head_frames * a.C * 4 : (size_t) a.in_frames * a.C * 4;
             size_t skip = (size_t) max (w0 - origin, 0) * CG * 4;
@@ -893,18 +893,22 @@ bool artfir_pass_fixup_wanted (const ArtFirArgs *a)
 {
     // (the pass's slot list holds 1024 x 32 slots of a period: a longer period — the period multiple included — keeps the kernels' own
     // PASS epilogues, decided HERE, before the instantiation is chosen, so that no launch can end up with neither)
-    const long period = (long) a->period_out * (a->period_out > 0 ? artfir_period_multiple (a->period_out, 32) : 1);
+    // (the period multiple of the launch's own geometry — matrix_geometry: 64-row tiles where the slab kernel is enabled — so that the bound here IS the
+    // bound on g.P the pass sees)
+    const long period = (long) a->period_out * (a->period_out > 0 ? artfir_period_multiple (a->period_out, artfir_i8_slab_enabled () ? 64 : 32) : 1);
     return !a->interpolate && !a->lowpass && a->out_pitch == 0 && a->in_pitch == 0 && period > 0 && period <= 8192 && (size_t)(a->n_end - a->n_begin) * a->C >= pass_fixup_min ();
 }
-void artfir_pass_fixup (const ArtFirArgs *a, const MfmaGeom &g, hipStream_t st)
+int artfir_pass_fixup (const ArtFirArgs *a, const MfmaGeom &g, hipStream_t st)
 {
-    if (g.P > 1024 * 32) { fprintf (stderr, "artamd: pass-through pass: a period of %d slots (cannot be: artfir_pass_fixup_wanted)\n", g.P); abort (); }
+    // (cannot be — artfir_pass_fixup_wanted bounds the same period — but a library does not abort its host: the launch fails, counted by the caller)
+    if (g.P > 1024 * 32) { fprintf (stderr, "artamd: pass-through pass: a period of %d slots\n", g.P); return -1; }
     const unsigned int total = a->n_end - a->n_begin;
     const unsigned long long items = (unsigned long long)((total + g.P - 1) / g.P) * a->C;       // (per flagged slot)
     unsigned int blocks = (unsigned int)((items + 255) / 256);
     if (blocks > 2048u) blocks = 2048u;
     if (blocks == 0u) blocks = 1u;
     hipLaunchKernelGGL (pass_fixup_kernel, dim3 (blocks), dim3 (256), 0, st, *a, g);
+    return 0;
 }
 
 bool artfir_takes_matrix_path (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref)
@@ -983,6 +987,9 @@ static int matrix_geometry (const ArtFirArgs *a, MfmaGeom &g)
     g.period_groups = (int)((periods + g.ppw - 1) / g.ppw);
     g.groups_per_xcd = (g.period_groups + 7) / 8;
     g.eff = nullptr; g.canon_ip = g.canon_fi = nullptr; g.canon_frac = nullptr; g.head = nullptr; g.head_frames = 0; g.tile_w0 = nullptr; g.w_shift = 0;
+    // (a launch anchored on the canonical period starts its first period's tiles at slot 0: up to Q frames in front of the first output, whose own window
+    // starts about T/2 frames into the history — ADVICE r5: with 64 zero frames, streams whose period_in exceeds T/2 + 64 fell back to rows of their own)
+    g.head_pad = MF_HEAD_PAD + (g.Q > a->T / 2 ? ((g.Q - a->T / 2 + 3) & ~3) : 0);
     return cgt;
 }
 
@@ -1034,7 +1041,7 @@ static int matrix_split_parts (const ArtFirArgs *a, const MfmaGeom &g, unsigned 
         if (k_env > 0) ks = k_env;
     }
     {   static const int force = [] { const char *e = getenv ("ARTAMD_SPLIT_FORCE_KS"); return e && *e ? atoi (e) : 0; } ();      // (A/B runs)
-        if (force > 0 && kernel_pref != 8) return force;
+        if (force > 0 && kernel_pref != 8) ks = force;         // (clamped below like any other count: four chunks a part at least)
     }
     while (ks > 1 && nchunks / ks < 4) --ks;
     return ks;
@@ -1167,7 +1174,7 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
                 // the call's head as one contiguous array: everything a tile whose window starts inside the history can read
                 // (+ the two chunks the staging runs ahead)
                 const size_t used = (((size_t)((char *)(g.tile_w0 + 3 * g.slot_tiles) - base)) + 255) & ~(size_t) 255;
-                g.head_frames = MF_HEAD_PAD + a->H + (g.ppw - 1) * g.Q + g.ktot + 3 * MF_KC;
+                g.head_frames = g.head_pad + a->H + (g.ppw - 1) * g.Q + g.ktot + 3 * MF_KC;
                 if (used + (size_t) g.head_frames * a->C * sizeof (float) > a->scratch_bytes) return 0;
                 g.head = (float *)(base + used);
             }
@@ -1181,8 +1188,10 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
         // Fixed point on the integer matrix cores (fir_matrix_i8.hip) where the launch has its digit planes: staging pass + main
         // kernel, which carries the f32 tile loop as its own stand-by (a sample the digits cannot hold is only found on the
         // device) and takes the history roll along.  kernel_pref 6 pins the f32 kernel.
-        if (regular && !ART_PREF_PINS_F32 (kernel_pref) && artfir_i8_launch (a, segs, g, cgt, roll_blocks, st))
-            return hipGetLastError () == hipSuccess ? (ART_KERNEL_MFMA | (a->roll_dst ? ART_FIR_ROLLED : 0)) : -1;
+        if (regular && !ART_PREF_PINS_F32 (kernel_pref)) {
+            const int i8 = artfir_i8_launch (a, segs, g, cgt, roll_blocks, st);       // 1: enqueued, 0: not for this launch, -1: failed part-way
+            if (i8) return i8 > 0 && hipGetLastError () == hipSuccess ? (ART_KERNEL_MFMA | (a->roll_dst ? ART_FIR_ROLLED : 0)) : -1;
+        }
         // The f32 streaming kernel on rows kept across calls (fir_matrix_i8.hip, "The rows across calls": the same canonical period, one set of
         // eff / canon_* / tile_w0 at the head of a->rows — no block alignment to honour): the launch is anchored on the canonical period
         // (n_skip slots of its first period computed and not stored), the set's linear indices carried w_shift frames on, and all the call
@@ -1194,12 +1203,10 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
         {
             ArtRowsCache *rc = regular && g.head && artfir_rows_cache_enabled () && a->rows && artfir_f32_set_bytes (g) <= a->rows_bytes ? (ArtRowsCache *) a->rows_cache : nullptr;
             HostPos pos0; int slot0 = 0, w = 0;
-            // (the tile that holds the launch's first STORED output must start inside the head's zero frames: all its rows share its K origin.  Tiles
-            // in front of it — a period_in longer than T/2 + 64 and a launch that starts late in its period: downsampling streams — hold skipped slots only; their
-            // origin is clamped to the head's first frame by the staging (a shifted window: sums that are never stored).  Round 5 tested slot 0's window here,
-            // and such launches fell back to rows of their own: other bits for other cuts)
+            // (the virtual start's window inside the head's zero frames — head_pad covers a whole period's input: every tile of the launch's first period
+            // group is based on the virtual period's start, so it is slot 0's window that must lie inside, not only the first stored slot's)
             if (rc && artfir_rows_canonical (a, segs, g.P, g.Q, rc, &pos0, &slot0, &w) &&
-                rc->c_ip [(slot0 / 32) * 32] + w - a->T / 2 + 1 >= -MF_HEAD_PAD) {
+                rc->c_ip [0] + w - a->T / 2 + 1 >= -g.head_pad) {
                 ArtFirArgs t = *a;
                 t.n_begin = a->n_begin + (unsigned int)(g.P - slot0); t.n_end = a->n_end + (unsigned int) g.P;
                 t.out = a->out - (size_t) g.P * a->C; t.n_skip = slot0;
@@ -1269,7 +1276,7 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
 #undef MK_GO
 #undef MK_GO_
                 if (a->ev_stop) arthip_event_record (a->ev_stop, stream);
-                if (fixup) artfir_pass_fixup (a, g, st);
+                if (fixup && artfir_pass_fixup (a, g, st)) return -1;
                 return hipGetLastError () == hipSuccess ? (ART_KERNEL_MFMA | (a->roll_dst ? ART_FIR_ROLLED : 0)) : -1;
             }
             const dim3 sgrid ((unsigned int)(8 * wgs_per_xcd) + roll_blocks);
@@ -1282,7 +1289,7 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
 #undef MS_GO
 #undef MS_GO_
             if (a->ev_stop) arthip_event_record (a->ev_stop, stream);
-            if (fixup) artfir_pass_fixup (a, g, st);
+            if (fixup && artfir_pass_fixup (a, g, st)) return -1;
             return hipGetLastError () == hipSuccess ? (ART_KERNEL_MFMA | (a->roll_dst ? ART_FIR_ROLLED : 0)) : -1;
         }
 #define MF_GO(I, CGT) do { if (ws && CGT) hipLaunchKernelGGL ((fir_mfma_kernel<I, CGT, (CGT != 0), 1>), grid, dim3 (2 * MF_THREADS), 0, st, *a, *segs, g); \

@@ -310,7 +310,7 @@ void arthip_fir_rows_cache_reset (void *) { }
 void arthip_fir_rows_cache_free (void *) { }
 }
 size_t artfir_split_bytes (const ArtFirArgs *, unsigned int, int) { return 0; }
-bool artfir_matrix_spans_segments (const ArtFirArgs *, const ArtSegTable *, int) { return false; }    // (the fp64 kernel checks every output's position against the table)        // (the fixed-point kernel is a 4-byte-sample path)
+bool artfir_matrix_spans_segments (const ArtFirArgs *, const ArtSegTable *, int) { return false; }    // (the fp64 kernel checks every output's position against the table)
 
 int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, void *stream)
 {

@@ -17,9 +17,12 @@ struct MfmaGeom {
     float *eff;                           // [slot_tiles*tile_rows][ktot]  blended rows, shifted to the tile's K origin, zero padded
     int *canon_ip, *canon_fi;             // [slot_tiles*tile_rows]        canonical position of each slot (period 0 of the launch)
     double *canon_frac;                 // K columns [band_lo, band_hi) hold every row's central taps
-    // the head of the call as ONE contiguous array (history ++ first input frames, MF_HEAD_PAD zero frames in front): tiles that
+    // the head of the call as ONE contiguous array (history ++ first input frames, head_pad zero frames in front): tiles that
     // reach into the history stage from it exactly as all others stage from `in` (written by mfma_prepare_kernel)
     float *head; int head_frames;
+    // zero frames in front of linear frame 0 in the head: MF_HEAD_PAD, more where a period's input is longer than half a window + that — a launch
+    // anchored on the canonical period starts its tiles up to Q frames in front of its first output's window (downsampling streams; round 6)
+    int head_pad;
     // per slot tile, 3 ints: [0] linear index of K column 0 in period 0 of the launch; [1] the tile's pass-through rows (nearest-
     // filter mode without a low-pass: the slots whose rounded filter index is a whole input sample, which the reference copies),
     // one bit per row — such a row's sample in period 0 is canon_ip + canon_fi / F; [2] unused (streaming kernels)
@@ -30,10 +33,10 @@ struct MfmaGeom {
 };
 
 // fir_matrix_i8.hip: the fixed-point kernel of regular launches
-size_t artfir_i8_bytes (const ArtFirArgs *a, const MfmaGeom &g, int cgt, unsigned int outputs);
-size_t artfir_i8_rows_bytes (const ArtFirArgs *a, const MfmaGeom &g, int cgt, unsigned int outputs);   // device bytes of the rows kept ACROSS calls (0: none)   // device bytes of the digit planes of a call making `outputs` frames (0: not for it)
+size_t artfir_i8_bytes (const ArtFirArgs *a, const MfmaGeom &g, int cgt, unsigned int outputs);        // device bytes of the digit planes of a call making `outputs` frames (0: not for it)
+size_t artfir_i8_rows_bytes (const ArtFirArgs *a, const MfmaGeom &g, int cgt, unsigned int outputs);   // device bytes of the rows kept ACROSS calls (0: none)
 bool artfir_i8_slab_enabled ();           // 64-slot tiles of the slab kernel (periods are taken so as to fill those); ARTAMD_I8_SLAB=0: off
-// stage + main kernel of one launch (1), or 0: not for this path (no planes, shape)
+// stage + main kernel of one launch (1), 0: not for this path (no planes, shape), -1: a launch of it failed
 int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGeom &g, int cgt, unsigned int roll_blocks, hipStream_t st);
 
 // Nearest-filter mode without a low-pass: the outputs whose position falls exactly on an input sample are copies of that sample
@@ -42,7 +45,7 @@ int artfir_i8_launch (const ArtFirArgs *a, const ArtSegTable *segs, const MfmaGe
 // on; default all of them) run the plain instantiation and this pass behind it on the same stream: the flagged slots (tile_w0 [3 st + 1], 32-row slot tiles) of every period
 // are overwritten with their samples — the same values the PASS epilogues store.  Returns true if the launch is to run that way.
 bool artfir_pass_fixup_wanted (const ArtFirArgs *a);
-void artfir_pass_fixup (const ArtFirArgs *a, const MfmaGeom &g, hipStream_t st);
+int  artfir_pass_fixup (const ArtFirArgs *a, const MfmaGeom &g, hipStream_t st);        // 0, or -1: not launched
 
 namespace {
 
@@ -96,6 +99,7 @@ struct ArtRowsCache {
     int last_slot, next_slot;             // where the last launch looked up started and where a launch that continues it will (tried before the scan)
     double *c_ph; int *c_ip, *c_fi;       // [cap >= P]
     double c_base; int c_lin; unsigned int c_n0;              // ... as the device evaluates it: epoch offset, ring-to-linear shift, first output
+    long long c_origin;                   // ArtFirArgs.lin_origin of the founding launch: (w + lin_origin - c_origin) frames is a launch's distance from the period IN THE STREAM
     // the fixed-point kernel's sets built for it
     int lowpass, tr, ktot, tiles, g, slot_tiles, ktot32; size_t set_bytes;
     int nsets, victim, valid [4], w_build [4];
@@ -179,6 +183,27 @@ __attribute__ ((unused)) static bool artfir_rows_canonical (const ArtFirArgs *a_
             if (fabs (w_exact - (double) wr) > 1e-6) break;
             found = true; slot0 = s; w = wr;
         }
+        // Several periods at a time (P = mu x period_out): slots s, s + period_out, ... are the same phase, and the launch's first output is ONE of them in the
+        // stream's own tiling — the one a whole number of P-periods (Q frames) behind its canonical slot.  Round 5 always took the first: right where
+        // period_out is a multiple of the 32-row tiles (160: slot s + 160 sits in the same row of a tile five further on, on the same K chunks), wrong where it
+        // is not (96k -> 44.1k: 147 x 3 — a launch that starts in its period's second or third part was anchored 147 / 294 slots off the tiling a longer launch
+        // walks: other tile rows, other K chunks, the last bits moved with the cut; tests/test_gpu_cut_invariance.py, round 6).  Which part: from the frames
+        // between the launch and the canonical period — the stream's positions alone, not a context's history.
+        if (found && P0 < P && Q % (P / P0) == 0) {
+            const int mu = P / P0, Q0 = Q / mu;
+            // (w counts linear frames, whose origin moves with every call: the distance in the stream is w + the calls' input in between)
+            const long long w_stream = (long long) w + (a_in->lin_origin - rc->c_origin);
+            if (w_stream % Q0 == 0) {
+                const int k = (int)(((w_stream / Q0) % mu + mu) % mu), sk = slot0 + k * P0;
+                if (k && sk < P) {
+                    double d = fabs (rc->c_ph [sk] - pos0.ph);
+                    if (d > 0.5 * F) d = F - d;
+                    const double w_exact = ((double) pos0.ip + pos0.ph / F) - ((double) rc->c_ip [sk] + rc->c_ph [sk] / F);
+                    const int wr = (int) floor (w_exact + 0.5);
+                    if (d <= tol && fabs (w_exact - (double) wr) <= 1e-6 && ((long long) wr + (a_in->lin_origin - rc->c_origin)) % Q == 0) { slot0 = sk; w = wr; }
+                }
+            }
+        }
         if (found && !a_in->interpolate && verify_nearest)    // nearest filter: the canonical rounded filter index in every slot, from this launch's own positions
             for (int t = 0; t < P && found; ++t) {                // (its first P outputs are slots s, s + 1, ... of the canonical period, wrapping into the next)
                 const unsigned int n = a_in->n_begin + (unsigned int) t;
@@ -198,7 +223,7 @@ __attribute__ ((unused)) static bool artfir_rows_canonical (const ArtFirArgs *a_
         // and constants the row workgroups can evaluate themselves)
         int e = 0;
         while (e + 1 < segs->count && segs->first [e + 1] <= a_in->n_begin) ++e;
-        rc->c_base = segs->base [e]; rc->c_lin = segs->lin_base [e]; rc->c_n0 = a_in->n_begin;
+        rc->c_base = segs->base [e]; rc->c_lin = segs->lin_base [e]; rc->c_n0 = a_in->n_begin; rc->c_origin = a_in->lin_origin;
         ArtSegTable one; one.count = 1; one.lin_floor = segs->lin_floor; one.first [0] = 0u; one.lin_base [0] = rc->c_lin; one.base [0] = rc->c_base;
         for (int i = 0; i < P; ++i) { const HostPos p = host_locate (a_in, &one, rc->c_n0 + (unsigned int) i); rc->c_ph [i] = p.ph; rc->c_ip [i] = p.ip; rc->c_fi [i] = p.fi; }
         rc->bank = (const void *) a_in->bank; rc->T = a_in->T; rc->F = a_in->F; rc->interp = a_in->interpolate; rc->P = P; rc->Q = Q; rc->ratio = a_in->ratio;

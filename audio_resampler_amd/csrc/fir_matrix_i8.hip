@@ -225,7 +225,7 @@ __device__ __forceinline__ void stage_slice (const ArtFirArgs &a, const MfmaGeom
     const unsigned int voff_out = (unsigned int)(bl0 * a.C + c) * 4u;       // (bl0 counts from the region's start)
     // (the call's head as one contiguous float array, for the stand-by's tiles that reach into the history)
     const __amdgpu_buffer_rsrc_t r_head = make_rsrc (g.head, g.head ? (unsigned int) g.head_frames * row : 0u);
-    const unsigned int voff_head = (unsigned int)((lin0 + MF_HEAD_PAD) * a.C + c) * 4u;
+    const unsigned int voff_head = (unsigned int)((lin0 + g.head_pad) * a.C + c) * 4u;
 #pragma unroll
     for (int k = 0; k < I8_STAGE_K; ++k) {
         if (bl0 + k * per_k < bl_end) {
@@ -385,7 +385,7 @@ void i8_stage_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g, I8Geom q)
     const int slice = xid % q.slices, xb = xid / q.slices, eb = xb / groups, cgi = xb - eb * groups;
     const int gb0 = q.b0 + eb * q.eb_step;                      // the region's first block
     // (slices that start inside the history ++ head span — the first few — read two arrays and leave the stand-by its head)
-    if (4 * (gb0 + slice * q.slice_blocks) - I8_PADF < max (a.H, g.head_frames - MF_HEAD_PAD)) stage_slice<true, PEAK> (a, g, q, eb, cgi, slice, gb0);
+    if (4 * (gb0 + slice * q.slice_blocks) - I8_PADF < max (a.H, g.head_frames - g.head_pad)) stage_slice<true, PEAK> (a, g, q, eb, cgi, slice, gb0);
     else stage_slice<false, PEAK> (a, g, q, eb, cgi, slice, gb0);
 }
 
@@ -1769,7 +1769,7 @@ int artfir_i8_launch (const ArtFirArgs *a_in, const ArtSegTable *segs, const Mfm
         switch (cgt) { case 32: I8_SLAB (32); break; case 16: I8_SLAB (16); break; case 8: I8_SLAB (8); break; default: I8_SLAB (4); }
 #undef I8_SLAB
         if (a->ev_stop) arthip_event_record (a->ev_stop, (void *) st);
-        if (fixup) artfir_pass_fixup (a, g, st);
+        if (fixup && artfir_pass_fixup (a, g, st)) return -1;
 #ifdef I8_SLAB_TRACE
         {
             static int n_launch = 0;
@@ -1803,7 +1803,7 @@ int artfir_i8_launch (const ArtFirArgs *a_in, const ArtSegTable *segs, const Mfm
 #undef I8_DMA
 #undef I8_GO
     if (a->ev_stop) arthip_event_record (a->ev_stop, (void *) st);
-    if (fixup) artfir_pass_fixup (a, g, st);
+    if (fixup && artfir_pass_fixup (a, g, st)) return -1;
     return 1;
 }
 

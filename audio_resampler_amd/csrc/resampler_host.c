@@ -60,6 +60,7 @@ struct artamd_resampler {
     ArtamdSegment *segs; int seg_cap;
     int floor_active;                       /* ring index 0 is a hard history floor (after a flush-time rewind) */
     int kernel_pref, last_kernel;
+    long long lin_origin;                    /* input frames appended since init / reset (ArtFirArgs.lin_origin) */
     unsigned int invariant_fallbacks;        /* launches the cut-invariant policy had to give to the general kernel (resampleHipCutInvariantFallbacks) */
     int stream_channels;                     /* a shard: channels of the whole stream (kernel choice); 0 otherwise */
     /* cached rational structure of the current ratio */
@@ -689,7 +690,12 @@ void resampleFree (Resample *cxt)
         arthip_event_destroy (hip->ev_parent);
         free (hip->shards); free (hip->shard_first); free (hip->ev_shard);
         bank_release (hip->bank); arthip_free (hip->d_hist [0]); arthip_free (hip->d_hist [1]);
-        arthip_free (hip->d_in); arthip_free (hip->d_out); arthip_free (hip->d_tmp); arthip_free (hip->d_fix); arthip_free (hip->d_scratch); arthip_free (hip->d_pad); arthip_free (hip->d_planes); arthip_free (hip->d_rows); if (hip->rows_cache) { arthip_fir_rows_cache_free (hip->rows_cache); free (hip->rows_cache); } arthip_free (hip->d_split); arthip_free (hip->d_patch); arthip_free (hip->d_batch);
+        {   /* every device buffer the context may have grown (NULL where it never did) */
+            void *const device_buffers [] = { hip->d_in, hip->d_out, hip->d_tmp, hip->d_fix, hip->d_scratch, hip->d_pad, hip->d_planes, hip->d_rows,
+                                              hip->d_split, hip->d_patch, hip->d_batch };
+            for (size_t i = 0; i < sizeof (device_buffers) / sizeof (device_buffers [0]); ++i) arthip_free (device_buffers [i]);
+        }
+        if (hip->rows_cache) { arthip_fir_rows_cache_free (hip->rows_cache); free (hip->rows_cache); }
         arthip_host_free (hip->h_in); arthip_host_free (hip->h_out);
         for (int i = 0; i < hip->ev_cap; ++i) arthip_event_destroy (hip->ev [i]);
         if (hip->own_stream) arthip_stream_destroy (hip->stream);
@@ -717,7 +723,7 @@ void resampleReset (Resample *cxt)
         arthip_zero (hip->d_hist [1], hist_bytes, hip->stream);
         LEAVE_DEVICE (hip);
     }
-    hip->floor_active = 0;
+    hip->floor_active = 0; hip->lin_origin = 0;
     cxt->outputOffset = cxt->numTaps / 2;
     cxt->inputIndex = cxt->numTaps;
 
@@ -1139,7 +1145,7 @@ static int consume_silently (Resample *cxt, const art_s *d_in, long in_pitch, in
     if (res.output_generated || (int) res.input_used != frames) return -1;
 
     if (arthip_roll_history (hip->d_hist [hip->cur ^ 1], hip->d_hist [hip->cur], d_in, in_pitch, frames, H, C, hip->stream)) return -1;
-    hip->cur ^= 1;
+    hip->cur ^= 1; hip->lin_origin += frames;
     cxt->outputOffset = pos.outputOffset; cxt->inputIndex = pos.inputIndex;
     hip->floor_active = pos.floorActive;
     return 0;
@@ -1225,6 +1231,7 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
         a.out = d_out; a.out_pitch = out_pitch;
         a.C = C; a.T = T; a.F = cxt->numFilters; a.H = H;
         a.stream_C = hip->stream_channels;
+        a.lin_origin = hip->lin_origin;
         a.interpolate = (cxt->flags & SUBSAMPLE_INTERPOLATE) != 0;
         a.lowpass = (cxt->flags & INCLUDE_LOWPASS) != 0;
         /* the double-precision build has one arithmetic: EXTEND_CONVOLUTION_MATH only matters for 4-byte samples
@@ -1355,7 +1362,7 @@ static ResampleResult enqueue_call (Resample *cxt, const art_s *d_in, long in_pi
     if (appended > 0) {
         if (!rolled)
             arthip_roll_history (hip->d_hist [hip->cur ^ 1], hip->d_hist [hip->cur], is_flush ? flush_in : d_in, is_flush ? 0 : in_pitch, appended, H, C, hip->stream);
-        hip->cur ^= 1;
+        hip->cur ^= 1; hip->lin_origin += appended;
     }
 
     cxt->outputOffset = trial.outputOffset; cxt->inputIndex = trial.inputIndex;
@@ -1413,6 +1420,7 @@ static int batch_plan (Resample *cxt, const art_s *d_in, int nIn, art_s *d_out, 
     a->mode = (!ART_WIDE && (cxt->flags & EXTEND_CONVOLUTION_MATH)) ? ART_MODE_PRECISE : ART_MODE_FAST;
     a->ratio = eff_ratio;
     a->period_out = hip->period_out; a->period_in = hip->period_in;
+    a->lin_origin = hip->lin_origin;
 
     tab->count = nseg; tab->lin_floor = lin_floor;
     for (int s = 0; s < nseg; ++s) {
@@ -1476,7 +1484,7 @@ int resampleProcessBatchInterleavedDevice (Resample *const *cxts, int n, const a
         }
         for (int k = 0; k < gathered; ++k) {
             Resample *cxt = cxts [owner [k]];
-            if (args [k].roll_dst) cxt->hip->cur ^= 1;
+            if (args [k].roll_dst) { cxt->hip->cur ^= 1; cxt->hip->lin_origin += args [k].roll_appended; }
             cxt->outputOffset = trials [k].outputOffset; cxt->inputIndex = trials [k].inputIndex;
             cxt->flags = (cxt->flags & ~(RESAMPLER_FLUSHED | EXTRAPOLATE_PREFILL)) | (trials [k].flags & RESAMPLER_FLUSHED);
             cxt->hip->floor_active = trials [k].floorActive;

@@ -157,7 +157,9 @@ def other_configs(A, torch, steps, warmup):
         fixed_state, pairs = rs.fixed_point()
         interp = bool(rs.L.resampleInterpolationUsed(rs.p))
         g = math.gcd(src, dst)
-        kpad = ((taps + int(31.0 * (src // g) / (dst // g)) + 2 + 3 + 31) // 32) * 32
+        # (K columns a tile walks: 64-slot tiles of the slab kernel spread their rows' window starts twice as far as 32-slot tiles)
+        rows = 64 if rs.fixed_point_kernel() == "fir_i8_slab_kernel" else 32
+        kpad = ((taps + int((rows - 1.0) * (src // g) / (dst // g)) + 2 + 3 + 31) // 32) * 32
         rate = n_ev / (ms * 1e-3) if ms > 0 else 0.0
         if kernel == 2 and fixed_state == 1:
             name, ops, peak, unit = rs.fixed_point_kernel() or "fir_i8", 2 * kpad * pairs, PEAK_I8_TOPS, "TOP/s"
@@ -462,7 +464,13 @@ def main():
         # lerp = 4T+3 flop) at the same speed is reported separately and may exceed the peak.
         per_launch_samples = out_frames * Cn / max(launches, 1)
         avg_ms = kernel_ms / max(launches, 1)
-        kpad = ((TAPS + 31 + 31) // 32) * 32
+        # K columns a tile walks: T + the spread of its rows' window starts + alignment, a whole number of 32-tap images — 1,024 for the 32-slot tiles
+        # (f32 kernels, fir_i8_dma / _stream), 1,056 = 33 images for the 64-slot tiles of fir_i8_slab_kernel (the slab kernel had been priced at
+        # 1,024, understating what it executes by 3 %)
+        def k_columns(rows):
+            return ((TAPS + int((rows - 1.0) * 147 / 160) + 2 + 3 + 31) // 32) * 32
+        kpad_f32 = k_columns(32)
+        kpad = k_columns(64) if fixed_kernel_name == "fir_i8_slab_kernel" else kpad_f32
         fixed = kernel_used == 2 and fixed_state == 1
         # fixed-point kernel: every (sample, K column) costs one integer multiply-add per digit pair issued (13, or 9 where the
         # rows' most significant digit plane is all zero: resampleHipLastFixedPoint reports the average)
@@ -524,7 +532,7 @@ def main():
                          "unit_note": "integer multiply-adds of v_mfma_i32_32x32x32_i8, 2 ops each (TOP/s), against the dense int8 MFMA peak" if fixed else "f32 MFMA",
                          "frac": round(tflops_exec / peak, 4),
                          "frac_of_sustained_live_peak": round(tflops_exec / SUSTAINED_LIVE_I8_TOPS, 4) if fixed else None,
-                         "frac_at_round3_products": round(rate * 2 * kpad * 9.5 / 1e12 / peak, 4) if fixed else None,
+                         "frac_at_round3_products": round(rate * 2 * kpad_f32 * 9.5 / 1e12 / peak, 4) if fixed else None,
                          "frac_at_round3_products_note": ("the same samples/s priced at round 3's 9.5 products per chunk (this round skips the products with the "
                                                           "rows' second digit plane where it is all zero: fewer operations EXECUTED, so `frac` does not rise "
                                                           "with the speed-up; this figure is the one comparable with rounds 2-3)") if fixed else None,
@@ -539,7 +547,7 @@ def main():
                          "prep_note": "HIP events: what each launch spends before its dominant kernel (fixed point: peak pass + digit-plane staging pass; f32: row-table pass)",
                          "flop_per_sample_executed": round(executed_per_sample, 1), "bytes_per_sample": round(BYTES_PER_SAMPLE, 3),
                          "digit_pairs_per_chunk": round(fixed_pairs, 3) if fixed else None,
-                         "f32_mfma_equivalent_frac": round(rate * 2 * kpad / 1e12 / PEAK_FP32_TFLOPS, 4) if kernel_used == 2 else None,
+                         "f32_mfma_equivalent_frac": round(rate * 2 * kpad_f32 / 1e12 / PEAK_FP32_TFLOPS, 4) if kernel_used == 2 else None,
                          "useful_frac": round(tflops_useful / peak, 4),
                          "algorithmic_vs_reference_formulation": round(tflops_ref_form / PEAK_FP32_TFLOPS, 4),
                          "note": "achieved/frac = operations the kernel EXECUTES on the matrix cores (2 x Kpad per sample, lerp folded into one "
@@ -559,7 +567,7 @@ def main():
             f_launches = max(f32[3], 1)
             f_rate = f32[1] * Cn / f_launches / (f32[2] / f_launches * 1e-3)
             line["value_f32"] = round(agg_f32["samples_total"] / agg_f32["seconds_max"] / 1e6, 2)
-            line["f32_frac"] = round(f_rate * 2 * kpad / 1e12 / PEAK_FP32_TFLOPS, 4)
+            line["f32_frac"] = round(f_rate * 2 * kpad_f32 / 1e12 / PEAK_FP32_TFLOPS, 4)
             line["f32_avg_kernel_ms"] = round(f32[2] / f_launches, 4)
             line["value_f32_note"] = ("same W + K steps with the f32 matrix-core kernel pinned (kernel preference 6: exact-f32 FMA chains with fp64 flushes — "
                                       "what launches below the fixed-point threshold, and the fixed-point kernel's stand-by, run); f32_frac = executed "

@@ -131,22 +131,27 @@ def test_cut_invariant_policy_any_cut_default_kernel_preference(stream, rates):
         assert hashlib.sha256(y.tobytes()).hexdigest() == want, (name, int(np.count_nonzero(y.view(np.uint32) != ref.view(np.uint32))))
 
 
-def test_reference_artest_fixed_ratio_block_size_invariance_on_the_library():
-    """SURVEY appendix C, the reference's own test program (oracle/_ref/artest_amd = artest.c on this library): `-e` output has ONE checksum at
-    every -b — under the policy (ARTAMD_KERNEL=9) in the DEFAULT numeric mode, as under ARTAMD_STRICT=1."""
+def test_reference_artest_fixed_ratio_block_size_invariance_on_the_library(tmp_path):
+    """SURVEY appendix C, with the reference's own test program (oracle/_ref/artest_amd = artest.c on this library): the `-e` output of ONE raw
+    source stream (written once by `artest -w1`, read back with `-r -a`) has one checksum at every -b — under the policy (ARTAMD_KERNEL=9) in the
+    DEFAULT numeric mode, as it has in the reference and under ARTAMD_STRICT=1."""
     import os, re, subprocess
     from _oracle import ORACLE_DIR
-    exe = os.path.join(ORACLE_DIR, "_ref", "artest_amd")
-    if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/artest_amd not built (needs /root/reference at build time)")
-    sums = {}
-    for args in ("-3 -e -c2 -n3 -s44100 -d48000", "-4 -e -l -c8 -n2 -s96000 -d44100"):
+    exe, gen = os.path.join(ORACLE_DIR, "_ref", "artest_amd"), os.path.join(ORACLE_DIR, "_ref", "artest_strict")
+    if not (os.path.exists(exe) and os.path.exists(gen)):
+        pytest.skip("oracle/_ref/artest_* not built (needs /root/reference at build time)")
+    for ch, rates, preset in ((2, "-s44100 -d48000", "-3"), (8, "-s96000 -d44100", "-4 -l")):
+        raw = tmp_path / f"src{ch}.raw"
+        with open(raw, "wb") as f:
+            p = subprocess.run([gen] + f"-3 -c{ch} -n3 {rates} -a -w1".split(), stdout=f, stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0 and raw.stat().st_size > 100000, p.stderr[-1500:]
+        got = set()
         for b in (256, 1000, 4096, 65536):
             env = dict(os.environ, ARTAMD_KERNEL="9"); env.pop("ARTAMD_STRICT", None)
-            p = subprocess.run([exe] + args.split() + [f"-b{b}"], capture_output=True, text=True, env=env, timeout=600)
+            with open(raw, "rb") as f:
+                p = subprocess.run([exe] + f"{preset} -e -c{ch} {rates} -r -a -b{b}".split(), stdin=f, capture_output=True, text=True, env=env, timeout=600)
             assert p.returncode == 0, p.stderr[-1500:]
             m = re.search(r"output \(-w\d\): count =\s*(\d+), checksum = ([0-9a-f]{16})", p.stderr)
             assert m, p.stderr[-1500:]
-            sums.setdefault(args, set()).add((m.group(1), m.group(2)))
-    for args, got in sums.items():
-        assert len(got) == 1, (args, got)
+            got.add((m.group(1), m.group(2)))
+        assert len(got) == 1, (ch, rates, got)
