@@ -181,7 +181,7 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
             }
             else if constexpr (LEAN) {
                 // The plain loop below, instruction for instruction leaner (the kernel is bound by vector-instruction ISSUE — ~210 wave
-                // instructions per pass of two outputs for its 12 packed multiply-adds at 380 taps, tools/attic/fir_cell_kernel_r5.txt —
+                // instructions per pass of two outputs for its 12 packed multiply-adds at 380 taps, profiles/r5_config_e.txt; the shelved cell kernel is in git history, tools/attic/ up to round 5 —
                 // not by the trips its loads make): R steps at a time, their coefficient loads (buffer loads: one address per lane and
                 // side, the step in the instruction's offset) and LDS reads (likewise) all issued before the first multiply-add, no loop
                 // control or address arithmetic between them.  A lane takes the same taps in the same order: the same bits.

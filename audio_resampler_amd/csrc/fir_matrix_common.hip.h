@@ -189,7 +189,8 @@ __attribute__ ((unused)) static bool artfir_rows_canonical (const ArtFirArgs *a_
         // is not (96k -> 44.1k: 147 x 3 — a launch that starts in its period's second or third part was anchored 147 / 294 slots off the tiling a longer launch
         // walks: other tile rows, other K chunks, the last bits moved with the cut; tests/test_gpu_cut_invariance.py, round 6).  Which part: from the frames
         // between the launch and the canonical period — the stream's positions alone, not a context's history.
-        if (found && P0 < P && Q % (P / P0) == 0) {
+        static const bool first_slot = [] { const char *e = getenv ("ARTAMD_ROWS_FIRST_SLOT"); return e && *e == '1'; } ();      // (A/B runs: round 5's choice)
+        if (found && P0 < P && Q % (P / P0) == 0 && !first_slot) {
             const int mu = P / P0, Q0 = Q / mu;
             // (w counts linear frames, whose origin moves with every call: the distance in the stream is w + the calls' input in between)
             const long long w_stream = (long long) w + (a_in->lin_origin - rc->c_origin);
