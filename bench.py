@@ -485,7 +485,7 @@ def main():
         # with the gfx950 wide-read correction + WRITE_SIZE); it cannot be taken inside this process, so the committed
         # per-launch figure is reported when — and only when — this run is the workload it was measured on.
         traffic = traffic_source = None
-        for name in ([args.pmc_json] if args.pmc_json else []) + ["r5_traffic.json", "r4_traffic.json"]:
+        for name in ([args.pmc_json] if args.pmc_json else []) + ["r6_traffic.json", "r5_traffic.json", "r4_traffic.json"]:
             try:
                 tr = json.load(open(name if os.path.isabs(name) or os.path.exists(name) else os.path.join(ROOT, "profiles", name)))
                 w = tr["workload"]

@@ -78,7 +78,8 @@ void resampleHipSetKernel (Resample *cxt, int which);
  * guarantee held for every output so far.  Equivalent: resampleHipSetKernel (cxt, 9), ARTAMD_KERNEL=9.
  * What it costs against the library's own choice (tools/bench_cut_invariant.py, profiles/r6_cut_invariant.txt): nothing is free — small calls lose the
  * general kernel's short launch, mid-sized calls of long filters the K split, big calls the fixed-point kernel — which is why it is a context
- * setting and not the default.  RESAMPLE_STRICT_ORDER (bit-exact reference order) and preference 1 (the general kernel alone) are cut-invariant too. */
+ * setting and not the default.  RESAMPLE_STRICT_ORDER (bit-exact reference order) and preference 1 (the general kernel alone) are cut-invariant too.
+ * (4-byte samples.  The 8-byte build has no kept rows: there the setting is preference 2 — use RESAMPLE_STRICT_ORDER or preference 1.) */
 void resampleHipSetCutInvariant (Resample *cxt, int on);
 unsigned int resampleHipCutInvariantFallbacks (Resample *cxt);
 /* The streaming matrix kernels keep their filter rows across the calls of a context (built once for the stream's canonical period; every later

@@ -13,18 +13,18 @@
  * init functions return NULL (message on stderr) without one.
  *
  * One deviation from the reference to know about.  The reference's fixed-ratio output (resampler.c:323-335,
- * 533-535) is bitwise independent of how the input is cut into calls.  Here that holds with
- * RESAMPLE_STRICT_ORDER (art_hip.h: the reference's own summation order, bit for bit), and — since the matrix
- * kernels keep their filter rows across calls and anchor every launch's tiles on the stream's canonical period —
- * on the f32 matrix-core streaming kernel alone (resampleHipSetKernel (cxt, 6), art_hip.h): a stream initialised
- * with resampleFixedRatioInit gives the same bits for any cut into calls of at least one period of outputs
- * (1,000 frames is plenty), from host buffers of any length or from device buffers aligned to a frame (one or
- * two channels) / to 16 bytes (four channels and more) (tests/test_gpu_cut_invariance.py).  In the DEFAULT mode
- * the size of a call picks the kernel (general / f32 matrix cores / fixed point on the integer matrix
- * cores), each of which rounds differently inside the parity bar: the same stream cut into other blocks
- * gives output that is within 2^-23 max(1,|y|) of the double-accumulate result either way — two cuts differ
- * by at most twice that — but not the same bits (tests/test_gpu_parity.py: bounded there).  Counts and
- * positions (input_used, output_generated, resampleGetPosition) do not depend on the cut in any mode.
+ * 533-535) is bitwise independent of how the input is cut into calls.  In the DEFAULT mode of this library the size
+ * of a call picks the kernel (general / f32 matrix cores, K split or not / fixed point on the integer matrix
+ * cores), each of which rounds differently inside the parity bar: the same stream cut into other blocks gives
+ * output within 2^-23 max(1,|y|) of the double-accumulate result either way — two cuts differ by at most twice
+ * that — but not the same bits (tests/test_gpu_parity.py: bounded there; what that means in a 16- or 24-bit
+ * file: tests/test_gpu_pcm_default_mode.py).  The reference's property is available three ways (art_hip.h):
+ * RESAMPLE_STRICT_ORDER (the reference's own summation order, bit for bit, slow); the general kernel alone
+ * (resampleHipSetKernel (cxt, 1)); and the cut-invariant stream policy, resampleHipSetCutInvariant (cxt, 1) /
+ * ARTAMD_KERNEL=9 — one arithmetic per stream, the f32 matrix-core streaming kernel anchored on the stream's
+ * canonical period for every launch of any size: the same bits for ANY cut into calls, host or device buffers
+ * (tests/test_gpu_cut_invariance.py; its cost per call: DESIGN.md 4.1).  Counts and positions (input_used,
+ * output_generated, resampleGetPosition) do not depend on the cut in any mode.
  *
  * Device-pointer / stream extensions live in art_hip.h.
  */
