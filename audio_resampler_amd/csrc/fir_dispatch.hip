@@ -1,5 +1,7 @@
 // fir_dispatch.hip — arthip_fir: one FIR call -> the kernel that runs it (strict order, matrix cores, general).
 #include "fir_common.hip.h"
+#include <atomic>
+#include <cstdlib>
 
 extern "C" {
 
@@ -108,6 +110,12 @@ int arthip_fir (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref, v
     hipStream_t st = (hipStream_t) stream;
 
     if (a->n_end <= a->n_begin) return ART_KERNEL_GENERAL;
+    {   // (test hook, tests/test_gpu_failure_path.py: ARTAMD_TEST_FAIL_FIR=k makes the k-th FIR launch of the process fail before anything is enqueued —
+        // the only way to see the host's failure path without breaking a device)
+        static const int fail_at = [] { const char *e = getenv ("ARTAMD_TEST_FAIL_FIR"); return e && *e ? atoi (e) : 0; } ();
+        static std::atomic<int> launches { 0 };
+        if (fail_at > 0 && ++launches == fail_at) return -1;
+    }
     artfir_rows_touch (a, segs);                              // (the canonical period of the rows kept across calls: every launch looks after it)
 
     if (a->segs_truncated && ((a->mode & 3) == ART_MODE_STRICT || !artfir_matrix_spans_segments (a, segs, kernel_pref))) return -2;

@@ -26,7 +26,7 @@ def pytest_configure(config):
 # 3 = bench.py and multi-rank launches.  Within a class the usual (alphabetical, definition) order stays.
 _FIRST = ("test_gpu_parity", "test_gpu_rows_cache", "test_gpu_cut_invariance", "test_gpu_fullsize", "test_gpu_fixed_point", "test_gpu_fuzz", "test_wide", "test_stretch",
           "test_oracle_golden", "test_oracle_vs_ref", "test_host_logic")
-_CHILD = ("test_gpu_general_pipe", "test_gpu_asrc", "test_gpu_pass_fixup", "test_gpu_slab_kernel", "test_gpu_dropin", "test_gpu_pcm_default_mode")
+_CHILD = ("test_gpu_failure_path", "test_gpu_general_pipe", "test_gpu_asrc", "test_gpu_pass_fixup", "test_gpu_slab_kernel", "test_gpu_dropin", "test_gpu_pcm_default_mode")
 _WIDE_CHILD = ("test_reference_artest64_binary_on_the_hip_library_matches_reference_checksums", "test_art64_cli_on_hip_library_writes_the_same_file_as_reference_art64")
 _LAUNCH = ("test_gpu_bench_ranks", "test_shard_gloo")
 

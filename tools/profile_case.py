@@ -52,7 +52,9 @@ elif case == "matrix_D32":     # BASELINE configs[3] on ONE GPU: all 32 channels
 elif case in ("fixed_D4", "fixed_D32"):     # the same two shapes as the library runs them: the fixed-point kernel (integer matrix cores)
     step, rs = resampler_case(4, 988, 988, BH | IN, 1 << 20) if case == "fixed_D4" else resampler_case(32, 988, 988, BH | IN, 1 << 18)
     step(); state, pairs = rs.fixed_point(); assert state == 1, state
-    info.update(kernel="fir_i8_", flop_per_sample=round(2 * 1024 * pairs, 1), bytes_per_sample=4 * 44100 / 48000 + 4, peak="i8")
+    # (K columns a tile walks: 33 images for the 64-slot tiles of the slab kernel, 32 for the 32-slot kernels — as bench.py prices them since round 6)
+    kcols = 1056 if rs.fixed_point_kernel() == "fir_i8_slab_kernel" else 1024
+    info.update(kernel="fir_i8_", flop_per_sample=round(2 * kcols * pairs, 1), bytes_per_sample=4 * 44100 / 48000 + 4, peak="i8")
 elif case == "strict":         # RESAMPLE_STRICT_ORDER: the parity instrument
     step, rs = resampler_case(8, 988, 988, BH | IN | A.RESAMPLE_STRICT_ORDER, 1 << 16)
     info.update(kernel="fir_strict_kernel", flop_per_sample=4 * 988 + 3, bytes_per_sample=4 * 44100 / 48000 + 4, peak="fp32")
