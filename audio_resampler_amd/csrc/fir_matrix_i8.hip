@@ -101,7 +101,10 @@ __device__ __forceinline__ int shift_of_peak (unsigned int bits)
 }
 
 constexpr int I8_STAGE_THREADS = 256;     // workgroup of the two staging passes
-constexpr int I8_STAGE_K = 4;             // units (4 frames of one channel) per staging thread
+#ifndef I8_STAGE_UNITS
+#define I8_STAGE_UNITS 4
+#endif
+constexpr int I8_STAGE_K = I8_STAGE_UNITS;  // units (4 frames of one channel) per staging thread (-DI8_STAGE_UNITS=n: tools/micro/stage_units_ab.sh)
 
 // digits of a fixed-point value as one dword: byte 3 = d0 ... byte 0 = d3, each signed
 __device__ __forceinline__ unsigned int digits_of (int q) { return ((unsigned int) q + 0x80808080u) ^ 0x80808080u; }

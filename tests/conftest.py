@@ -28,7 +28,7 @@ _FIRST = ("test_gpu_parity", "test_gpu_rows_cache", "test_gpu_cut_invariance", "
           "test_oracle_golden", "test_oracle_vs_ref", "test_host_logic")
 _CHILD = ("test_gpu_failure_path", "test_gpu_general_pipe", "test_gpu_asrc", "test_gpu_pass_fixup", "test_gpu_slab_kernel", "test_gpu_dropin", "test_gpu_pcm_default_mode")
 _WIDE_CHILD = ("test_reference_artest64_binary_on_the_hip_library_matches_reference_checksums", "test_art64_cli_on_hip_library_writes_the_same_file_as_reference_art64")
-_LAUNCH = ("test_gpu_bench_ranks", "test_shard_gloo")
+_LAUNCH = ("test_gpu_bench_ranks", "test_shard_gloo", "test_gpu_dispatch_selfcheck")      # (the self-check TIMES kernels on the box: last, so that a slow box cannot stand in front of a parity test)
 
 
 def _run_class(item):
