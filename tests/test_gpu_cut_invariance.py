@@ -95,6 +95,7 @@ POLICY_STREAMS = [
     ((8, 988, 988, BH | INTERP), (96000.0, 44100.0)),      # BASELINE configs[2]'s conversion: 147 x 988, period_in 320
     ((2, 380, 380, BH | INTERP), (96000.0, 44100.0)),      # period_in 320 > T/2 + 64 = 254
     ((2, 156, 156, BH | INTERP), (48000.0, 32000.0)),      # 2 outputs per 3 inputs: the kernels take 16 periods at a time
+    ((6, 380, 380, BH | INTERP), (44100.0, 48000.0)),      # not a compiled width: every launch runs as a 4-wide and a 2-wide group behind copies (fir_dispatch.hip)
 ]
 
 

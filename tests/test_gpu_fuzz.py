@@ -88,7 +88,7 @@ def test_random_session_strict_bit_exact(seed):
 
 
 @pytest.mark.parametrize("seed", range(60))
-@pytest.mark.parametrize("kernel", [0, 2])
+@pytest.mark.parametrize("kernel", [0, 2, 9], ids=["auto", "matrix", "cut_invariant_policy"])
 def test_random_session_fast_within_tolerance(seed, kernel):
     s = random_session(seed)
     y, tr = play(HipResampler, s, kernel=kernel)
