@@ -1230,7 +1230,7 @@ int artfir_matrix (const ArtFirArgs *a, const ArtSegTable *segs, int kernel_pref
                 }
             }
         }
-        // the cut-invariant policy runs anchored launches only: anything else is handed to the general kernel (0: arthip_fir counts it)
+        // the cut-invariant policy runs anchored launches only: anything else is handed to the general kernel (0; the host counts it: resampleHipCutInvariantFallbacks)
         if (kernel_pref == ART_KERNEL_INVARIANT && !on_kept_rows) return 0;
         a = &a_v;
         {   static const bool trace = [] { const char *e = getenv ("ARTAMD_ROWS_TRACE"); return e && *e == '1'; } ();

@@ -30,7 +30,8 @@
 // one period + one window, quantised with each block's own exponents; a tile column stages from ITS period's block): plane p
 // (digit d_p), 4-frame block b, channel c -> one
 // dword holding frames 4b..4b+3 of that channel (byte q = frame 4b + q): [e][p][b - b0 - e * step][c].  Linear frame lin
-// (history ++ input) lives in block (lin + I8_PADF) / 4.  A tile
+// (history ++ input) lives in block (lin + pad) / 4, pad = MfmaGeom.head_pad zero frames in front of linear frame 0 (64, more where a period's input
+// is longer than half a window: a launch anchored on the canonical period starts up to Q frames in front of its first output).  A tile
 // takes every g-th period (g = 4 / gcd (Q, 4)) so that all its columns start at the same offset r in their first block; r is
 // absorbed by the tile's filter rows, which exist once per (slot tile, residue) shifted r taps to the right.  A digit planes:
 // [slot tile * g + residue][chunk][p][row][32 taps]: the 4 KB a workgroup stages per chunk are contiguous.
@@ -49,7 +50,6 @@ constexpr int I8_KC = 32;                 // taps per staged chunk = K of one in
 constexpr int I8_PITCH = 48;              // LDS bytes per (row or column, plane) of a chunk: 32 + 16 pad, conflict-free b128 reads
 constexpr int I8_COLS = 128;              // columns per workgroup
 constexpr int I8_MAX_PPW = 64;
-constexpr int I8_PADF = 64;               // zero frames in front of linear frame 0 in the digit planes
 constexpr float I8_SCALE = 1073741824.0f; // 2^30: the filter rows' fixed point
 constexpr float I8_LIMIT = 1.98f;         // |row value| the digits can hold: 0x7f7f7f7f / 2^30 = 1.98437..., rounded down
 
@@ -148,7 +148,7 @@ __device__ __forceinline__ void stage_slice (const ArtFirArgs &a, const MfmaGeom
     const int per_k = I8_STAGE_THREADS / q.cgrp;               // blocks between a thread's consecutive units
     const int bl0 = slice * q.slice_blocks + tid / q.cgrp;      // (block index inside the region)
     const int bl_end = min ((slice + 1) * q.slice_blocks, q.eb_blocks);
-    const int lin0 = 4 * (gb0 + bl0) - I8_PADF;                 // the thread's first frame (>= -I8_PADF)
+    const int lin0 = 4 * (gb0 + bl0) - g.head_pad;              // the thread's first frame (>= -head_pad)
     const unsigned int row = (unsigned int) a.C * 4u;           // bytes per frame
     const __amdgpu_buffer_rsrc_t r_in = make_rsrc (a.in, (unsigned int)((size_t) a.in_frames * row));
     const __amdgpu_buffer_rsrc_t r_hist = make_rsrc (a.hist, (unsigned int) a.H * row);
@@ -165,7 +165,7 @@ __device__ __forceinline__ void stage_slice (const ArtFirArgs &a, const MfmaGeom
         // the peak pass of a plain slice needs no frame x channel transposition: whole 16-byte vectors (4 channels of one frame)
         if (q.cgrp >= 4) {
             const int vpf = q.cgrp >> 2, cq = tid & (vpf - 1), per_f = I8_STAGE_THREADS / vpf;
-            const int f0 = 4 * (gb0 + slice * q.slice_blocks) - I8_PADF - a.H + tid / vpf, f_end = 4 * (gb0 + bl_end) - I8_PADF - a.H;
+            const int f0 = 4 * (gb0 + slice * q.slice_blocks) - g.head_pad - a.H + tid / vpf, f_end = 4 * (gb0 + bl_end) - g.head_pad - a.H;
             const unsigned int voff = (unsigned int)(f0 * a.C + cgi * q.cgrp + 4 * cq) * 4u;
             unsigned int m4 [4] = { 0u, 0u, 0u, 0u };
 #pragma unroll
@@ -332,7 +332,7 @@ void i8_stage_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g, I8Geom q)
         const Pos p = slot_pos (st * q.tr + min (row, rows_valid - 1));
         const float *h0 = a.bank + (size_t) p.fi * a.T;
         // K column 0 of this tile family sits r frames before the first slot's window (the start of its 4-frame block)
-        const int r = max (p0.ip - a.T / 2 + 1 + jr * g.Q + I8_PADF, 0) & 3;
+        const int r = max (p0.ip - a.T / 2 + 1 + jr * g.Q + g.head_pad, 0) & 3;
         const int shift = p.ip - p0.ip + r;
         bool bad = false;
         __shared__ unsigned long long s_mask, s_mask1;
@@ -388,7 +388,7 @@ void i8_stage_kernel (ArtFirArgs a, ArtSegTable segs, MfmaGeom g, I8Geom q)
     const int slice = xid % q.slices, xb = xid / q.slices, eb = xb / groups, cgi = xb - eb * groups;
     const int gb0 = q.b0 + eb * q.eb_step;                      // the region's first block
     // (slices that start inside the history ++ head span — the first few — read two arrays and leave the stand-by its head)
-    if (4 * (gb0 + slice * q.slice_blocks) - I8_PADF < max (a.H, g.head_frames - g.head_pad)) stage_slice<true, PEAK> (a, g, q, eb, cgi, slice, gb0);
+    if (4 * (gb0 + slice * q.slice_blocks) - g.head_pad < max (a.H, g.head_frames - g.head_pad)) stage_slice<true, PEAK> (a, g, q, eb, cgi, slice, gb0);
     else stage_slice<false, PEAK> (a, g, q, eb, cgi, slice, gb0);
 }
 
@@ -516,7 +516,7 @@ void fir_i8_stream_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
             if (!f_live) return;
             // (readfirstlane: the table entry arrives in a vector register, and a resource built from it would make every load a
             // waterfall loop; the value is the same in all lanes)
-            const int la = max (__builtin_amdgcn_readfirstlane (g.tile_w0 [3 * st]) + g.w_shift + j0 * g.Q + I8_PADF, 0);
+            const int la = max (__builtin_amdgcn_readfirstlane (g.tile_w0 [3 * st]) + g.w_shift + j0 * g.Q + g.head_pad, 0);
             // the tile's exponent block and its first 4-frame block inside that block's own planes
             const int eb = j0 / q.eb_periods;
             unsigned int skip = (unsigned int) max ((la >> 2) - q.b0 - eb * q.eb_step, 0) * (unsigned int)(CG * 4);
@@ -770,7 +770,7 @@ void fir_i8_dma_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, int wgs_per_xcd)
             for (f_within += wgs_per_xcd; f_within < tiles_per_xcd; f_within += wgs_per_xcd)
                 if (tile_at (f_within, st, j0)) { f_live = true; break; }
             if (!f_live) return;
-            const int la = max (tile_w0 [3 * st] + g.w_shift + j0 * g.Q + I8_PADF, 0);
+            const int la = max (tile_w0 [3 * st] + g.w_shift + j0 * g.Q + g.head_pad, 0);
             const int eb = j0 / q.eb_periods;
             unsigned int skip = (unsigned int) max ((la >> 2) - q.b0 - eb * q.eb_step, 0) * (unsigned int)(CG * 4);
             if (skip > q.eb_plane_bytes) skip = q.eb_plane_bytes;
@@ -1044,7 +1044,7 @@ void fir_i8_slab_kernel (ArtFirArgs a, MfmaGeom g, I8Geom q, I8Slab sl)
         ++f_seg;
         segment (f_seg, within, c0, f_c1);
         tile_of (within, st, j0);
-        const int la = max (tile_w0 [3 * (2 * st)] + g.w_shift + j0 * g.Q + I8_PADF, 0);     // (the origin of the pair's first 32-row slot tile)
+        const int la = max (tile_w0 [3 * (2 * st)] + g.w_shift + j0 * g.Q + g.head_pad, 0);     // (the origin of the pair's first 32-row slot tile)
         const int eb = j0 / q.eb_periods;
         unsigned int skip = (unsigned int) max ((la >> 2) - q.b0 - eb * q.eb_step, 0) * (unsigned int)(CG * 4);
         if (skip > q.eb_plane_bytes) skip = q.eb_plane_bytes;
@@ -1645,8 +1645,9 @@ int artfir_i8_launch (const ArtFirArgs *a_in, const ArtSegTable *segs, const Mfm
     HostPos pos0;
     int slot0 = 0, w = 0;
     if (!artfir_rows_canonical (a_in, segs, g.P, g.Q, rc, &pos0, &slot0, &w)) rc = nullptr;
-    // (the virtual start's window must not begin in front of the zero frames the planes hold before linear frame 0)
-    if (rc && rc->c_ip [0] + w - a_in->T / 2 + 1 + I8_PADF < 0) rc = nullptr;
+    // (the virtual start's window must not begin in front of the zero frames the planes hold before linear frame 0: head_pad covers a whole period's input —
+    // round 5's fixed 64 frames sent a third of the launches of a 96k -> 44.1k stream back to rows of their own)
+    if (rc && rc->c_ip [0] + w - a_in->T / 2 + 1 + g.head_pad < 0) rc = nullptr;
     if (rc) {
         a_v.n_begin = a_in->n_begin + (unsigned int)(g.P - slot0); a_v.n_end = a_in->n_end + (unsigned int) g.P;
         a_v.out = a_in->out - (size_t) g.P * a_in->C; a_v.n_skip = slot0;
@@ -1712,7 +1713,7 @@ int artfir_i8_launch (const ArtFirArgs *a_in, const ArtSegTable *segs, const Mfm
     {   // block of the first tile's window start: the launch's first output's position (the reference's arithmetic, host_locate), or the
         // canonical period's first slot carried to this launch
         const int ip = rc ? rc->c_ip [0] + w : pos0.ip;
-        const int la = ip - a->T / 2 + 1 + I8_PADF;
+        const int la = ip - a->T / 2 + 1 + g.head_pad;
         q.b0 = (la > 0 ? la : 0) >> 2;
     }
     const unsigned int x_wgs = (unsigned int)(q.ebs * (a->C / q.cgrp) * q.slices);

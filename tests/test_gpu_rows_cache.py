@@ -132,3 +132,37 @@ def test_cached_rows_against_rows_rebuilt_by_every_launch():
     finally:
         for f in (a, b):
             name = f.fid.name; f.close(); os.unlink(name)
+
+
+def test_every_launch_of_a_downsampling_stream_runs_on_the_kept_rows():
+    """a launch anchored on the canonical period starts up to period_in frames in front of its first output; with 64 zero frames in front of the
+    history, streams whose period_in exceeds T/2 + 64 (96k -> 44.1k: 320 x 3 against 494 + 64) sent such launches back to rows of their own — a rebuild per call,
+    and bits that moved with the cut.  The pad now covers a period's input (MfmaGeom.head_pad, both the f32 head and the fixed-point planes): ONE build per
+    stream, every later launch a hit, on the fixed-point path (1M-frame calls) and on the f32 path (300,000-frame calls)."""
+    import os, re, subprocess, sys
+    code = r'''
+import sys, os
+sys.path.insert(0, %r)
+import numpy as np, torch
+import audio_resampler_amd as A
+from audio_resampler_amd.synth import noise
+for src, dst, block in ((96000, 44100, 1048576), (96000, 44100, 300000), (48000, 32000, 1048576)):
+    ch, taps = 8, 988
+    rs = A.Resampler(ch, taps, taps, 0.0, A.BLACKMAN_HARRIS | A.SUBSAMPLE_INTERPOLATE | A.INCLUDE_LOWPASS, fixed=(float(src), float(dst), 0)); rs.advance(taps / 2.0)
+    x, _ = noise(block * ch); d_in = torch.from_numpy(x.reshape(block, ch)).cuda(); cap = int((block + taps) * dst / src) + 64; d_out = torch.empty(cap, ch, device="cuda")
+    print("== stream", file=sys.stderr)
+    for k in range(9): rs.process_device(d_in, block, d_out, cap, 0.0)
+    torch.cuda.synchronize()
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, ARTAMD_ROWS_TRACE="1"), timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    streams = p.stderr.split("== stream")[1:]
+    assert len(streams) == 3
+    for text in streams:
+        fixed = re.findall(r"rows: launch .*?cache (on|off) .*?set (-?\d+)\s+(BUILD|hit|-)", text)
+        f32 = re.findall(r"rows \(f32\): launch .*?kept (\d)\s+ready (\d)", text)
+        assert len(fixed) + len(f32) == 9, text[-1500:]
+        if fixed:
+            assert [f[0] for f in fixed] == ["on"] * 9 and [f[2] for f in fixed] == ["BUILD"] + ["hit"] * 8, fixed
+        else:
+            assert [k for k, r in f32] == ["1"] * 9 and [r for k, r in f32] == ["0"] + ["1"] * 8, f32
