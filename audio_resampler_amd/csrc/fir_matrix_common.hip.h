@@ -159,7 +159,7 @@ __attribute__ ((unused)) static bool artfir_rows_canonical (const ArtFirArgs *a_
     if (rc->cap < P) {
         free (rc->c_ph); free (rc->c_ip); free (rc->c_fi);
         rc->cap = P; rc->canon_valid = 0;
-        rc->c_ph = (double *) malloc (sizeof (double) * (size_t) rc->cap); rc->c_ip = (int *) malloc (sizeof (int) * (size_t) rc->cap); rc->c_fi = (int *) malloc (sizeof (int) * (size_t) rc->cap);
+        rc->c_ph = (double *) malloc (sizeof (double) * (size_t) rc->cap); rc->c_ip = (int *) malloc (sizeof (int) * (size_t) rc->cap); rc->c_fi = (int *) malloc (sizeof (int) * 2 * (size_t) rc->cap);       // (+ cap flags behind the indices: slots verified below)
         if (!rc->c_ph || !rc->c_ip || !rc->c_fi) { free (rc->c_ph); free (rc->c_ip); free (rc->c_fi); rc->c_ph = nullptr; rc->c_ip = rc->c_fi = nullptr; rc->cap = 0; return false; }
     }
     int slot0 = 0, w = 0;
@@ -205,7 +205,12 @@ __attribute__ ((unused)) static bool artfir_rows_canonical (const ArtFirArgs *a_
                 }
             }
         }
-        if (found && !a_in->interpolate && verify_nearest)    // nearest filter: the canonical rounded filter index in every slot, from this launch's own positions
+        // (nearest filter: the canonical rounded filter index in every slot, from this launch's own positions — P position evaluations on the host, 6 - 13 us at
+        // P = 320 on a path of ~20 us a call: done ONCE per start slot of a canonical period.  A later launch that starts on the same slot sits on the same
+        // lattice a whole number of frames on, and the launch's regularity test has already excluded slots near a half step: ADVICE r5)
+        int *const c_ok = rc->c_fi + rc->cap;
+        const bool whole_period = a_in->n_end - a_in->n_begin >= (unsigned int) P;
+        if (found && !a_in->interpolate && verify_nearest && !c_ok [slot0]) {
             for (int t = 0; t < P && found; ++t) {                // (its first P outputs are slots s, s + 1, ... of the canonical period, wrapping into the next)
                 const unsigned int n = a_in->n_begin + (unsigned int) t;
                 if (n >= a_in->n_end) break;
@@ -217,6 +222,8 @@ __attribute__ ((unused)) static bool artfir_rows_canonical (const ArtFirArgs *a_
                 const HostPos p = host_locate (a_in, segs, n);
                 found = (long long) p.ip * a_in->F + p.fi == ((long long) rc->c_ip [sp] + w + (long long) Q * (sidx / P)) * a_in->F + rc->c_fi [sp];
             }
+            if (found && whole_period) c_ok [slot0] = 1;
+        }
         if (!found) rc->canon_valid = 0;
     }
     if (!rc->canon_valid) {                                   // a new canonical period: this launch's first
@@ -228,6 +235,7 @@ __attribute__ ((unused)) static bool artfir_rows_canonical (const ArtFirArgs *a_
         ArtSegTable one; one.count = 1; one.lin_floor = segs->lin_floor; one.first [0] = 0u; one.lin_base [0] = rc->c_lin; one.base [0] = rc->c_base;
         for (int i = 0; i < P; ++i) { const HostPos p = host_locate (a_in, &one, rc->c_n0 + (unsigned int) i); rc->c_ph [i] = p.ph; rc->c_ip [i] = p.ip; rc->c_fi [i] = p.fi; }
         rc->bank = (const void *) a_in->bank; rc->T = a_in->T; rc->F = a_in->F; rc->interp = a_in->interpolate; rc->P = P; rc->Q = Q; rc->ratio = a_in->ratio;
+        for (int i = 0; i < P; ++i) (rc->c_fi + rc->cap) [i] = 0;
         rc->canon_valid = 1; slot0 = 0; w = 0;
         for (int k = 0; k < 4; ++k) rc->valid [k] = 0;
         rc->f_valid = 0;
