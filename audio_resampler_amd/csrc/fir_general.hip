@@ -20,7 +20,7 @@ constexpr int GEN_MAX_TILE = 48;
 // reduction and the per-output bookkeeping are then paid once per FOUR outputs, which is most of the cost when taps x
 // channels is small).  G depends on the tap count only, never on the tile, so a frame's value does not depend on how a
 // call is cut up.
-template <int CG, bool INTERP, bool PRECISE, int G, bool PIPE = false, bool LEAN = false>
+template <int CG, bool INTERP, bool PRECISE, int G, bool PIPE = false, int LEAN = 0>
 __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const ArtSegTable &segs, int tile, unsigned int bx, unsigned int by)
 {
     constexpr int SUBS = 64 / G;
@@ -69,6 +69,32 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
 
     const int lin_lo = s_ip [0] - half + 1;
     const int span = s_ip [cnt - 1] + half + 1 - lin_lo;
+
+    // LEAN == 2 (round 6, stereo streams; tools/micro/general_lean_first.sh): the lean loop with the FIRST round's coefficient loads of the wave's first output issued
+    // before the tile's span is staged — they need the filter index only, so that trip to the L2 and the staging's overlap; 2 x R registers, not the 2 x steps
+    // of the all-at-once form that lost its occupancy (profiles/r6_config_e.txt).  Same taps, same order: same bits.
+    constexpr int RL = CG >= 2 ? 3 : 6;
+    art_s pre0 [LEAN == 2 ? RL : 1] [2], pre1 [LEAN == 2 && INTERP ? RL : 1] [2];
+    if constexpr (LEAN == 2) {
+        constexpr unsigned int SZ = sizeof (art_s);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc (const_cast<art_s *> (a.bank), 0, (int)((unsigned int)(a.F + 1) * (unsigned int) a.T * SZ), 0x00020000);
+        constexpr int SUBS_ = 64 / G;
+        const int i_first = wave * SUBS_ + sub < cnt ? wave * SUBS_ + sub : cnt - 1;
+        const int steps = (half + G - 1) / G, le = l < half ? l : 0;
+        const unsigned int row = (unsigned int) s_fi [i_first] * (unsigned int) a.T;
+        const unsigned int lo = (row + (unsigned int) le) * SZ, hi = (row + (unsigned int)(a.T - 1 - le)) * SZ, next_row = INTERP ? (unsigned int) a.T * SZ : 0u;
+        static_assert (sizeof (art_s) == 4 || LEAN != 2, "4-byte samples");
+#pragma unroll
+        for (int u = 0; u < RL; ++u)
+            if (u < steps) {
+                pre0 [u] [0] = __uint_as_float (__builtin_amdgcn_raw_buffer_load_b32 (rb, (int)(lo + (unsigned int)(u * G) * SZ), 0, 0));
+                pre0 [u] [1] = __uint_as_float (__builtin_amdgcn_raw_buffer_load_b32 (rb, (int)(hi - (unsigned int)(u * G) * SZ), 0, 0));
+                if constexpr (INTERP) {
+                    pre1 [u] [0] = __uint_as_float (__builtin_amdgcn_raw_buffer_load_b32 (rb, (int)(lo + (unsigned int)(u * G) * SZ), (int) next_row, 0));
+                    pre1 [u] [1] = __uint_as_float (__builtin_amdgcn_raw_buffer_load_b32 (rb, (int)(hi - (unsigned int)(u * G) * SZ), (int) next_row, 0));
+                }
+            }
+    }
 
     if constexpr (PIPE) {
         // (four loads in flight per thread: one at a time, a long span's rounds are as many trips to memory)
@@ -179,7 +205,7 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
                 }
                 if (i0 + STRIDE < cnt) fetch (index_of (i0 + STRIDE), 0);      // (the next output's first round travels under this one's reduction)
             }
-            else if constexpr (LEAN) {
+            else if constexpr (LEAN != 0) {
                 // The plain loop below, instruction for instruction leaner (the kernel is bound by vector-instruction ISSUE — ~210 wave
                 // instructions per pass of two outputs for its 12 packed multiply-adds at 380 taps, profiles/r5_config_e.txt; the shelved cell kernel is in git history, tools/attic/ up to round 5 —
                 // not by the trips its loads make): R steps at a time, their coefficient loads (buffer loads: one address per lane and
@@ -200,9 +226,15 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
                         if (r0 + u < steps) {
                             // (the last step of a row may lie past its half for the upper lanes: what they read — taps of the row's other half, inside
                             // the row and the window — is dropped below)
+                            if (LEAN == 2 && r0 == 0 && i0 == wave * SUBS) {       // (the wave's first output: its first round came in before the staging)
+                                c0v [u] [0] = pre0 [u] [0]; c0v [u] [1] = pre0 [u] [1];
+                                if (INTERP) { c1v [u] [0] = pre1 [u] [0]; c1v [u] [1] = pre1 [u] [1]; }
+                            }
+                            else {
                             c0v [u] [0] = tap (lo + (unsigned int)(u * G) * SZ, 0u);
                             c0v [u] [1] = tap (hi - (unsigned int)(u * G) * SZ, 0u);
                             if (INTERP) { c1v [u] [0] = tap (lo + (unsigned int)(u * G) * SZ, next_row); c1v [u] [1] = tap (hi - (unsigned int)(u * G) * SZ, next_row); }
+                            }
 #pragma unroll
                             for (int c = 0; c < CG; ++c) { xv [u] [0] [c] = xl [(size_t)(u * G) * CG + c]; xv [u] [1] [c] = (xh - (size_t)(u * G) * CG) [c]; }
                         }
@@ -299,7 +331,7 @@ __device__ __forceinline__ void fir_general_body (const ArtFirArgs &a, const Art
   }
 }
 
-template <int CG, bool INTERP, bool PRECISE, int G, bool PIPE, bool LEAN>
+template <int CG, bool INTERP, bool PRECISE, int G, bool PIPE, int LEAN>
 __global__ __launch_bounds__ (GEN_THREADS)
 void fir_general_kernel (ArtFirArgs a, ArtSegTable segs, int tile)
 {
@@ -460,8 +492,12 @@ int launch_general (const ArtFirArgs &a, const ArtSegTable &segs, hipStream_t st
     static const bool pipe_on = [] { const char *e = getenv ("ARTAMD_GENERAL_PIPE"); return !(e && *e == '0'); } ();      // (A/B runs and the bit-identity test)
 
 #define GO(I, P) do { const int gg = general_group (a.T); if (gg == 16) GO_ (I, P, 16); else if (gg == 32) GO_ (I, P, 32); else GO_ (I, P, 64); } while (0)
-    static const bool lean_on = [] { const char *e = getenv ("ARTAMD_GENERAL_LEAN"); return !(e && *e == '0'); } ();      // (likewise: =0 pins the plain loop)
-#define GO_(I, P, GG) do { if (CG >= 4 && a.T >= 512 && pipe_on) GO__ (I, P, GG, (CG >= 4), false); else if (lean_on && CG <= 2) GO__ (I, P, GG, false, (CG <= 2)); else GO__ (I, P, GG, false, false); } while (0)
+    // (ARTAMD_GENERAL_LEAN: 0 pins the plain loop, 1 round 5's lean loop; default 2 = the lean loop, and for STEREO streams its first round's coefficient loads issued
+    // before the staging — config E 12.5 -> 12.0 us a call, stereo interpolating 16.6 -> 16.4; mono loses (68 -> 78 registers: 11.0 against 10.2 us) and keeps 1:
+    // tools/micro/general_lean_first.sh, profiles/r6_config_e.txt)
+    static const int lean_on = [] { const char *e = getenv ("ARTAMD_GENERAL_LEAN"); return e && *e >= '0' && *e <= '2' ? *e - '0' : 2; } ();
+#define GO_(I, P, GG) do { if (CG >= 4 && a.T >= 512 && pipe_on) GO__ (I, P, GG, (CG >= 4), 0); else if (lean_on == 2 && CG == 2 && sizeof (art_s) == 4) GO__ (I, P, GG, false, (CG == 2 && sizeof (art_s) == 4 ? 2 : 0)); \
+        else if (lean_on && CG <= 2) GO__ (I, P, GG, false, (CG <= 2 ? 1 : 0)); else GO__ (I, P, GG, false, 0); } while (0)
 #define GO__(I, P, GG, PP, LL) do { auto k = fir_general_kernel<CG, I, P, GG, PP, LL>; \
         if (lds > 48 * 1024) (void) hipFuncSetAttribute ((const void *) k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
         hipLaunchKernelGGL (k, grid, dim3 (GEN_THREADS), lds, st, a, segs, tile); } while (0)
